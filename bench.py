@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the full DCGAN G+D training step (train/dcgan_trainer.py:155-189 of the
+reference), 64x64x3 synthetic images, batch 256 per GPU, on the MI355X-native HIP path.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; data parallel = replicate, shard the batch, all-reduce D and G gradients with RCCL
+(torch.distributed "nccl") - D's all-reduce overlaps the gradient-penalty pass.  Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM, including the RNG draws
+(instance noise x2, z, GP alpha), four D passes, one G pass, five backward chains, two Adam steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "jck-generation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+# algorithmic MACs per image: D forward, G forward and their pieces
+D_FWD, D_CONV1, G_FWD, G_CONV1 = 103_817_216, 3_145_728, 104_628_224, 819_200
+
+
+def step_flops_per_image(dead_wgrad=False):
+    """FLOPs of the work the engine performs per image and step (2 FLOP per MAC)."""
+    mac = 4 * D_FWD + G_FWD                              # forward passes
+    mac += 2 * (D_FWD + (D_FWD - D_CONV1))               # D backward for real and fake: wgrad + dgrad without conv1
+    mac += D_FWD                                         # gradient-penalty pass: full dgrad chain
+    mac += D_FWD                                         # G phase: dgrad through D to the image
+    if dead_wgrad:
+        mac += D_FWD                                     # the reference also forms D's (dead) weight gradients here
+    mac += G_FWD + (G_FWD - G_CONV1)                     # G backward: wgrad + dgrad without conv1
+    return 2 * mac
+
+
+def cpu_baseline(batch, seconds_budget=25.0):
+    """The CPU oracle (a restatement of the reference's step, pinned to it by tests/golden) timed on the host cores."""
+    import torch
+    from oracle.gan_oracle import GanOracle
+    torch.manual_seed(0)
+    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+    g = torch.Generator().manual_seed(2024)
+    real = torch.rand(batch, 3, 64, 64, generator=g) * 2 - 1
+    cores = torch.get_num_threads()
+    orc.step(real)                                       # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while True:
+        orc.step(real)
+        n += 1
+        dt = time.time() - t0
+        if dt > seconds_budget or n >= 12:
+            break
+    return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} full G+D steps at batch {batch} after 1 warm-up ({dt:.1f} s), torch fp32 CPU oracle "
+                      f"(oracle/gan_oracle.py), anomaly detection off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from hipgan.engine import DcganEngine
+    from hipgan.dist import GradReducer
+    from hipgan import lib
+    from model import DCGAN
+
+    B = a.batch
+    dev = torch.device("cuda", local)
+    eng = DcganEngine(batch=B, prec=a.prec, device=dev)
+    torch.manual_seed(12345)                            # change_randomseed.py:1 - identical weights on every rank
+    net_g, net_d = DCGAN.Generator(), DCGAN.Discriminator()
+    net_g.apply(DCGAN.weights_init)
+    net_d.apply(DCGAN.weights_init)
+    eng.load_state(net_g.state_dict(), net_d.state_dict())
+    gen = torch.Generator(device=dev).manual_seed(2024 + rank)
+    batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    red = GradReducer(world) if world > 1 else None
+
+    def one_step(i):
+        noise = eng.draw_noise(gen)                     # device-side RNG, inside the step like the reference
+        if red:
+            eng.step_async(batches[i % 4], noise, 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
+        else:
+            eng.step_async(batches[i % 4], noise, 2e-4)
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    scal = eng.scalars()
+    ms = dt / a.steps * 1e3
+    value = world * B * a.steps / dt
+
+    out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": a.prec if a.prec == "bf16" else "f32(split-bf16x3)",
+           "data": "synthetic",
+           "config": {"workload": f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
+                                  f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})",
+                      "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                      "dead_D_wgrad_in_G_phase": "skipped (never observable: zeroed at train/dcgan_trainer.py:155)"},
+           "losses_last_step": {k: round(v, 5) for k, v in scal.items() if k in ("loss_d", "loss_g", "gp")}}
+    fl = step_flops_per_image() * B
+    out["step_mfma"] = {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                        "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    if rank == 0 and not a.no_roofline:
+        import ctypes as C
+        lib.jck_prof_enable(1)
+        for i in range(3):
+            one_step(i)
+        torch.cuda.synchronize()
+        lib.jck_prof_enable(0)
+        cap = 32
+        names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        n = lib.jck_prof_collect(cap, names, cnt, msv, flv)
+        rows = [{"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i],
+                 "ms_per_step": msv[i] / 3, "tflops": flv[i] / (msv[i] * 1e-3) / 1e12} for i in range(n)]
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        if rows:
+            d = rows[0]
+            out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5),
+                               "launches_per_step": d["launches_per_step"],
+                               "method": "HIP events around every launch on the launch stream, 3 extra steps after the timed region"}
+            out["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+            out["mfma_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 4)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

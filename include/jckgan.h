@@ -1,0 +1,174 @@
+/* jckgan.h - C ABI of libjckgan_hip.so: the MI355X (gfx950) replacement for the DCGAN / CGAN
+ * training hot path of hy-vision-learning/jck-generation.
+ *
+ * The reference has no FFI layer of its own: its hot path is torch.nn modules + autograd
+ * (model/DCGAN.py, model/CGAN.py, train/dcgan_trainer.py, train/cgan_trainer.py).  Every entry
+ * point below names the reference call site (file:line under the reference root) whose ATen work it
+ * replaces.  The Python side (jck-generation_amd/hipgan) binds these symbols with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes, `void* stream` = hipStream_t (NULL = default)
+ *   - every function returns 0 on success, a negative JCK_E_* code on error; jck_last_error()
+ *     returns the message of the calling thread's last failure
+ *   - no allocation, no ownership transfer: outputs and workspaces are caller-allocated
+ *   - asynchronous with respect to the host; thread-compatible (one stream per caller thread)
+ *   - `prec` selects storage / arithmetic:
+ *       JCK_PREC_BF16  activations + gradients bf16 in HBM, bf16 MFMA, fp32 accumulate   (fast)
+ *       JCK_PREC_F32   activations + gradients fp32 in HBM, split-bf16 x3 MFMA (~2^-16) (parity)
+ *     "T" below means bf16 (2 bytes) or float according to `prec`
+ *   - activations are NHWC; 3-channel images are stored with 4 channels (4th = 0)
+ *   - a stride-2 stage is described by its BIG side [N,Hb,Wb,Cb] and SMALL side [N,Hb/2,Wb/2,Cs];
+ *     Conv2d (D) maps big->small, ConvTranspose2d (G) maps small->big; both keep the weight as
+ *     [Cs][Cb][4][4] fp32 (Conv2d.weight [Cout,Cin,4,4] / ConvTranspose2d.weight [Cin,Cout,4,4])
+ */
+#ifndef JCKGAN_H
+#define JCKGAN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JCK_PREC_BF16 0
+#define JCK_PREC_F32 1
+
+#define JCK_OK 0
+#define JCK_E_ARG (-1)      /* bad argument / unsupported shape */
+#define JCK_E_HIP (-2)      /* HIP runtime error (see jck_last_error) */
+#define JCK_E_WS (-3)       /* workspace too small */
+
+const char* jck_last_error(void);
+int jck_version(void);
+/* rows of a packed weight matrix for `c` output channels (tile padding): 16, 64 or a multiple of 128 */
+int jck_pad_rows(int c);
+/* channels per pixel as stored in HBM: 3 -> 4, otherwise c (must be a power of two) */
+int jck_pad_chan(int c);
+
+/* ---- weight packing: fp32 parameter -> bf16 GEMM operand planes (hi, and lo for JCK_PREC_F32; lo may be NULL) ----
+ * down : [pad_rows(Cs)][16*pad_chan(Cb)]      operand of Conv2d forward / ConvTranspose2d dgrad
+ * up   : [4][pad_rows(Cb)][4*Cs]              operand of ConvTranspose2d forward / Conv2d dgrad
+ * g1   : [16*Co][CiPad]                       G.conv1, ConvTranspose2d(k4,s1,p0) on a 1x1 input (model/DCGAN.py:42)
+ * head : float[16*C]                          D.conv5, Conv2d(512,1,k4,s1,p0) as a dot product (model/DCGAN.py:26) */
+int jck_pack_down(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream);
+int jck_pack_up(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream);
+int jck_pack_g1(const float* w, int Ci, int Co, int CiPad, void* hi, void* lo, void* stream);
+int jck_pack_head(const float* w, int C, float* wp, void* stream);
+
+/* ---- convolution-shaped products (replace aten::convolution / convolution_backward) -----------------------
+ * stats: float[2*C] (sum, sum of squares per output channel, ACCUMULATED into - zero it first) or NULL */
+/* small = Conv2d_k4s2p1(big)            model/DCGAN.py:10-22 forward; dgrad of model/DCGAN.py:46-58 */
+int jck_conv_down(int prec, const void* big, const void* w_hi, const void* w_lo, void* small_out, float* stats,
+                  int N, int Hb, int Wb, int Cb, int Cs, void* stream);
+/* big = ConvTranspose2d_k4s2p1(small)   model/DCGAN.py:46-58 forward; dgrad of model/DCGAN.py:10-22.  epi_tanh=1 fuses model/DCGAN.py:66 */
+int jck_conv_up(int prec, const void* small_in, const void* w_hi, const void* w_lo, void* big_out, float* stats,
+                int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream);
+/* grad[Cs][Cb][4][4] (+)= sum small (x) gather(big)     weight gradient of either layer kind */
+size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs);
+int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes, float* grad,
+                   int accumulate, int N, int Hb, int Wb, int Cb, int Cs, void* stream);
+/* out[B][16*Co] = z[B][CiPad] x W   (NHWC [B,4,4,Co]); stats over Co channels   model/DCGAN.py:42,62 */
+int jck_g1_fwd(int prec, const void* z, const void* w_hi, const void* w_lo, void* out, float* stats, int B, int CiPad,
+               int Co, void* stream);
+size_t jck_g1_wgrad_ws_bytes(int B, int CiPad, int Co);
+int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, size_t ws_bytes, float* grad, int accumulate, int B,
+                 int Ci, int CiPad, int Co, void* stream);
+
+/* ---- BatchNorm2d (training mode) + ReLU / LeakyReLU  (model/DCGAN.py:11-24,43-56; aten::native_batch_norm*) ----
+ * aux: float[4*C] = scale(gamma*invstd) | shift | mean | invstd, produced by jck_bn_finalize */
+int jck_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* aux, int C,
+                    void* stream);
+int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void* a, long long rows, int C, void* stream);
+/* sums: float[2*C] zeroed by the caller; g_y may alias g_a */
+int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                   float* dgamma, float* dbeta, long long rows, int C, void* stream);
+
+/* ---- images, noise, heads, loss ----------------------------------------------------------------------------- */
+/* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */
+int jck_img_prep(int prec, const float* img_nchw, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,
+                 void* stream);
+int jck_nhwc4_to_nchw(int prec, const void* in, float* out_nchw, int N, int HW, void* stream);
+/* out = keep*x + mix*noise for an NHWC4 x                                      train/dcgan_trainer.py:171 */
+int jck_axpy_noise(int prec, const void* x, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,
+                   void* stream);
+/* x_hat = alpha*a + (1-alpha)*b                                                 train/dcgan_trainer.py:111-112 */
+int jck_interp(int prec, const void* a, const void* b, const float* alpha, void* out, int N, int HW, void* stream);
+/* scal[slot] += sum_n (||g[n]||_2 - 1)^2 ; norms[n] optional                    train/dcgan_trainer.py:125-126 */
+int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, float* norms, void* stream);
+/* g_out = scale * g * (1 - y^2)                                                 tanh backward, model/DCGAN.py:66 */
+int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out, long long numel, void* stream);
+/* D head: logit = <a4[n], wp>, p = sigmoid (model/DCGAN.py:34), BCELoss with the -100 clamp (train/dcgan_trainer.py:64,163);
+ * mode 0: ds = dLoss/dlogit for mean BCE against `target`; scal[slot_loss] += sum loss_n; mode 1: ds = p(1-p) (GP pass).
+ * scal[slot_p] += sum p.  slot < 0 disables. */
+int jck_head_fwd(int prec, const void* a4, const float* wp, int B, int K, float target, int mode, float* prob, float* ds,
+                 float* scal, int slot_loss, int slot_p, void* stream);
+int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int B, int K, void* g_a4, float* dwp,
+                 int accumulate, void* stream);
+/* grad[1][C][4][4] (+)= dwp (packed (h,w,c) order) */
+int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream);
+
+/* ---- optimiser (torch.optim.Adam as built at train/dcgan_trainer.py:61-62) over a flat fp32 arena ---------- */
+int jck_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+             int step, float grad_scale, void* stream);
+
+/* ---- whole-step engine (train/dcgan_trainer.py:155-189 as one native schedule) --------------------------- */
+typedef struct jck_engine jck_engine;
+/* family 0 = DCGAN.  Layout queries let the host build flat parameter arenas with the reference's state-dict order. */
+int jck_engine_create(jck_engine** out, int family, int prec, int batch);
+void jck_engine_destroy(jck_engine*);
+int jck_engine_num_tensors(int family, int net /*0=G,1=D*/);
+/* kind: 0 = parameter, 1 = running_mean, 2 = running_var ; name buffer gets the state-dict key */
+int jck_engine_tensor_info(int family, int net, int idx, char* name, int name_cap, int* kind, long long* offset,
+                           long long* numel, int* shape4);
+size_t jck_engine_workspace_bytes(const jck_engine*);
+/* arenas: params/grads/m/v are flat fp32 of jck_engine_arena_numel(net, 0); bn = running stats arena (kind 1,2);
+ * nbt = int64[4] per net */
+long long jck_engine_arena_numel(int family, int net, int which /*0 params, 1 bn buffers*/);
+int jck_engine_bind(jck_engine*, void* workspace, size_t ws_bytes, float* g_params, float* g_grads, float* g_m, float* g_v,
+                    float* g_bn, int64_t* g_nbt, float* d_params, float* d_grads, float* d_m, float* d_v, float* d_bn,
+                    int64_t* d_nbt);
+/* re-derive the bf16 GEMM operand planes from the fp32 parameters (after init / load_state_dict) */
+int jck_engine_repack(jck_engine*, int net, void* stream);
+/* phases of one step; between them the host may all-reduce the grads arenas (data parallel).
+ *   PHASE_D_LOSS : zero D grads; D(real'), D(fake): forward+backward; G forward   (dcgan_trainer.py:155-176)
+ *   PHASE_D_GP   : gradient-penalty pass (value only in DCGAN)                     (:178-179)
+ *   PHASE_D_STEP : Adam on D, repack D                                             (:180)
+ *   PHASE_G_LOSS : zero G grads; D(fake) with the new D; backward into G           (:182-188)
+ *   PHASE_G_STEP : Adam on G, repack G, finalise the scalars                       (:189) */
+#define JCK_PHASE_D_LOSS 0
+#define JCK_PHASE_D_GP 1
+#define JCK_PHASE_D_STEP 2
+#define JCK_PHASE_G_LOSS 3
+#define JCK_PHASE_G_STEP 4
+typedef struct jck_step_inputs {
+  const float* real_nchw; /* [B,3,64,64] fp32 */
+  const float* noise_real; /* [B,3,64,64] N(0,1) */
+  const float* z;          /* [B,100] N(0,1) */
+  const float* noise_fake; /* [B,3,64,64] N(0,1) */
+  const float* alpha;      /* [B] U[0,1) */
+  float lr;
+  float grad_scale;        /* 1/world_size when grads were SUM-all-reduced, else 1 */
+  int step;                /* 1-based optimiser step (Adam bias correction) */
+} jck_step_inputs;
+int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
+/* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
+const float* jck_engine_scalars(const jck_engine*);
+/* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */
+int jck_engine_sample(jck_engine*, const float* z, int n, float* out_nchw, void* stream);
+/* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */
+const void* jck_engine_tensor(const jck_engine*, const char* name, long long* numel);
+
+/* per-launch HIP-event timing of the MFMA kernels (bench.py roofline leg).  enable(1) ... run ... collect():
+ * per kernel variant: launches, total milliseconds, total algorithmic FLOPs.  Returns the number of rows. */
+int jck_prof_enable(int on);
+int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out);
+
+/* debug probe: lane l of one wave returns the 8 elements wgrad's transposed LDS read hands it from a
+ * [32][ld] 16-bit tile: out[l*8+j] must equal in[(8*(l>>4)+j)*ld + (l&15)] */
+int jck_debug_tr_read(const void* in, int ld, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

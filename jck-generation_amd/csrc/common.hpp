@@ -1,0 +1,134 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the DCGAN/CGAN hot path.
+// Wave = 64 lanes, MFMA v_mfma_f32_16x16x32_bf16, LDS tiles with 16-byte padded rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                     // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;         // one MFMA A/B fragment (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;           // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define JCK_WAVE 64
+
+// ---- precision tags -----------------------------------------------------------------------------
+// Bf16 : activations stored bf16, one MFMA per product           (fast mode)
+// F32  : activations stored f32, every operand split hi+lo bf16, three MFMAs per product
+//        (a*b ~= ah*bh + ah*bl + al*bh, relative error ~2^-16)   (parity mode)
+struct PrecBf16 { typedef bf16_t T; static constexpr int NPLANE = 1; };
+struct PrecF32  { typedef float  T; static constexpr int NPLANE = 2; };
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                  // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+// split f into hi + lo bf16 (lo = rne(f - hi))
+__device__ __forceinline__ void split_bf(float f, bf16_t& hi, bf16_t& lo) {
+  hi = f2bf(f);
+  lo = f2bf(f - bf2f(hi));
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---- 8-element vector load/store of T as floats ------------------------------------------------------
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = r;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+  u32x2 r = *reinterpret_cast<const u32x2*>(p);
+  v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+  v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
+  u32x2 r; r[0] = pack2bf(v[0], v[1]); r[1] = pack2bf(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(p) = r;
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+  f32x4 a; a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+
+// ---- wave reductions ---------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 16 lanes that share (lane>>4)
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum256(float v, float* sm /* >= 4 floats */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// ---- MFMA --------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4)+j][col l&15],
+// C/D[row = 4*(l>>4) + reg][col = l&15].
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* p) {      // 16-byte aligned LDS read
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+// ds_read_b64_tr_b16: per 16-lane group reads a 4(row) x 16(col) block of 16-bit elements and hands
+// lane i of the group column i (rows 0..3).  Lane 4q+p of the group supplies &block[row q][col 4p].
+__device__ __forceinline__ short4v lds_tr4(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (short4v __attribute__((address_space(3)))*)(const_cast<bf16_t*>(p)));
+}
+__device__ __forceinline__ bf16x8 join_tr(short4v a, short4v b) {
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// 8 consecutive elements of T held in registers between the global load and the LDS store
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { u32x4 v; };
+template <> struct Raw8<float> { f32x4 a, b; };
+
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,406 @@
+// Whole-step engine: the reference's training iteration (train/dcgan_trainer.py:155-189) as one native
+// schedule of kernel launches on a HIP stream.  The host makes one call per phase; nothing in here
+// allocates, synchronises or reads back - scalars stay on the device until the trainer logs them.
+#include <cstring>
+#include <vector>
+
+#include "ops_internal.hpp"
+
+namespace {
+
+struct TensorInfo { const char* name; int kind; long long offset, numel; int shape[4]; };
+
+struct NetLayout {
+  std::vector<TensorInfo> t;
+  long long n_params = 0, n_bn = 0;
+};
+
+constexpr long long ALIGN_F = 64;   // floats
+
+void add_param(NetLayout& L, const char* name, int a, int b, int c, int d) {
+  TensorInfo ti{name, 0, L.n_params, (long long)a * b * c * d, {a, b, c, d}};
+  L.t.push_back(ti);
+  L.n_params = (L.n_params + ti.numel + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
+}
+void add_bn(NetLayout& L, const char* wn, const char* bn, const char* rm, const char* rv, int c) {
+  add_param(L, wn, c, 1, 1, 1);
+  add_param(L, bn, c, 1, 1, 1);
+  TensorInfo m{rm, 1, L.n_bn, c, {c, 1, 1, 1}};
+  L.t.push_back(m);
+  L.n_bn += (c + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
+  TensorInfo v{rv, 2, L.n_bn, c, {c, 1, 1, 1}};
+  L.t.push_back(v);
+  L.n_bn += (c + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
+}
+
+// channel plan (model/DCGAN.py:10-26, :42-58)
+const int D_CS[4] = {64, 128, 256, 512}, D_CB[4] = {3, 64, 128, 256}, D_HB[4] = {64, 32, 16, 8};
+const int G_CS[4] = {512, 256, 128, 64}, G_CB[4] = {256, 128, 64, 3}, G_HS[4] = {4, 8, 16, 32};   // conv2..conv5
+const int G_C1 = 512, Z_DIM = 100, Z_PAD = 128;
+
+NetLayout make_layout(int family, int net) {
+  (void)family;
+  NetLayout L;
+  static const char* CW[5] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight"};
+  static const char* NW[4] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight"};
+  static const char* NB[4] = {"norm1.bias", "norm2.bias", "norm3.bias", "norm4.bias"};
+  static const char* RM[4] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean"};
+  static const char* RV[4] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var"};
+  if (net == 0) {
+    add_param(L, CW[0], Z_DIM, G_C1, 4, 4);
+    add_bn(L, NW[0], NB[0], RM[0], RV[0], G_C1);
+    for (int i = 0; i < 4; ++i) {
+      add_param(L, CW[i + 1], G_CS[i], G_CB[i], 4, 4);
+      if (i < 3) add_bn(L, NW[i + 1], NB[i + 1], RM[i + 1], RV[i + 1], G_CB[i]);
+    }
+  } else {
+    for (int i = 0; i < 4; ++i) {
+      add_param(L, CW[i], D_CS[i], D_CB[i], 4, 4);
+      add_bn(L, NW[i], NB[i], RM[i], RV[i], D_CS[i]);
+    }
+    add_param(L, CW[4], 1, 512, 4, 4);
+  }
+  return L;
+}
+
+const TensorInfo* find(const NetLayout& L, const char* name) {
+  for (auto& t : L.t) if (!strcmp(t.name, name)) return &t;
+  return nullptr;
+}
+
+struct Carver {
+  size_t off = 0;
+  unsigned char* base = nullptr;
+  template <typename T> T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = (off + count * sizeof(T) + 255) / 256 * 256;
+    return p;
+  }
+};
+
+struct BnBuf { float *stats, *sums, *aux; };
+
+}  // namespace
+
+struct jck_engine {
+  int family, prec, B;
+  size_t esz;
+  NetLayout LG, LD;
+  size_t ws_bytes = 0;
+  bool bound = false;
+  // arenas
+  float *gp = nullptr, *gg = nullptr, *gm = nullptr, *gv = nullptr, *gbn = nullptr;
+  float *dp = nullptr, *dg = nullptr, *dm = nullptr, *dv = nullptr, *dbn = nullptr;
+  int64_t *gnbt = nullptr, *dnbt = nullptr;
+  // packed weights
+  void *d_down_hi[4], *d_down_lo[4], *d_up_hi[4], *d_up_lo[4];
+  float *d_head_wp, *d_head_dwp;
+  void *g1_hi, *g1_lo, *g_up_hi[4], *g_up_lo[4], *g_down_hi[4], *g_down_lo[4];
+  // activations
+  void *d_y[4], *d_a[4], *d_g[4], *d_gx;
+  void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
+  void *real_noisy, *xhat;
+  // small buffers
+  unsigned char* zero_d; size_t zero_d_bytes;      // stats + sums of D's 4 layers
+  unsigned char* zero_g; size_t zero_g_bytes;
+  BnBuf d_bn[4], g_bn[4];
+  float *acc, *scal_out, *prob, *ds, *norms;
+  float* wg_ws; size_t wg_ws_bytes;
+
+  void carve(unsigned char* base) {
+    Carver c; c.base = base;
+    const size_t e = esz;
+    auto bytes = [&](size_t n) { return n * e; };
+    for (int i = 0; i < 4; ++i) {
+      const size_t nd = (size_t)jck_pad_rows(D_CS[i]) * 16 * jck_pad_chan(D_CB[i]);
+      d_down_hi[i] = c.take<bf16_t>(nd); d_down_lo[i] = c.take<bf16_t>(nd);
+      const size_t nu = (size_t)4 * jck_pad_rows(D_CB[i]) * 4 * D_CS[i];
+      d_up_hi[i] = c.take<bf16_t>(nu); d_up_lo[i] = c.take<bf16_t>(nu);
+    }
+    d_head_wp = c.take<float>(8192); d_head_dwp = c.take<float>(8192);
+    g1_hi = c.take<bf16_t>((size_t)16 * G_C1 * Z_PAD); g1_lo = c.take<bf16_t>((size_t)16 * G_C1 * Z_PAD);
+    for (int i = 0; i < 4; ++i) {
+      const size_t nu = (size_t)4 * jck_pad_rows(G_CB[i]) * 4 * G_CS[i];
+      g_up_hi[i] = c.take<bf16_t>(nu); g_up_lo[i] = c.take<bf16_t>(nu);
+      const size_t nd = (size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i]);
+      g_down_hi[i] = c.take<bf16_t>(nd); g_down_lo[i] = c.take<bf16_t>(nd);
+    }
+    const size_t img = (size_t)B * 64 * 64 * 4;
+    for (int i = 0; i < 4; ++i) {
+      const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+      d_y[i] = c.take<unsigned char>(bytes(n)); d_a[i] = c.take<unsigned char>(bytes(n)); d_g[i] = c.take<unsigned char>(bytes(n));
+    }
+    d_gx = c.take<unsigned char>(bytes(img));
+    g_z = c.take<unsigned char>(bytes((size_t)B * Z_PAD));
+    // G layer i (0..3): output of conv(i+1) = [B, h, h, C] with (h, C) = (4,512), (8,256), (16,128), (32,64)
+    for (int i = 0; i < 4; ++i) {
+      const int h = 4 << i, C = 512 >> i;
+      const size_t n = (size_t)B * h * h * C;
+      g_y[i] = c.take<unsigned char>(bytes(n)); g_a[i] = c.take<unsigned char>(bytes(n)); g_gr[i] = c.take<unsigned char>(bytes(n));
+    }
+    fake_raw = c.take<unsigned char>(bytes(img)); fake = c.take<unsigned char>(bytes(img)); g_raw = c.take<unsigned char>(bytes(img));
+    real_noisy = c.take<unsigned char>(bytes(img)); xhat = c.take<unsigned char>(bytes(img));
+    // zeroed-per-pass regions
+    {
+      size_t start = c.off;
+      zero_d = base ? base + start : nullptr;
+      for (int i = 0; i < 4; ++i) { d_bn[i].stats = c.take<float>(2 * D_CS[i]); d_bn[i].sums = c.take<float>(2 * D_CS[i]); }
+      zero_d_bytes = c.off - start;
+      for (int i = 0; i < 4; ++i) d_bn[i].aux = c.take<float>(4 * D_CS[i]);
+      start = c.off;
+      zero_g = base ? base + start : nullptr;
+      for (int i = 0; i < 4; ++i) { const int C = 512 >> i; g_bn[i].stats = c.take<float>(2 * C); g_bn[i].sums = c.take<float>(2 * C); }
+      zero_g_bytes = c.off - start;
+      for (int i = 0; i < 4; ++i) g_bn[i].aux = c.take<float>(4 * (512 >> i));
+    }
+    acc = c.take<float>(16); scal_out = c.take<float>(8);
+    prob = c.take<float>(B); ds = c.take<float>(B); norms = c.take<float>(B);
+    size_t w = 0;
+    for (int i = 0; i < 4; ++i) {
+      w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
+      w = std::max(w, jck_conv_wgrad_ws_bytes(B, G_HS[i] * 2, G_HS[i] * 2, G_CB[i], G_CS[i]));
+    }
+    w = std::max(w, jck_g1_wgrad_ws_bytes(B, Z_PAD, G_C1));
+    wg_ws_bytes = w;
+    wg_ws = c.take<float>(w / 4);
+    ws_bytes = c.off;
+  }
+
+  float* P(const NetLayout& L, float* arena, const char* name) const { return arena + find(L, name)->offset; }
+};
+
+static const char* NAMES_CW[5] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight"};
+static const char* NAMES_NW[4] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight"};
+static const char* NAMES_NB[4] = {"norm1.bias", "norm2.bias", "norm3.bias", "norm4.bias"};
+static const char* NAMES_RM[4] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean"};
+static const char* NAMES_RV[4] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var"};
+
+extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int batch) {
+  if (!out) JCK_FAIL(JCK_E_ARG, "null out");
+  if (family != 0) JCK_FAIL(JCK_E_ARG, "only family 0 (DCGAN) has a native step engine in this build");
+  if (prec != JCK_PREC_BF16 && prec != JCK_PREC_F32) JCK_FAIL(JCK_E_ARG, "bad prec");
+  if (batch < 1 || batch > 8192) JCK_FAIL(JCK_E_ARG, "batch must be in [1, 8192]");
+  jck_engine* e = new jck_engine();
+  e->family = family; e->prec = prec; e->B = batch; e->esz = prec == JCK_PREC_BF16 ? 2 : 4;
+  e->LG = make_layout(family, 0); e->LD = make_layout(family, 1);
+  e->carve(nullptr);
+  *out = e;
+  return JCK_OK;
+}
+extern "C" void jck_engine_destroy(jck_engine* e) { delete e; }
+extern "C" int jck_engine_num_tensors(int family, int net) { return (int)make_layout(family, net).t.size(); }
+extern "C" int jck_engine_tensor_info(int family, int net, int idx, char* name, int name_cap, int* kind, long long* offset,
+                                      long long* numel, int* shape4) {
+  NetLayout L = make_layout(family, net);
+  if (idx < 0 || idx >= (int)L.t.size()) JCK_FAIL(JCK_E_ARG, "index out of range");
+  const TensorInfo& t = L.t[idx];
+  if (name && name_cap > 0) { strncpy(name, t.name, name_cap - 1); name[name_cap - 1] = 0; }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  return JCK_OK;
+}
+extern "C" long long jck_engine_arena_numel(int family, int net, int which) {
+  NetLayout L = make_layout(family, net);
+  return which == 0 ? L.n_params : L.n_bn;
+}
+extern "C" size_t jck_engine_workspace_bytes(const jck_engine* e) { return e ? e->ws_bytes : 0; }
+
+extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, float* g_params, float* g_grads, float* g_m,
+                               float* g_v, float* g_bn, int64_t* g_nbt, float* d_params, float* d_grads, float* d_m,
+                               float* d_v, float* d_bn, int64_t* d_nbt) {
+  if (!e || !workspace) JCK_FAIL(JCK_E_ARG, "null engine / workspace");
+  if (ws_bytes < e->ws_bytes) JCK_FAIL(JCK_E_WS, "workspace too small: need " + std::to_string(e->ws_bytes));
+  if (((uintptr_t)workspace) % 256) JCK_FAIL(JCK_E_ARG, "workspace must be 256-byte aligned");
+  e->carve(reinterpret_cast<unsigned char*>(workspace));
+  e->gp = g_params; e->gg = g_grads; e->gm = g_m; e->gv = g_v; e->gbn = g_bn; e->gnbt = g_nbt;
+  e->dp = d_params; e->dg = d_grads; e->dm = d_m; e->dv = d_v; e->dbn = d_bn; e->dnbt = d_nbt;
+  e->bound = true;
+  return JCK_OK;
+}
+
+extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (net == 1) {
+    for (int i = 0; i < 4; ++i) {
+      const float* w = e->P(e->LD, e->dp, NAMES_CW[i]);
+      JCK_TRY(jck_pack_down(w, D_CS[i], D_CB[i], e->d_down_hi[i], e->d_down_lo[i], stream));
+      JCK_TRY(jck_pack_up(w, D_CS[i], D_CB[i], e->d_up_hi[i], e->d_up_lo[i], stream));
+    }
+    JCK_TRY(jck_pack_head(e->P(e->LD, e->dp, NAMES_CW[4]), 512, e->d_head_wp, stream));
+  } else {
+    JCK_TRY(jck_pack_g1(e->P(e->LG, e->gp, NAMES_CW[0]), Z_DIM, G_C1, Z_PAD, e->g1_hi, e->g1_lo, stream));
+    for (int i = 0; i < 4; ++i) {
+      const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
+      JCK_TRY(jck_pack_up(w, G_CS[i], G_CB[i], e->g_up_hi[i], e->g_up_lo[i], stream));
+      JCK_TRY(jck_pack_down(w, G_CS[i], G_CB[i], e->g_down_hi[i], e->g_down_lo[i], stream));
+    }
+  }
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------------------------------------
+static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
+
+static int d_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
+  HIPCHK(hipMemsetAsync(e->zero_d, 0, e->zero_d_bytes, st));
+  const void* in = x_in;
+  for (int i = 0; i < 4; ++i) {
+    const int hb = D_HB[i], cs = D_CS[i];
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down_hi[i], e->d_down_lo[i], e->d_y[i], e->d_bn[i].stats, B, hb, hb, D_CB[i], cs, st));
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    JCK_TRY(jck_bn_finalize(e->d_bn[i].stats, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
+                            e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
+                            e->dnbt + i, BN_MOM, BN_EPS, e->d_bn[i].aux, cs, st));
+    JCK_TRY(jck_bn_act_fwd(e->prec, e->d_y[i], e->d_bn[i].aux, LRELU, e->d_a[i], rows, cs, st));
+    in = e->d_a[i];
+  }
+  return JCK_OK;
+}
+
+static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, bool want_xgrad, hipStream_t st) {
+  JCK_TRY(jck_head_bwd(e->prec, e->ds, e->d_head_wp, e->d_a[3], B, 8192, e->d_g[3], want_wgrad ? e->d_head_dwp : nullptr, 0, st));
+  if (want_wgrad) JCK_TRY(jck_head_unpack_grad(e->d_head_dwp, 512, e->P(e->LD, e->dg, NAMES_CW[4]), 1, st));
+  for (int i = 3; i >= 0; --i) {
+    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    JCK_TRY(jck_bn_act_bwd(e->prec, e->d_g[i], e->d_y[i], e->d_bn[i].aux, LRELU, e->d_bn[i].sums, e->d_g[i],
+                           want_wgrad ? e->P(e->LD, e->dg, NAMES_NW[i]) : nullptr,
+                           want_wgrad ? e->P(e->LD, e->dg, NAMES_NB[i]) : nullptr, rows, cs, st));
+    const void* big = i == 0 ? x_in : e->d_a[i - 1];
+    if (want_wgrad)
+      JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    if (i > 0)
+      JCK_TRY(jck_conv_up(e->prec, e->d_g[i], e->d_up_hi[i], e->d_up_lo[i], e->d_g[i - 1], nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+    else if (want_xgrad)
+      JCK_TRY(jck_conv_up(e->prec, e->d_g[0], e->d_up_hi[0], e->d_up_lo[0], e->d_gx, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+  }
+  return JCK_OK;
+}
+
+template <typename T>
+static void launch_pad_rows(const float* z, int B, void* out, hipStream_t st) {
+  const long long total = (long long)B * Z_PAD;
+  hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, B, Z_DIM, Z_PAD, (T*)out);
+}
+
+static int g_forward(jck_engine* e, const float* z, int B, bool update_running, hipStream_t st) {
+  (void)update_running;
+  HIPCHK(hipMemsetAsync(e->zero_g, 0, e->zero_g_bytes, st));
+  if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, e->g_z, st); else launch_pad_rows<float>(z, B, e->g_z, st);
+  HIPCHK(hipGetLastError());
+  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_hi, e->g1_lo, e->g_y[0], e->g_bn[0].stats, B, Z_PAD, G_C1, st));
+  for (int i = 0; i < 4; ++i) {
+    const int h = 4 << i, C = 512 >> i;
+    const long long rows = (long long)B * h * h;
+    JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, (float)rows, e->P(e->LG, e->gp, NAMES_NW[i]), e->P(e->LG, e->gp, NAMES_NB[i]),
+                            e->gbn + find(e->LG, NAMES_RM[i])->offset, e->gbn + find(e->LG, NAMES_RV[i])->offset,
+                            e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
+    JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
+    if (i < 3)
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up_hi[i], e->g_up_lo[i], e->g_y[i + 1], e->g_bn[i + 1].stats, 0, B, h, h, G_CS[i], G_CB[i], st));
+    else
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[3], e->g_up_hi[3], e->g_up_lo[3], e->fake_raw, nullptr, 1, B, 32, 32, 64, 3, st));
+  }
+  return JCK_OK;
+}
+
+// g_fake = gradient w.r.t. the noisy fake image (NHWC4); fills G's grads arena (accumulating)
+static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st) {
+  JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * 64 * 64 * 4, st));
+  const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
+  for (int i = 3; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = G_CS[i]), big side has G_CB[i] channels
+    const int hs = G_HS[i], cs = G_CS[i], cb = G_CB[i];
+    JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[i + 1]), 1, B,
+                           2 * hs, 2 * hs, cb, cs, st));
+    JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down_hi[i], e->g_down_lo[i], e->g_gr[i], nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
+    const long long rows = (long long)B * hs * hs;
+    JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
+                           e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
+    gbig = e->g_gr[i];
+  }
+  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, Z_DIM, Z_PAD, G_C1, st));
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// phases
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in, void* stream) {
+  if (!e || !e->bound || !in) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = e->B, HW = 64 * 64;
+  switch (phase) {
+    case JCK_PHASE_D_LOSS: {
+      if (!in->real_nchw || !in->z) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw and z");
+      HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
+      JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+      JCK_TRY(d_forward(e, e->real_noisy, B, st));                                                // :162
+      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.9f, 0, e->prob, e->ds, e->acc, 0, 3, st));   // :163,165
+      JCK_TRY(d_backward(e, e->real_noisy, B, true, false, st));                                  // :164
+      JCK_TRY(g_forward(e, in->z, B, true, st));                                                  // :168-169
+      JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));     // :171
+      JCK_TRY(d_forward(e, e->fake, B, st));                                                      // :173
+      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.1f, 0, e->prob, e->ds, e->acc, 1, 4, st));   // :174,176
+      JCK_TRY(d_backward(e, e->fake, B, true, false, st));                                        // :175
+      return JCK_OK;
+    }
+    case JCK_PHASE_D_GP: {                                                                        // :110-127, 178
+      if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
+      JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
+      JCK_TRY(d_forward(e, e->xhat, B, st));
+      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.f, 1, e->prob, e->ds, e->acc, -1, -1, st));
+      JCK_TRY(d_backward(e, e->xhat, B, false, true, st));
+      JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, HW, e->acc, 6, e->norms, st));
+      return JCK_OK;
+    }
+    case JCK_PHASE_D_STEP: {                                                                      // :180
+      JCK_TRY(jck_adam(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
+      return jck_engine_repack(e, 1, st);
+    }
+    case JCK_PHASE_G_LOSS: {                                                                      // :182-188
+      HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
+      JCK_TRY(d_forward(e, e->fake, B, st));
+      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.9f, 0, e->prob, e->ds, e->acc, 2, 5, st));
+      // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
+      JCK_TRY(d_backward(e, e->fake, B, false, true, st));
+      JCK_TRY(g_backward(e, e->d_gx, B, st));
+      return JCK_OK;
+    }
+    case JCK_PHASE_G_STEP: {                                                                      // :189
+      JCK_TRY(jck_adam(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
+      JCK_TRY(jck_engine_repack(e, 0, st));
+      hipLaunchKernelGGL(scalars_finalize_kernel, dim3(1), dim3(64), 0, st, e->acc, 1.0f / (float)B, 10.0f, e->scal_out);
+      HIPCHK(hipGetLastError());
+      return JCK_OK;
+    }
+  }
+  JCK_FAIL(JCK_E_ARG, "unknown phase");
+}
+
+extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }
+
+extern "C" int jck_engine_sample(jck_engine* e, const float* z, int n, float* out_nchw, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (n < 1 || n > e->B) JCK_FAIL(JCK_E_ARG, "sample: n must be in [1, batch]");
+  hipStream_t st = (hipStream_t)stream;
+  JCK_TRY(g_forward(e, z, n, true, st));
+  return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, 64 * 64, st);
+}
+
+extern "C" const void* jck_engine_tensor(const jck_engine* e, const char* name, long long* numel) {
+  if (!e || !e->bound || !name) return nullptr;
+  const long long img = (long long)e->B * 64 * 64 * 4;
+  struct { const char* n; const void* p; long long c; } tab[] = {
+      {"fake", e->fake, img}, {"fake_raw", e->fake_raw, img}, {"real_noisy", e->real_noisy, img}, {"xhat", e->xhat, img},
+      {"d_gx", e->d_gx, img}, {"prob", e->prob, e->B}, {"ds", e->ds, e->B}, {"norms", e->norms, e->B}, {"acc", e->acc, 16},
+      {"d_y1", e->d_y[0], (long long)e->B * 32 * 32 * 64}, {"d_a4", e->d_a[3], (long long)e->B * 8192},
+      {"g_y1", e->g_y[0], (long long)e->B * 8192}, {"g_a4", e->g_a[3], (long long)e->B * 32 * 32 * 64}};
+  for (auto& t : tab)
+    if (!strcmp(t.n, name)) { if (numel) *numel = t.c; return t.p; }
+  return nullptr;
+}

@@ -1,0 +1,467 @@
+// C-ABI launchers for the per-op entry points of include/jckgan.h (host side; kernels in *.hpp).
+#include "ops_internal.hpp"
+
+#include <string>
+
+static thread_local std::string g_err;
+void jck_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* jck_last_error(void) { return g_err.c_str(); }
+extern "C" int jck_version(void) { return 100; }
+extern "C" int jck_pad_rows(int c) { return c <= 16 ? 16 : (c <= 64 ? 64 : (c + 127) / 128 * 128); }
+extern "C" int jck_pad_chan(int c) { return c == 3 ? 4 : c; }
+
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's roofline
+// leg).  Off by default: zero cost in the timed region.
+// ---------------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { int variant; double flops; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "igemm<bf16,64,128,img>", "igemm<bf16,64,128>",
+                                  "igemm<bf16,16,256>",  "igemm<f32,128,128>", "igemm<f32,128,64>",      "igemm<f32,64,128,img>",
+                                  "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
+                                  "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
+                                  "wgrad<f32,64,64,img>", "wgrad<f32,64,64>"};
+struct ProfScope {
+  ProfRec r; bool on; hipStream_t st;
+  ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    r.variant = variant; r.flops = flops;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(r.e1, st);
+    g_prof.push_back(r);
+  }
+};
+}  // namespace
+extern "C" int jck_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return JCK_OK;
+}
+// Synchronises the recorded events, accumulates per kernel variant: count, total ms, total algorithmic FLOPs.
+// Returns the number of variants written (<= cap).  name_out[i] points at a static string.
+extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out) {
+  constexpr int NV = sizeof(PROF_NAMES) / sizeof(PROF_NAMES[0]);
+  int cnt[NV] = {0}; double ms[NV] = {0}, fl[NV] = {0};
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.e0, r.e1);
+    if (r.variant >= 0 && r.variant < NV) { cnt[r.variant]++; ms[r.variant] += t; fl[r.variant] += r.flops; }
+    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  int n = 0;
+  for (int v = 0; v < NV && n < cap; ++v)
+    if (cnt[v]) { name_out[n] = PROF_NAMES[v]; count_out[n] = cnt[v]; ms_out[n] = ms[v]; flops_out[n] = fl[v]; ++n; }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gather-GEMM dispatch
+// ---------------------------------------------------------------------------------------------------------
+template <class P, int BCH, int BPIX, int NSUB>
+static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStream_t st) {
+  typedef IgemmCfg<P, BCH, BPIX> C;
+  constexpr int variant = (P::NPLANE == 2 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
+  ProfScope prof(variant, p.flops, st);
+  auto kern = igemm_kernel<P, BCH, BPIX, NSUB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+template <class P>
+static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st) {
+  if (nch_pad % 128 == 0) {
+    if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4-channel gather with >=128 output rows unsupported");
+    // keep >= ~256 workgroups in flight: halve the pixel tile for small pixel counts
+    const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
+    if (wgs >= 256) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st);
+    return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st);
+  }
+  if (nch_pad == 64) {
+    if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st);
+    return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st);
+  }
+  if (nch_pad == 16) {
+    if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4->4 channel product unsupported");
+    return launch_igemm_t<P, 16, 256, 1>(p, nch_pad, phases, st);
+  }
+  JCK_FAIL(JCK_E_ARG, "igemm: unsupported padded row count " + std::to_string(nch_pad));
+}
+
+int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st) {
+  if (p.K % IG_BK != 0) JCK_FAIL(JCK_E_ARG, "igemm: K must be a multiple of 64, got " + std::to_string(p.K));
+  if (p.M <= 0) JCK_FAIL(JCK_E_ARG, "igemm: empty problem");
+  if (prec == JCK_PREC_BF16) return launch_igemm_p<PrecBf16>(p, nch_pad, phases, nsub, st);
+  if (prec == JCK_PREC_F32) {
+    if (!p.w_lo) JCK_FAIL(JCK_E_ARG, "igemm: JCK_PREC_F32 needs the low weight plane");
+    return launch_igemm_p<PrecF32>(p, nch_pad, phases, nsub, st);
+  }
+  JCK_FAIL(JCK_E_ARG, "bad prec");
+}
+
+extern "C" int jck_conv_down(int prec, const void* big, const void* w_hi, const void* w_lo, void* small_out, float* stats,
+                             int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
+  const int cbp = jck_pad_chan(Cb);
+  if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
+    JCK_FAIL(JCK_E_ARG, "conv_down: shapes must be powers of two (Hb,Wb,Cb) and Cs % 4 == 0");
+  if ((long long)N * Hb * Wb * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_down: tensor exceeds 2^31 elements");
+  IgemmParams p = {};
+  p.act = big; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = small_out; p.stats = stats;
+  const int OH = Hb / 2, OW = Wb / 2;
+  p.M = N * OH * OW; p.NchStore = Cs; p.logC = ilog2(cbp); p.K = 16 << p.logC;
+  p.H = Hb; p.W = Wb; p.logOW = ilog2(OW); p.logOHW = ilog2(OH * OW); p.sy = p.sx = 2; p.ntaps = 16;
+  for (int t = 0; t < 16; ++t) { p.dy[0][t] = (signed char)(t / 4 - 1); p.dx[0][t] = (signed char)(t % 4 - 1); }
+  p.osN = (long long)OH * OW * Cs; p.osY = OW * Cs; p.osX = Cs; p.obase[0] = 0;
+  p.cstat = Cs; p.cstat_mask = 0x7fffffff; p.epi = 0; p.w_phase_stride = 0;
+  p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
+  return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream);
+}
+
+extern "C" int jck_conv_up(int prec, const void* small_in, const void* w_hi, const void* w_lo, void* big_out, float* stats,
+                           int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
+  const int cbp = jck_pad_chan(Cb);
+  if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
+    JCK_FAIL(JCK_E_ARG, "conv_up: shapes must be powers of two (Hs,Ws,Cs>=16)");
+  if ((long long)N * Hs * Ws * 4 * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_up: tensor exceeds 2^31 elements");
+  IgemmParams p = {};
+  p.act = small_in; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = big_out; p.stats = stats;
+  p.M = N * Hs * Ws; p.NchStore = cbp; p.logC = ilog2(Cs); p.K = 4 << p.logC;
+  p.H = Hs; p.W = Ws; p.logOW = ilog2(Ws); p.logOHW = ilog2(Hs * Ws); p.sy = p.sx = 1; p.ntaps = 4;
+  static const int DI[2][2] = {{0, -1}, {1, 0}};          // input offset of tap th for output parity ph
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      const int z = ph * 2 + pw;
+      for (int t = 0; t < 4; ++t) { p.dy[z][t] = (signed char)DI[ph][t >> 1]; p.dx[z][t] = (signed char)DI[pw][t & 1]; }
+      p.obase[z] = (ph * 2 * Ws + pw) * cbp;
+    }
+  p.osN = (long long)4 * Hs * Ws * cbp; p.osY = 2 * 2 * Ws * cbp; p.osX = 2 * cbp;
+  p.cstat = cbp; p.cstat_mask = 0x7fffffff; p.epi = epi_tanh ? 1 : 0;
+  const int rows = jck_pad_rows(Cb);
+  p.w_phase_stride = (long long)rows * p.K;
+  if (p.K % 64 != 0) JCK_FAIL(JCK_E_ARG, "conv_up: 4*Cs must be a multiple of 64");
+  p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
+  return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream);
+}
+
+extern "C" int jck_g1_fwd(int prec, const void* z, const void* w_hi, const void* w_lo, void* out, float* stats, int B,
+                          int CiPad, int Co, void* stream) {
+  if (!is_pow2(CiPad) || CiPad < 64 || !is_pow2(Co) || (16 * Co) % 128 != 0)
+    JCK_FAIL(JCK_E_ARG, "g1_fwd: CiPad must be a power of two >= 64, Co a power of two");
+  IgemmParams p = {};
+  p.act = z; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = out; p.stats = stats;
+  p.M = B; p.NchStore = 16 * Co; p.logC = ilog2(CiPad); p.K = CiPad;
+  p.H = 1; p.W = 1; p.logOW = 0; p.logOHW = 0; p.sy = p.sx = 1; p.ntaps = 1;
+  p.dy[0][0] = 0; p.dx[0][0] = 0;
+  p.osN = (long long)16 * Co; p.osY = 0; p.osX = 0; p.obase[0] = 0;
+  p.cstat = Co; p.cstat_mask = Co - 1; p.epi = 0; p.w_phase_stride = 0;
+  p.flops = 2.0 * B * 16.0 * Co * CiPad;
+  return launch_igemm(prec, p, 16 * Co, 1, 1, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------
+struct WgradPlan { int BG, BS, gx, gy, Z, mchunk, CsRows, ncols; size_t ws; };
+
+static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
+  WgradPlan pl;
+  pl.ncols = ncols;
+  pl.BG = (ncols % 128 == 0) ? 128 : 64;
+  pl.BS = (Cs >= 128) ? 128 : 64;
+  pl.gx = cdiv(ncols, pl.BG);
+  pl.gy = cdiv(Cs, pl.BS);
+  pl.CsRows = pl.gy * pl.BS;
+  const int tiles = pl.gx * pl.gy;
+  long long Z = std::max(1, 1024 / tiles);
+  const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
+  Z = std::min(Z, maxZ);
+  long long mchunk = (Mtot + Z - 1) / Z;
+  mchunk = (mchunk + WG_BKP - 1) / WG_BKP * WG_BKP;
+  Z = (Mtot + mchunk - 1) / mchunk;
+  pl.Z = (int)Z; pl.mchunk = (int)mchunk;
+  pl.ws = (size_t)Z * pl.CsRows * ncols * sizeof(float);
+  return pl;
+}
+
+template <class P, int BG, int BS, int NSUB>
+static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  constexpr int variant = 10 + (P::NPLANE == 2 ? 4 : 0) + (BG == 128 ? (BS == 128 ? 0 : 1) : (NSUB == 2 ? 2 : 3));
+  ProfScope prof(variant, p.flops, st);
+  constexpr int LDSB = 2 * P::NPLANE * WG_BKP * ((BG + 16) + (BS + 16)) * 2;
+  auto kern = wgrad_kernel<P, BG, BS, NSUB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.gx, pl.gy, pl.Z), dim3(256), LDSB, st, p);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+template <class P>
+static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, hipStream_t st) {
+  if (pl.BG == 128 && pl.BS == 128 && nsub == 1) return launch_wgrad_t<P, 128, 128, 1>(p, pl, st);
+  if (pl.BG == 128 && pl.BS == 64 && nsub == 1) return launch_wgrad_t<P, 128, 64, 1>(p, pl, st);
+  if (pl.BG == 64 && pl.BS == 64 && nsub == 2) return launch_wgrad_t<P, 64, 64, 2>(p, pl, st);
+  if (pl.BG == 64 && pl.BS == 64 && nsub == 1) return launch_wgrad_t<P, 64, 64, 1>(p, pl, st);
+  JCK_FAIL(JCK_E_ARG, "wgrad: unsupported tile plan");
+}
+
+static int run_wgrad(int prec, WgradParams& p, const WgradPlan& pl, int nsub, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < pl.ws) JCK_FAIL(JCK_E_WS, "wgrad: workspace too small: need " + std::to_string(pl.ws));
+  p.part = ws; p.CsRows = pl.CsRows; p.ncols = pl.ncols; p.mchunk = pl.mchunk;
+  if (prec == JCK_PREC_BF16) return launch_wgrad_p<PrecBf16>(p, pl, nsub, st);
+  if (prec == JCK_PREC_F32) return launch_wgrad_p<PrecF32>(p, pl, nsub, st);
+  JCK_FAIL(JCK_E_ARG, "bad prec");
+}
+
+extern "C" size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs) {
+  return plan_wgrad((long long)N * (Hb / 2) * (Wb / 2), 16 * jck_pad_chan(Cb), Cs).ws;
+}
+
+extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes,
+                              float* grad, int accumulate, int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
+  const int cbp = jck_pad_chan(Cb);
+  if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Cs % 8 != 0) JCK_FAIL(JCK_E_ARG, "conv_wgrad: bad shape");
+  const int OH = Hb / 2, OW = Wb / 2;
+  WgradParams p = {};
+  p.sside = small_side; p.big = big_side; p.Mtot = N * OH * OW; p.CsStride = Cs; p.logCb = ilog2(cbp);
+  p.H = Hb; p.W = Wb; p.logOW = ilog2(OW); p.logOHW = ilog2(OH * OW); p.sy = p.sx = 2; p.ntaps = 16;
+  for (int t = 0; t < 16; ++t) { p.dy[t] = (signed char)(t / 4 - 1); p.dx[t] = (signed char)(t % 4 - 1); }
+  const WgradPlan pl = plan_wgrad(p.Mtot, 16 * cbp, Cs);
+  p.flops = 2.0 * p.Mtot * Cs * 16.0 * Cb;
+  int rc = run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long total = (long long)Cs * Cb * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, ws, pl.Z, pl.CsRows, pl.ncols, Cs, Cb, p.logCb, 16, grad, accumulate);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+extern "C" size_t jck_g1_wgrad_ws_bytes(int B, int CiPad, int Co) { return plan_wgrad(B, 16 * Co, CiPad).ws; }
+
+extern "C" int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, size_t ws_bytes, float* grad,
+                            int accumulate, int B, int Ci, int CiPad, int Co, void* stream) {
+  if (!is_pow2(Co) || CiPad % 64 != 0) JCK_FAIL(JCK_E_ARG, "g1_wgrad: bad shape");
+  WgradParams p = {};
+  p.sside = z; p.big = dy; p.Mtot = B; p.CsStride = CiPad; p.logCb = ilog2(Co);
+  p.H = 4; p.W = 4; p.logOW = 0; p.logOHW = 0; p.sy = p.sx = 1; p.ntaps = 16;
+  for (int t = 0; t < 16; ++t) { p.dy[t] = (signed char)(t / 4); p.dx[t] = (signed char)(t % 4); }
+  const WgradPlan pl = plan_wgrad(B, 16 * Co, CiPad);
+  p.flops = 2.0 * B * Ci * 16.0 * Co;
+  int rc = run_wgrad(prec, p, pl, 1, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long total = (long long)Ci * Co * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, ws, pl.Z, pl.CsRows, pl.ncols, Ci, Co, p.logCb, 16, grad, accumulate);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// packing
+// ---------------------------------------------------------------------------------------------------------
+static unsigned ew_grid(long long n, int per_block = 256) { return (unsigned)std::max<long long>(1, std::min<long long>((n + per_block - 1) / per_block, 8192)); }
+
+extern "C" int jck_pack_down(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream) {
+  const int cbp = jck_pad_chan(Cb), rows = jck_pad_rows(Cs);
+  if (!is_pow2(cbp)) JCK_FAIL(JCK_E_ARG, "pack_down: Cb must be 3 or a power of two");
+  const long long total = (long long)rows * 16 * cbp;
+  hipLaunchKernelGGL(pack_down_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows, ilog2(cbp),
+                     (bf16_t*)hi, (bf16_t*)lo);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_pack_up(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream) {
+  const int rows = jck_pad_rows(Cb);
+  const long long total = 4ll * rows * 4 * Cs;
+  hipLaunchKernelGGL(pack_up_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows, (bf16_t*)hi,
+                     (bf16_t*)lo);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_pack_g1(const float* w, int Ci, int Co, int CiPad, void* hi, void* lo, void* stream) {
+  const long long total = 16ll * Co * CiPad;
+  hipLaunchKernelGGL(pack_g1_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Ci, Co, CiPad, (bf16_t*)hi,
+                     (bf16_t*)lo);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_pack_head(const float* w, int C, float* wp, void* stream) {
+  hipLaunchKernelGGL(pack_head_kernel, dim3(cdiv(16 * C, 256)), dim3(256), 0, (hipStream_t)stream, w, C, wp);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int64_t* nbt, float momentum, float eps, float* aux, int C,
+                               void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                     running_mean, running_var, (long long*)nbt, momentum, eps, aux, C);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+#define DISPATCH_T(prec, CALL)                                  \
+  do {                                                          \
+    if ((prec) == JCK_PREC_BF16) { typedef bf16_t T; CALL; }    \
+    else if ((prec) == JCK_PREC_F32) { typedef float T; CALL; } \
+    else JCK_FAIL(JCK_E_ARG, "bad prec");                       \
+  } while (0)
+
+extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void* a, long long rows, int C,
+                              void* stream) {
+  if (!is_pow2(C) || C < 8) JCK_FAIL(JCK_E_ARG, "bn_act_fwd: C must be a power of two >= 8");
+  const long long total8 = rows * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)y, aux, slope, (T*)a, total8, C));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
+                              void* g_y, float* dgamma, float* dbeta, long long rows, int C, void* stream) {
+  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C must be a power of two in [8, 2048]");
+  const int rstep = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  if (C / 8 > 256) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C too large");
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((rows + rstep * 8 - 1) / (rstep * 8), 1024));
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks), dim3(256), 2 * C * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, sums, rows, C));
+  HIPCHK(hipGetLastError());
+  const long long total8 = rows * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C));
+  HIPCHK(hipGetLastError());
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, dgamma, dbeta, C);
+    HIPCHK(hipGetLastError());
+  }
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// images, heads
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_img_prep(int prec, const float* img, const float* noise, float keep, float mix, void* out, int N, int HW,
+                            void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0,
+                                      (hipStream_t)stream, img, noise, keep, mix, (T*)out, N, HW));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_nhwc4_to_nchw(int prec, const void* in, float* out, int N, int HW, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(nhwc4_to_nchw_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0,
+                                      (hipStream_t)stream, (const T*)in, out, N, HW));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_axpy_noise(int prec, const void* x, const float* noise, float keep, float mix, void* out, int N, int HW,
+                              void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(axpy_noise_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0,
+                                      (hipStream_t)stream, (const T*)x, noise, keep, mix, (T*)out, N, HW));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_interp(int prec, const void* a, const void* b, const float* alpha, void* out, int N, int HW, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(interp_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)a, (const T*)b, alpha, (T*)out, N, HW));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, float* norms, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(gp_norm_kernel<T>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)g, HW, scal,
+                                      slot, norms));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out, long long numel, void* stream) {
+  if (numel % 4) JCK_FAIL(JCK_E_ARG, "tanh_bwd: numel % 4 != 0");
+  DISPATCH_T(prec, hipLaunchKernelGGL(tanh_bwd_kernel<T>, dim3(ew_grid(numel / 4)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)g, (const T*)y, scale, (T*)out, numel / 4));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, int B, int K, float target, int mode, float* prob,
+                            float* ds, float* scal, int slot_loss, int slot_p, void* stream) {
+  if (K % 8) JCK_FAIL(JCK_E_ARG, "head_fwd: K % 8 != 0");
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K,
+                                      target, mode, 1.0f / (float)B, prob, ds, scal, slot_loss, slot_p));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int B, int K, void* g_a4, float* dwp,
+                            int accumulate, void* stream) {
+  if (K % 8) JCK_FAIL(JCK_E_ARG, "head_bwd: K % 8 != 0");
+  if (g_a4) {
+    const long long total8 = (long long)B * K / 8;
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_dgrad_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, ds, wp,
+                                        K, (T*)g_a4, total8));
+    HIPCHK(hipGetLastError());
+  }
+  if (dwp) {
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64)), dim3(64), 0, (hipStream_t)stream, ds,
+                                        (const T*)a4, B, K, dwp, accumulate));
+    HIPCHK(hipGetLastError());
+  }
+  return JCK_OK;
+}
+extern "C" int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(16 * C, 256)), dim3(256), 0, (hipStream_t)stream, dwp, 1, 1, 16 * C, 1, C,
+                     ilog2(C), 16, grad, accumulate);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                        double eps, int step, float grad_scale, void* stream) {
+  if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
+  // scalar preparation in double exactly as torch.optim.Adam does it in Python, then one cast to float
+  const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+  const float step_size = (float)(lr / bc1), bc2s = (float)std::sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2s, grad_scale);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// debug probe: what ds_read_b64_tr_b16 returns for the addressing wgrad.hpp uses (pins the hardware
+// semantics the weight-gradient kernel relies on; exercised by tests/test_ops_gpu.py)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void debug_tr_kernel(const bf16_t* __restrict__ in, int ld, bf16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* t = reinterpret_cast<bf16_t*>(smem_raw);
+  for (int i = threadIdx.x; i < 32 * ld; i += 64) t[i] = in[i];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int trow = (lane >> 4) * 8 + ((lane & 15) >> 2), tcol = (lane & 3) * 4;
+  short4v a = lds_tr4(t + trow * ld + tcol), b = lds_tr4(t + (trow + 4) * ld + tcol);
+  for (int j = 0; j < 4; ++j) { out[lane * 8 + j] = (bf16_t)a[j]; out[lane * 8 + 4 + j] = (bf16_t)b[j]; }
+}
+extern "C" int jck_debug_tr_read(const void* in, int ld, void* out, void* stream) {
+  if (ld % 4 || ld < 16) JCK_FAIL(JCK_E_ARG, "ld must be a multiple of 4 and >= 16");
+  hipLaunchKernelGGL(debug_tr_kernel, dim3(1), dim3(64), 32 * ld * 2, (hipStream_t)stream, (const bf16_t*)in, ld, (bf16_t*)out);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}

@@ -1,0 +1,36 @@
+// Internal glue shared by ops.hip and engine.hip.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "../../include/jckgan.h"
+#include "common.hpp"
+#include "ew.hpp"
+#include "igemm.hpp"
+#include "wgrad.hpp"
+
+void jck_set_error(const std::string& s);
+
+#define JCK_FAIL(code, msg)                                   \
+  do {                                                        \
+    jck_set_error(std::string(__func__) + ": " + (msg));     \
+    return (code);                                            \
+  } while (0)
+
+#define HIPCHK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      jck_set_error(std::string(__func__) + ": HIP error " + hipGetErrorString(e_) + " at " #expr);     \
+      return JCK_E_HIP;                                                                                  \
+    }                                                                                                    \
+  } while (0)
+
+#define JCK_TRY(expr)           \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != JCK_OK) return rc_; \
+  } while (0)
+
+int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st);

@@ -1,0 +1,131 @@
+"""ctypes loader + typed prototypes for every symbol declared in include/jckgan.h."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libjckgan_hip.so")
+PREC_BF16, PREC_F32 = 0, 1
+
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_size_t
+
+
+class StepInputs(C.Structure):
+    _fields_ = [("real_nchw", vp), ("noise_real", vp), ("z", vp), ("noise_fake", vp), ("alpha", vp),
+                ("lr", f32), ("grad_scale", f32), ("step", i32)]
+
+
+# name -> (restype, argtypes)      (keep in sync with include/jckgan.h; tests/test_abi.py checks the symbol list)
+PROTOS = {
+    "jck_last_error": (C.c_char_p, []),
+    "jck_version": (i32, []),
+    "jck_pad_rows": (i32, [i32]),
+    "jck_pad_chan": (i32, [i32]),
+    "jck_pack_down": (i32, [vp, i32, i32, vp, vp, vp]),
+    "jck_pack_up": (i32, [vp, i32, i32, vp, vp, vp]),
+    "jck_pack_g1": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "jck_pack_head": (i32, [vp, i32, vp, vp]),
+    "jck_conv_down": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "jck_conv_up": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jck_conv_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "jck_conv_wgrad": (i32, [i32, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jck_g1_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "jck_g1_wgrad_ws_bytes": (sz, [i32, i32, i32]),
+    "jck_g1_wgrad": (i32, [i32, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, vp]),
+    "jck_bn_finalize": (i32, [vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
+    "jck_bn_act_fwd": (i32, [i32, vp, vp, f32, vp, i64, i32, vp]),
+    "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
+    "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),
+    "jck_axpy_noise": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "jck_interp": (i32, [i32, vp, vp, vp, vp, i32, i32, vp]),
+    "jck_gp_norm": (i32, [i32, vp, i32, i32, vp, i32, vp, vp]),
+    "jck_tanh_bwd": (i32, [i32, vp, vp, f32, vp, i64, vp]),
+    "jck_head_fwd": (i32, [i32, vp, vp, i32, i32, f32, i32, vp, vp, vp, i32, i32, vp]),
+    "jck_head_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
+    "jck_head_unpack_grad": (i32, [vp, i32, vp, i32, vp]),
+    "jck_adam": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, i32, f32, vp]),
+    "jck_engine_create": (i32, [C.POINTER(vp), i32, i32, i32]),
+    "jck_engine_destroy": (None, [vp]),
+    "jck_engine_num_tensors": (i32, [i32, i32]),
+    "jck_engine_tensor_info": (i32, [i32, i32, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64),
+                                     C.POINTER(i32)]),
+    "jck_engine_workspace_bytes": (sz, [vp]),
+    "jck_engine_arena_numel": (i64, [i32, i32, i32]),
+    "jck_engine_bind": (i32, [vp, vp, sz] + [vp] * 12),
+    "jck_engine_repack": (i32, [vp, i32, vp]),
+    "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
+    "jck_engine_scalars": (vp, [vp]),
+    "jck_engine_sample": (i32, [vp, vp, i32, vp, vp]),
+    "jck_engine_tensor": (vp, [vp, C.c_char_p, C.POINTER(i64)]),
+    "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),
+    "jck_prof_enable": (i32, [i32]),
+    "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
+}
+
+
+class JckError(RuntimeError):
+    pass
+
+
+_cdll = None
+
+
+def load_library(path=None):
+    """Loads the shared library and attaches the prototypes.  Raises (never falls back) if missing."""
+    global _cdll
+    if _cdll is not None:
+        return _cdll
+    path = path or os.environ.get("JCKGAN_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise JckError(f"{path} not found: build it with `python __graft_entry__.py build` "
+                       f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    dll = C.CDLL(path)
+    partial = os.environ.get("JCKGAN_ALLOW_PARTIAL") == "1"      # development only
+    for name, (res, args) in PROTOS.items():
+        if partial and not hasattr(dll, name):
+            continue
+        fn = getattr(dll, name)          # AttributeError here = header / library mismatch
+        fn.restype, fn.argtypes = res, args
+    _cdll = dll
+    return dll
+
+
+def _arg(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+class _Lib:
+    """`lib.jck_conv_down(prec, big, w_hi, ...)`: tensors become device pointers, a non-zero return raises."""
+
+    def __getattr__(self, name):
+        dll = load_library()
+        fn = getattr(dll, name)
+
+        def call(*args):
+            for a in args:
+                if isinstance(a, torch.Tensor):
+                    if not a.is_cuda:
+                        raise JckError(f"{name}: tensor argument is on {a.device}; the HIP path needs device memory")
+                    if not a.is_contiguous():
+                        raise JckError(f"{name}: non-contiguous tensor argument")
+            r = fn(*[_arg(a) for a in args])
+            if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect") \
+                    and r != 0:
+                raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
+            return r
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
+lib = _Lib()
+
+
+def cur_stream():
+    return torch.cuda.current_stream().cuda_stream

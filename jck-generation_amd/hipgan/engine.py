@@ -1,0 +1,216 @@
+"""Python face of the native step engine (jck_engine_* in include/jckgan.h).
+
+The engine owns no memory: this wrapper allocates the flat fp32 arenas (parameters, gradients, Adam
+moments, BatchNorm running statistics) and one workspace as torch tensors on the device and binds
+them.  `named_views()` exposes every tensor under the reference's state-dict key
+(model/DCGAN.py:10-27,42-59) as a zero-copy view, so nn.Module parameters can live in the arenas.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, load_library
+
+PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP = range(5)
+_PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
+SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
+
+
+def _layout(family, net):
+    dll = load_library()
+    out = []
+    for i in range(dll.jck_engine_num_tensors(family, net)):
+        name = C.create_string_buffer(64)
+        kind, off, numel = C.c_int(), C.c_longlong(), C.c_longlong()
+        shape = (C.c_int * 4)()
+        rc = dll.jck_engine_tensor_info(family, net, i, name, 64, C.byref(kind), C.byref(off), C.byref(numel), shape)
+        if rc != 0:
+            raise JckError(dll.jck_last_error().decode())
+        shp = list(shape)
+        if kind.value == 0 and name.value.decode().startswith("conv"):
+            shp = shp
+        else:
+            shp = shp[:1]
+        out.append((name.value.decode(), kind.value, off.value, numel.value, shp))
+    return out
+
+
+class DcganEngine:
+    """One DCGAN training state resident in HBM + the native step schedule."""
+
+    family = 0
+
+    def __init__(self, batch, prec="bf16", device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise JckError("DcganEngine needs a GPU: the HIP path has no CPU fallback")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.prec = _PREC[prec]
+        self.batch = batch
+        self.t = 0                      # optimiser steps taken (Adam bias correction), D and G advance together
+        h = C.c_void_p()
+        dll = load_library()
+        if dll.jck_engine_create(C.byref(h), self.family, self.prec, batch) != 0:
+            raise JckError(dll.jck_last_error().decode())
+        self._h = h
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.arenas = {}
+        for net, tag in ((0, "g"), (1, "d")):
+            n, nb = dll.jck_engine_arena_numel(self.family, net, 0), dll.jck_engine_arena_numel(self.family, net, 1)
+            for what in ("params", "grads", "m", "v"):
+                self.arenas[f"{tag}_{what}"] = torch.zeros(n, **f32)
+            self.arenas[f"{tag}_bn"] = torch.zeros(nb, **f32)
+            self.arenas[f"{tag}_nbt"] = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self.ws_bytes = dll.jck_engine_workspace_bytes(h)
+        self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        a = self.arenas
+        lib.jck_engine_bind(h, self.workspace, self.ws_bytes, a["g_params"], a["g_grads"], a["g_m"], a["g_v"], a["g_bn"],
+                            a["g_nbt"], a["d_params"], a["d_grads"], a["d_m"], a["d_v"], a["d_bn"], a["d_nbt"])
+        self.layout = {"g": _layout(self.family, 0), "d": _layout(self.family, 1)}
+        # BN running_var starts at 1 (nn.BatchNorm2d)
+        for tag in ("g", "d"):
+            for name, kind, off, numel, shp in self.layout[tag]:
+                if kind == 2:
+                    a[f"{tag}_bn"][off:off + numel].fill_(1.0)
+        self._scal = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                load_library().jck_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- state ------------------------------------------------------------------------------------------
+    def named_views(self, tag, what="params"):
+        """{state-dict key: view}. what: 'params' (incl. BN buffers), 'grads', 'm', 'v'."""
+        out = {}
+        bn_i = 0
+        for name, kind, off, numel, shp in self.layout[tag]:
+            if kind == 0:
+                out[name] = self.arenas[f"{tag}_{what}"][off:off + numel].view(shp)
+            elif what == "params":
+                out[name] = self.arenas[f"{tag}_bn"][off:off + numel].view(shp)
+                if kind == 2:
+                    out[name.replace("running_var", "num_batches_tracked")] = self.arenas[f"{tag}_nbt"][bn_i]
+                    bn_i += 1
+        return out
+
+    def load_state(self, g_state, d_state):
+        """Copies reference-keyed state dicts (CPU or device tensors) into the arenas and re-derives the bf16 operands."""
+        for tag, sd in (("g", g_state), ("d", d_state)):
+            views = self.named_views(tag)
+            for k, v in sd.items():
+                if k not in views:
+                    raise JckError(f"unexpected key {k}")
+                views[k].copy_(v.detach().to(self.device).view(views[k].shape))
+        self.repack()
+
+    def state_dicts(self):
+        order = lambda tag: {k: v.detach().cpu().clone() for k, v in self._ordered(tag)}
+        return order("g"), order("d")
+
+    def _ordered(self, tag):
+        """reference state_dict order: per layer weight, [bias, running_mean, running_var, num_batches_tracked]."""
+        v = self.named_views(tag)
+        keys = []
+        for i in range(1, 6):
+            keys.append(f"conv{i}.weight")
+            if f"norm{i}.weight" in v:
+                keys += [f"norm{i}.weight", f"norm{i}.bias", f"norm{i}.running_mean", f"norm{i}.running_var",
+                         f"norm{i}.num_batches_tracked"]
+        return [(k, v[k]) for k in keys]
+
+    def repack(self):
+        lib.jck_engine_repack(self._h, 0, cur_stream())
+        lib.jck_engine_repack(self._h, 1, cur_stream())
+
+    # ---- the step ---------------------------------------------------------------------------------------
+    def _inputs(self, real, noise, lr, grad_scale):
+        B = self.batch
+        if real is not None and (real.shape != (B, 3, 64, 64) or real.dtype != torch.float32):
+            raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
+        si = StepInputs()
+        keep = []
+
+        def ptr(t, shape):
+            if t is None:
+                return None
+            t = t.to(self.device, torch.float32).contiguous()
+            if t.numel() != shape:
+                raise JckError(f"noise tensor has {t.numel()} elements, expected {shape}")
+            keep.append(t)
+            return t.data_ptr()
+        si.real_nchw = ptr(real, B * 3 * 64 * 64)
+        si.noise_real = ptr(noise.get("n1"), B * 3 * 64 * 64)
+        si.z = ptr(noise.get("z"), B * 100)
+        si.noise_fake = ptr(noise.get("n2"), B * 3 * 64 * 64)
+        si.alpha = ptr(noise.get("alpha"), B)
+        si.lr, si.grad_scale, si.step = lr, grad_scale, self.t + 1
+        return si, keep
+
+    def draw_noise(self, generator=None):
+        """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111)."""
+        B, dev = self.batch, self.device
+        return {"n1": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
+                "z": torch.randn(B, 100, 1, 1, device=dev, generator=generator),
+                "n2": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
+                "alpha": torch.rand(B, 1, 1, 1, device=dev, generator=generator)}
+
+    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0):
+        """Enqueues one full step on the current stream; no host sync.  `reduce_d/reduce_g(flat_grads)` are
+        called between the loss and the optimiser phases (data-parallel gradient all-reduce)."""
+        noise = noise if noise is not None else self.draw_noise()
+        si, keep = self._inputs(real, noise, lr, grad_scale)
+        st = cur_stream()
+        h = self._h
+        lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
+        handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
+        lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)       # overlaps the D all-reduce (no gradients in DCGAN)
+        if handle is not None:
+            handle()
+        lib.jck_engine_phase(h, PHASE_D_STEP, C.byref(si), st)
+        lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
+        handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+        if handle is not None:
+            handle()
+        lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
+        self.t += 1
+        self._keep = keep
+
+    def scalars(self):
+        """Host copy of the eight step scalars (one device->host sync)."""
+        vals = self._ws_view(load_library().jck_engine_scalars(self._h), 8, torch.float32).cpu().tolist()
+        return dict(zip(SCALAR_NAMES, vals))
+
+    def _ws_view(self, ptr, numel, dtype):
+        """Typed view of a region of the bound workspace given its device address."""
+        off = ptr - self.workspace.data_ptr()
+        nbytes = numel * torch.empty(0, dtype=dtype).element_size()
+        if off < 0 or off + nbytes > self.ws_bytes:
+            raise JckError("pointer outside the engine workspace")
+        return self.workspace[off:off + nbytes].view(dtype)
+
+    def step(self, real, noise=None, lr=2e-4, **kw):
+        self.step_async(real, noise, lr, **kw)
+        return self.scalars()
+
+    def sample(self, z):
+        """G(z) with train-mode BatchNorm (train/dcgan_trainer.py:199-200) -> NCHW fp32 on the device."""
+        n = z.shape[0]
+        out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
+        for i in range(0, n, self.batch):
+            zc = z[i:i + self.batch].to(self.device, torch.float32).contiguous().view(-1, 100)
+            lib.jck_engine_sample(self._h, zc, zc.shape[0], out[i:i + zc.shape[0]], cur_stream())
+        return out
+
+    def tensor(self, name):
+        """Debug/parity view of an internal NHWC tensor as a torch tensor (copy)."""
+        n = C.c_longlong()
+        p = load_library().jck_engine_tensor(self._h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        f32 = name in ("prob", "ds", "norms", "acc")
+        dt = torch.float32 if (f32 or self.prec == PREC_F32) else torch.bfloat16
+        return self._ws_view(p, n.value, dt).clone()

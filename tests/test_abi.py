@@ -1,0 +1,39 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol declared in
+include/jckgan.h; the ctypes table covers the header (no compute calls here - no GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "jckgan.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(jck_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from hipgan import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    dll = _lib.load_library()
+    syms = _header_symbols()
+    assert len(syms) > 30
+    for s in syms:
+        assert hasattr(dll, s), f"{s} declared in include/jckgan.h but not exported"
+        assert s in _lib.PROTOS, f"{s} has no ctypes prototype"
+    assert dll.jck_version() >= 100
+    assert dll.jck_pad_rows(3) == 16 and dll.jck_pad_rows(64) == 64 and dll.jck_pad_rows(200) == 256
+    assert dll.jck_pad_chan(3) == 4
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hipgan import JckError, lib
+    with pytest.raises(JckError):
+        lib.jck_adam(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 4, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None)

@@ -1,0 +1,277 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 CPU ops of the same
+function (the library the reference's hot path is made of).  Tolerances are relative to max|ref|:
+JCK_PREC_F32 (split-bf16 x3 MFMA, fp32 storage) 3e-5;  JCK_PREC_BF16 (bf16 storage) 1.5e-2 against a reference
+computed from bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+PRECS = [1, 0]
+
+
+def test_tr_read_semantics(G):
+    """ds_read_b64_tr_b16 as wgrad.hpp addresses it: lane l gets in[8*(l>>4)+j][l&15], j=0..7."""
+    ld = 48
+    ids = torch.arange(32 * ld, dtype=torch.int16).cuda()
+    out = torch.zeros(64 * 8, dtype=torch.int16).cuda()
+    G.lib.jck_debug_tr_read(ids, ld, out, G.cur_stream())
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 8)
+    exp = torch.tensor([[(8 * (l >> 4) + j) * ld + (l & 15) for j in range(8)] for l in range(64)], dtype=torch.int16)
+    if not torch.equal(got, exp):
+        rows, cols = got // ld, got % ld
+        raise AssertionError("tr-read mapping differs; (row,col) per lane:\n" +
+                             "\n".join(f"lane {l}: {[(int(rows[l, j]), int(cols[l, j])) for j in range(8)]}" for l in range(64)))
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128), (3, 64, 3, 64), (2, 16, 128, 256), (4, 8, 256, 512), (1, 4, 64, 128),
+                                   (5, 32, 64, 128)])
+def test_conv_down(G, prec, shape):
+    n, hb, cb, cs = shape
+    g = torch.Generator().manual_seed(1)
+    x = G.rnd(torch.randn(n, cb, hb, hb, generator=g), prec)
+    w = torch.randn(cs, cb, 4, 4, generator=g) * 0.05
+    wr = G.rnd(w, prec)
+    ref = F.conv2d(x, wr, None, 2, 1)
+    hi, lo = G.pack_down(w, prec)
+    out = torch.empty(n, hb // 2, hb // 2, cs, dtype=G.DT[prec], device="cuda")
+    stats = torch.zeros(2 * cs, device="cuda")
+    G.lib.jck_conv_down(prec, G.to_nhwc(x, prec), hi, lo, out, stats, n, hb, hb, cb, cs, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(G.from_nhwc(out), ref, G.TOL[prec], "conv_down")
+    G.check(stats[:cs].cpu(), ref.sum((0, 2, 3)), 2e-3 if prec == 0 else 1e-4, "stats sum")
+    G.check(stats[cs:].cpu(), (ref * ref).sum((0, 2, 3)), 2e-3 if prec == 0 else 1e-4, "stats sumsq")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 4, 512, 256), (2, 8, 256, 128), (3, 16, 128, 64), (2, 32, 64, 3), (5, 4, 128, 64)])
+def test_conv_up(G, prec, shape):
+    n, hs, cs, cb = shape
+    g = torch.Generator().manual_seed(2)
+    x = G.rnd(torch.randn(n, cs, hs, hs, generator=g), prec)
+    w = torch.randn(cs, cb, 4, 4, generator=g) * 0.05
+    wr = G.rnd(w, prec)
+    tanh = cb == 3
+    ref = F.conv_transpose2d(x, wr, None, 2, 1)
+    hi, lo = G.pack_up(w, prec)
+    cbp = G.lib.jck_pad_chan(cb)
+    out = torch.full((n, 2 * hs, 2 * hs, cbp), 7.0, dtype=G.DT[prec], device="cuda")
+    stats = torch.zeros(2 * cbp, device="cuda")
+    G.lib.jck_conv_up(prec, G.to_nhwc(x, prec), hi, lo, out, stats, 1 if tanh else 0, n, hs, hs, cs, cb, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(G.from_nhwc(out, cb), torch.tanh(ref) if tanh else ref, G.TOL[prec], "conv_up")
+    if cbp != cb:
+        assert float(out[..., cb:].float().abs().max()) == 0.0, "padding channel must be zero"
+    G.check(stats[:cb].cpu(), ref.sum((0, 2, 3)), 2e-3 if prec == 0 else 1e-4, "stats sum")
+    G.check(stats[cbp:cbp + cb].cpu(), (ref * ref).sum((0, 2, 3)), 2e-3 if prec == 0 else 1e-4, "stats sumsq")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128), (3, 64, 3, 64), (2, 16, 128, 256), (4, 8, 256, 512), (7, 8, 64, 128),
+                                   (16, 32, 64, 128)])
+def test_conv_wgrad(G, prec, shape):
+    """dW of Conv2d(big->small) == dW of ConvTranspose2d(small->big): one kernel, checked against both."""
+    n, hb, cb, cs = shape
+    g = torch.Generator().manual_seed(3)
+    big = G.rnd(torch.randn(n, cb, hb, hb, generator=g), prec)
+    small = G.rnd(torch.randn(n, cs, hb // 2, hb // 2, generator=g), prec)
+    w = torch.zeros(cs, cb, 4, 4, requires_grad=True)
+    (F.conv2d(big, w, None, 2, 1) * small).sum().backward()
+    ref = w.grad.clone()
+    w.grad = None
+    (F.conv_transpose2d(small, w, None, 2, 1) * big).sum().backward()
+    torch.testing.assert_close(w.grad, ref, rtol=1e-3, atol=1e-3 * ref.abs().max().item())
+    ws_bytes = G.lib.jck_conv_wgrad_ws_bytes(n, hb, hb, cb, cs)
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    grad = torch.full((cs, cb, 4, 4), 1.0, device="cuda")
+    G.lib.jck_conv_wgrad(prec, G.to_nhwc(small, prec), G.to_nhwc(big, prec), ws, ws_bytes, grad, 1, n, hb, hb, cb, cs,
+                         G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(grad.cpu() - 1.0, ref, 2e-5 if prec == 1 else 2e-3, "conv_wgrad(accumulate)")
+    G.lib.jck_conv_wgrad(prec, G.to_nhwc(small, prec), G.to_nhwc(big, prec), ws, ws_bytes, grad, 0, n, hb, hb, cb, cs,
+                         G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(grad.cpu(), ref, 2e-5 if prec == 1 else 2e-3, "conv_wgrad(overwrite)")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [(8, 100, 128, 512), (256, 100, 128, 512), (5, 200, 256, 512)])
+def test_g1(G, prec, cfg):
+    b, ci, cip, co = cfg
+    g = torch.Generator().manual_seed(4)
+    z = G.rnd(torch.randn(b, ci, 1, 1, generator=g), prec)
+    w = torch.randn(ci, co, 4, 4, generator=g) * 0.05
+    w.requires_grad_(True)
+    wr = G.rnd(w.detach(), prec)
+    ref = F.conv_transpose2d(z, wr, None, 1, 0)
+    zp = torch.zeros(b, cip)
+    zp[:, :ci] = z.view(b, ci)
+    zp = zp.to(G.DT[prec]).cuda()
+    hi = torch.empty(16 * co * cip, dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty_like(hi)
+    G.lib.jck_pack_g1(w.detach().cuda(), ci, co, cip, hi, lo, G.cur_stream())
+    out = torch.empty(b, 4, 4, co, dtype=G.DT[prec], device="cuda")
+    stats = torch.zeros(2 * co, device="cuda")
+    G.lib.jck_g1_fwd(prec, zp, hi, lo, out, stats, b, cip, co, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(G.from_nhwc(out), ref, G.TOL[prec], "g1_fwd")
+    G.check(stats[:co].cpu(), ref.sum((0, 2, 3)), 2e-3 if prec == 0 else 1e-4, "g1 stats")
+    dy = G.rnd(torch.randn(b, co, 4, 4, generator=g), prec)
+    (F.conv_transpose2d(z, w, None, 1, 0) * dy).sum().backward()
+    ws_bytes = G.lib.jck_g1_wgrad_ws_bytes(b, cip, co)
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    grad = torch.zeros(ci, co, 4, 4, device="cuda")
+    G.lib.jck_g1_wgrad(prec, zp, G.to_nhwc(dy, prec), ws, ws_bytes, grad, 0, b, ci, cip, co, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(grad.cpu(), w.grad, 2e-5 if prec == 1 else 2e-3, "g1_wgrad")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [(2, 8, 64, 0.2), (3, 4, 512, 0.0), (4, 16, 128, 0.2), (2, 32, 64, 0.0)])
+def test_bn_act(G, prec, cfg):
+    n, h, c, slope = cfg
+    g = torch.Generator().manual_seed(5)
+    y = G.rnd(torch.randn(n, c, h, h, generator=g) * 1.5 + 0.3, prec).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(c, generator=g)).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    bn = F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    a = F.leaky_relu(bn, slope) if slope else F.relu(bn)
+    ga = G.rnd(torch.randn(n, c, h, h, generator=g), prec)
+    a.backward(ga)
+    rows = n * h * h
+    yd = G.to_nhwc(y.detach(), prec)
+    yf = yd.float().view(rows, c)
+    stats = torch.cat([yf.sum(0), (yf * yf).sum(0)]).contiguous()
+    aux = torch.empty(4 * c, device="cuda")
+    rmd, rvd = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    G.lib.jck_bn_finalize(stats, float(rows), gamma.detach().cuda(), beta.detach().cuda(), rmd, rvd, nbt, 0.1, 1e-5, aux, c,
+                          G.cur_stream())
+    ad = torch.empty_like(yd)
+    G.lib.jck_bn_act_fwd(prec, yd, aux, slope, ad, rows, c, G.cur_stream())
+    sums = torch.zeros(2 * c, device="cuda")
+    gy = torch.empty_like(yd)
+    dgam, dbet = torch.ones(c, device="cuda"), torch.ones(c, device="cuda")
+    G.lib.jck_bn_act_bwd(prec, G.to_nhwc(ga, prec), yd, aux, slope, sums, gy, dgam, dbet, rows, c, G.cur_stream())
+    torch.cuda.synchronize()
+    tol = 1e-5 if prec == 1 else 1.5e-2
+    G.check(G.from_nhwc(ad), a.detach(), tol, "bn_act_fwd")
+    G.check(rmd.cpu(), rm, 1e-5, "running_mean")
+    G.check(rvd.cpu(), rv, 1e-5, "running_var")
+    assert int(nbt) == 1
+    G.check(G.from_nhwc(gy), y.grad, 2e-5 if prec == 1 else 2e-2, "bn_act_bwd dx")
+    G.check(dgam.cpu() - 1, gamma.grad, 2e-5 if prec == 1 else 1e-2, "dgamma")
+    G.check(dbet.cpu() - 1, beta.grad, 2e-5 if prec == 1 else 1e-2, "dbeta")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_head(G, prec):
+    b, c = 16, 512
+    g = torch.Generator().manual_seed(6)
+    a4 = G.rnd(torch.randn(b, c, 4, 4, generator=g), prec).requires_grad_(True)
+    w = (torch.randn(1, c, 4, 4, generator=g) * 0.02).requires_grad_(True)
+    p = torch.sigmoid(F.conv2d(a4, w)).view(-1)
+    loss = F.binary_cross_entropy(p, torch.full((b,), 0.9))
+    loss.backward()
+    wp = torch.empty(16 * c, device="cuda")
+    G.lib.jck_pack_head(w.detach().cuda(), c, wp, G.cur_stream())
+    a4d = G.to_nhwc(a4.detach(), prec)
+    prob, ds = torch.empty(b, device="cuda"), torch.empty(b, device="cuda")
+    scal = torch.zeros(16, device="cuda")
+    G.lib.jck_head_fwd(prec, a4d, wp, b, 16 * c, 0.9, 0, prob, ds, scal, 0, 3, G.cur_stream())
+    ga = torch.empty_like(a4d)
+    dwp = torch.zeros(16 * c, device="cuda")
+    G.lib.jck_head_bwd(prec, ds, wp, a4d, b, 16 * c, ga, dwp, 0, G.cur_stream())
+    gw = torch.zeros(1, c, 4, 4, device="cuda")
+    G.lib.jck_head_unpack_grad(dwp, c, gw, 0, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(prob.cpu(), p.detach(), 1e-5, "prob")
+    assert abs(scal[0].item() / b - loss.item()) < 1e-5 * abs(loss.item())
+    assert abs(scal[3].item() / b - p.mean().item()) < 1e-5
+    G.check(G.from_nhwc(ga), a4.grad, 1e-5 if prec == 1 else 1e-2, "head dgrad")
+    G.check(gw.cpu(), w.grad, 1e-5, "head wgrad")
+    # gradient-penalty mode: d sum(sigmoid) / d logit
+    G.lib.jck_head_fwd(prec, a4d, wp, b, 16 * c, 0.0, 1, prob, ds, scal, -1, -1, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(ds.cpu(), (p * (1 - p)).detach(), 1e-5, "gp ds")
+
+
+def test_head_clamp(G):
+    """saturated D: BCELoss clamps log at -100 and ATen's backward divides by max(p(1-p), 1e-12)."""
+    b, c = 4, 512
+    a4 = torch.ones(b, c, 4, 4)
+    w = torch.full((1, c, 4, 4), 0.05)
+    p = torch.sigmoid(F.conv2d(a4, w)).view(-1)
+    assert float(p[0]) == 1.0
+    ref = F.binary_cross_entropy(p, torch.full((b,), 0.1))
+    wp = torch.empty(16 * c, device="cuda")
+    G.lib.jck_pack_head(w.cuda(), c, wp, G.cur_stream())
+    prob, ds, scal = torch.empty(b, device="cuda"), torch.empty(b, device="cuda"), torch.zeros(16, device="cuda")
+    G.lib.jck_head_fwd(1, G.to_nhwc(a4, 1), wp, b, 16 * c, 0.1, 0, prob, ds, scal, 0, 3, G.cur_stream())
+    torch.cuda.synchronize()
+    assert scal[0].item() / b == pytest.approx(ref.item(), rel=1e-6) == pytest.approx(90.0)
+    assert float(ds.abs().max()) == 0.0
+
+
+def test_adam(G):
+    g = torch.Generator().manual_seed(7)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=2e-4, betas=[0.5, 0.999])
+    pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        p.grad = gr.clone()
+        opt.step()
+        G.lib.jck_adam(pd, gr.cuda(), m, v, n, 2e-4, 0.5, 0.999, 1e-8, step, 1.0, G.cur_stream())
+        torch.cuda.synchronize()
+        assert (pd.cpu() - p.detach()).abs().max().item() < 3e-7, step
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_image_ops(G, prec):
+    n, hw = 3, 64 * 64
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(n, 3, 64, 64, generator=g) * 2 - 1
+    nz = torch.randn(n, 3, 64, 64, generator=g)
+    out = torch.empty(n, 64, 64, 4, dtype=G.DT[prec], device="cuda")
+    G.lib.jck_img_prep(prec, img.cuda(), nz.cuda(), 0.9, 0.1, out, n, hw, G.cur_stream())
+    ref = 0.9 * img + 0.1 * nz
+    tol = 1e-6 if prec == 1 else 8e-3
+    G.check(G.from_nhwc(out, 3), ref, tol, "img_prep")
+    back = torch.empty(n, 3, 64, 64, device="cuda")
+    G.lib.jck_nhwc4_to_nchw(prec, out, back, n, hw, G.cur_stream())
+    G.check(back.cpu(), G.from_nhwc(out, 3), 0, "nhwc4_to_nchw")
+    x = G.rnd(torch.randn(n, 3, 64, 64, generator=g), prec)
+    o2 = torch.empty_like(out)
+    G.lib.jck_axpy_noise(prec, G.to_nhwc(x, prec), nz.cuda(), 0.9, 0.1, o2, n, hw, G.cur_stream())
+    G.check(G.from_nhwc(o2, 3), 0.9 * x + 0.1 * nz, tol, "axpy_noise")
+    al = torch.rand(n, generator=g)
+    o3 = torch.empty_like(out)
+    G.lib.jck_interp(prec, out, o2, al.cuda(), o3, n, hw, G.cur_stream())
+    a_, b_ = G.from_nhwc(out, 3), G.from_nhwc(o2, 3)
+    G.check(G.from_nhwc(o3, 3), al.view(n, 1, 1, 1) * a_ + (1 - al.view(n, 1, 1, 1)) * b_, tol, "interp")
+    scal = torch.zeros(16, device="cuda")
+    norms = torch.empty(n, device="cuda")
+    G.lib.jck_gp_norm(prec, o3, n, hw, scal, 6, norms, G.cur_stream())
+    gi = G.from_nhwc(o3, 3).view(n, -1)
+    G.check(norms.cpu(), gi.norm(2, dim=1), 1e-5, "gp norms")
+    assert abs(scal[6].item() - ((gi.norm(2, dim=1) - 1) ** 2).sum().item()) < 1e-3 * scal[6].item()
+    o4 = torch.empty_like(out)
+    yv = G.rnd(torch.tanh(torch.randn(n, 3, 64, 64, generator=g)), prec)
+    G.lib.jck_tanh_bwd(prec, G.to_nhwc(x, prec), G.to_nhwc(yv, prec), 0.9, o4, n * hw * 4, G.cur_stream())
+    G.check(G.from_nhwc(o4, 3), 0.9 * x * (1 - yv * yv), tol, "tanh_bwd")

@@ -1,0 +1,179 @@
+"""Whole-step parity on the GPU: the native DCGAN step engine (through the C ABI) against the CPU oracle
+(oracle/gan_oracle.py, itself pinned to the reference) on the same weights, batch and noise.
+
+Tolerances (relative):
+  JCK_PREC_F32 (fp32 storage, split-bf16 x3 MFMA): the north star's 1e-3 on losses from identical state, per step;
+      measured ~1e-5.  Gradient / weight digests 2e-3 (elements pass ~10 layers in reversed-order sums).
+  JCK_PREC_BF16 (fast path): 3e-2 on losses per step (bf16 storage of activations and gradients; SURVEY A.2 measured
+      3.4e-3 for bf16 conv operands alone), trajectories compared statistically against the reference's own
+      8-thread-vs-1-thread divergence (tests/golden/selfdiv.json)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"n1": torch.randn(B, 3, 64, 64, generator=g), "z": torch.randn(B, 100, 1, 1, generator=g),
+            "n2": torch.randn(B, 3, 64, 64, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g)}
+
+
+def _run(B, steps, prec, lr=2e-4, teacher_forced=True):
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import GanOracle
+    from util import synth_images
+    orc = GanOracle("dcgan", lr=lr, seed=12345)
+    eng = DcganEngine(batch=B, prec=prec)
+    eng.load_state(orc.g, orc.d)
+    imgs = synth_images(B * steps)
+    out = []
+    for s in range(steps):
+        real, nz = imgs[s * B:(s + 1) * B], _noise(B, 100 + s)
+        if teacher_forced and s > 0:      # restart the engine from the oracle's state: isolates one step
+            eng.load_state(orc.g, orc.d)
+            for tag, opt in (("g", orc.opt_g), ("d", orc.opt_d)):
+                for what, src in (("m", opt.m), ("v", opt.v)):
+                    v = eng.named_views(tag, what)
+                    for k, t in src.items():
+                        v[k].copy_(t)
+            eng.t = orc.opt_d.t
+        ref = orc.step(real, None, nz)
+        got = eng.step(real.cuda(), {k: v.cuda() for k, v in nz.items()}, lr=lr)
+        out.append((ref, got, {k: v.clone() for k, v in orc.d_grads.items()}, {k: v.clone() for k, v in orc.g_grads.items()}))
+    return orc, eng, out
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-12)
+
+
+def _cmp_tensors(views, refs, tol, what):
+    for k, r in refs.items():
+        g = views[k].detach().float().cpu().view(r.shape)
+        scale = r.abs().max().item() + 1e-30
+        err = (g - r).abs().max().item()
+        assert err <= tol * scale, f"{what}:{k}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_step_parity_f32(B):
+    orc, eng, out = _run(B, 3, "f32")
+    for s, (ref, got, dgr, ggr) in enumerate(out):
+        for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+            assert _rel(got[k], ref[k]) < 1e-3, (s, k, got[k], ref[k])
+    # last step: gradients, weights, Adam state and BN running statistics
+    ref, got, dgr, ggr = out[-1]
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 2e-3, "d_grads")
+    _cmp_tensors(eng.named_views("g", "grads"), ggr, 2e-3, "g_grads")
+    _cmp_tensors(eng.named_views("d"), {k: v for k, v in orc.d.items() if v.dtype == torch.float32}, 2e-4, "d_state")
+    _cmp_tensors(eng.named_views("g"), {k: v for k, v in orc.g.items() if v.dtype == torch.float32}, 2e-4, "g_state")
+    assert int(eng.named_views("d")["norm1.num_batches_tracked"]) == int(orc.d["norm1.num_batches_tracked"])
+    assert int(eng.named_views("g")["norm4.num_batches_tracked"]) == int(orc.g["norm4.num_batches_tracked"])
+    fake = eng.tensor("fake").view(B, 64, 64, 4)[..., :3].permute(0, 3, 1, 2).float().cpu()
+    assert (fake - ref["fake"]).abs().max().item() < 5e-4
+
+
+def test_step_first_step_tight_f32():
+    """Step 0 from identical state: measured agreement is ~1e-5, assert 1e-4 (10x under the north star's 1e-3)."""
+    orc, eng, out = _run(16, 1, "f32")
+    ref, got, dgr, ggr = out[0]
+    for k in ("loss_d", "loss_g", "gp"):
+        assert _rel(got[k], ref[k]) < 1e-4, (k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_step_parity_bf16(B):
+    orc, eng, out = _run(B, 3, "bf16")
+    for s, (ref, got, dgr, ggr) in enumerate(out):
+        for k in ("loss_d", "loss_g", "loss_real", "loss_fake"):
+            assert _rel(got[k], ref[k]) < 3e-2, (s, k, got[k], ref[k])
+        assert _rel(got["gp"], ref["gp"]) < 6e-2, (s, got["gp"], ref["gp"])
+    ref, got, dgr, ggr = out[-1]
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.5e-1, "d_grads")
+    _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.5e-1, "g_grads")
+
+
+def test_free_running_golden_f32():
+    """Free-running (no teacher forcing) against the fixture captured from the reference's own trainer run
+    (tests/golden/dcgan_steps.json, B=8, 3 steps, noise from the global CPU generator in the reference's order)."""
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import load_golden, synth_images
+    gold = load_golden("dcgan_steps")["B8"]
+    B = 8
+    torch.manual_seed(12345)
+    g, d = build_params("dcgan")
+    eng = DcganEngine(batch=B, prec="f32")
+    eng.load_state(g, d)
+    fixed = torch.randn(64, 100, 1, 1)
+    imgs = synth_images(B * 3)
+    for s in range(3):
+        nz = {"n1": torch.randn(B, 3, 64, 64), "z": torch.randn(B, 100, 1, 1), "n2": torch.randn(B, 3, 64, 64),
+              "alpha": torch.rand(B, 1, 1, 1)}
+        got = eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: v.cuda() for k, v in nz.items()}, lr=2e-4)
+        tol = 1e-3 if s == 0 else 5e-3          # later steps inherit Adam's amplification of rounding noise
+        assert _rel(got["loss_d"], gold["losses_d"][s]) < tol, (s, got["loss_d"], gold["losses_d"][s])
+        assert _rel(got["loss_g"], gold["losses_g"][s]) < tol * 3, (s, got["loss_g"], gold["losses_g"][s])
+        assert _rel(got["gp"], gold["step"][s]["gp"]) < tol * 3
+        if s == 0 or s == 2:
+            eng.sample(fixed.cuda())        # the eval branch moves G's BN running statistics
+
+
+def test_default_lr_clamp_plateau():
+    """lr 0.1 (main.py:54): D saturates after one step; BCELoss's -100 clamp gives loss_g = 10, loss_d = 110."""
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import load_golden, synth_images
+    gold = load_golden("dcgan_steps")["B8_lr0.1"]
+    B = 8
+    torch.manual_seed(12345)
+    g, d = build_params("dcgan")
+    eng = DcganEngine(batch=B, prec="f32")
+    eng.load_state(g, d)
+    fixed = torch.randn(64, 100, 1, 1)
+    imgs = synth_images(B * 4)
+    for s in range(4):
+        nz = {"n1": torch.randn(B, 3, 64, 64), "z": torch.randn(B, 100, 1, 1), "n2": torch.randn(B, 3, 64, 64),
+              "alpha": torch.rand(B, 1, 1, 1)}
+        got = eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: v.cuda() for k, v in nz.items()}, lr=0.1)
+        if s == 0:
+            eng.sample(fixed.cuda())
+        assert _rel(got["loss_d"], gold["losses_d"][s]) < 1e-3, (s, got)
+        assert _rel(got["loss_g"], gold["losses_g"][s]) < 1e-3, (s, got)
+
+
+def test_sample_matches_oracle():
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import GanOracle
+    orc = GanOracle("dcgan", seed=12345)
+    eng = DcganEngine(batch=16, prec="f32")
+    eng.load_state(orc.g, orc.d)
+    z = torch.randn(40, 100, 1, 1, generator=torch.Generator().manual_seed(3))
+    got = eng.sample(z.cuda()).cpu()
+    ref = torch.cat([orc.sample(z[i:i + 16]) for i in range(0, 40, 16)])
+    assert (got - ref).abs().max().item() < 2e-4
+
+
+def test_bf16_trajectory_statistics():
+    """30 free-running bf16 steps at B=64 stay inside the envelope the reference shows against ITSELF
+    (8 vs 1 thread, tests/golden/selfdiv.json): mean |rel diff| of loss_d over steps 10..29 within 3x of it."""
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import GanOracle
+    from util import load_golden, synth_images
+    sd = load_golden("selfdiv")
+    B, steps = 64, 30
+    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+    eng = DcganEngine(batch=B, prec="bf16")
+    eng.load_state(orc.g, orc.d)
+    imgs = synth_images(B * 4)
+    rd = []
+    for s in range(steps):
+        real, nz = imgs[(s % 4) * B:(s % 4 + 1) * B], _noise(B, 500 + s)
+        ref = orc.step(real, None, nz)
+        got = eng.step(real.cuda(), {k: v.cuda() for k, v in nz.items()}, lr=2e-4)
+        rd.append(_rel(got["loss_d"], ref["loss_d"]))
+        assert got["loss_d"] == got["loss_d"] and got["loss_g"] == got["loss_g"]     # no NaN
+    floor = sum(sd["rel_d"][10:30]) / 20
+    assert sum(rd[10:30]) / 20 < max(3 * floor, 0.15), (rd, floor)
+    assert rd[0] < 3e-2
