@@ -14,8 +14,8 @@
  *   - no allocation, no ownership transfer: outputs and workspaces are caller-allocated
  *   - asynchronous with respect to the host; thread-compatible (one stream per caller thread)
  *   - `prec` selects storage / arithmetic:
- *       JCK_PREC_BF16  activations + gradients bf16 in HBM, bf16 MFMA, fp32 accumulate   (fast)
- *       JCK_PREC_F32   activations + gradients fp32 in HBM, split-bf16 x3 MFMA (~2^-16) (parity)
+ *       JCK_PREC_BF16  activations, gradients, GEMM operands bf16 in HBM; v_mfma_f32_16x16x32_bf16, fp32 accumulate (fast)
+ *       JCK_PREC_F32   everything fp32 in HBM; v_mfma_f32_16x16x4_f32 = exact fp32 products + accumulation      (parity)
  *     "T" below means bf16 (2 bytes) or float according to `prec`
  *   - activations are NHWC; 3-channel images are stored with 4 channels (4th = 0)
  *   - a stride-2 stage is described by its BIG side [N,Hb,Wb,Cb] and SMALL side [N,Hb/2,Wb/2,Cs];
@@ -45,30 +45,34 @@ int jck_pad_rows(int c);
 /* channels per pixel as stored in HBM: 3 -> 4, otherwise c (must be a power of two) */
 int jck_pad_chan(int c);
 
-/* ---- weight packing: fp32 parameter -> bf16 GEMM operand planes (hi, and lo for JCK_PREC_F32; lo may be NULL) ----
+/* ---- weight packing: fp32 parameter -> GEMM operand of element type T ---------------------------------------------
  * down : [pad_rows(Cs)][16*pad_chan(Cb)]      operand of Conv2d forward / ConvTranspose2d dgrad
  * up   : [4][pad_rows(Cb)][4*Cs]              operand of ConvTranspose2d forward / Conv2d dgrad
  * g1   : [16*Co][CiPad]                       G.conv1, ConvTranspose2d(k4,s1,p0) on a 1x1 input (model/DCGAN.py:42)
  * head : float[16*C]                          D.conv5, Conv2d(512,1,k4,s1,p0) as a dot product (model/DCGAN.py:26) */
-int jck_pack_down(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream);
-int jck_pack_up(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream);
-int jck_pack_g1(const float* w, int Ci, int Co, int CiPad, void* hi, void* lo, void* stream);
+size_t jck_packed_bytes(int prec, long long elems);
+int jck_pack_down(int prec, const float* w, int Cs, int Cb, void* wp, void* stream);
+int jck_pack_up(int prec, const float* w, int Cs, int Cb, void* wp, void* stream);
+int jck_pack_g1(int prec, const float* w, int Ci, int Co, int CiPad, void* wp, void* stream);
 int jck_pack_head(const float* w, int C, float* wp, void* stream);
 
 /* ---- convolution-shaped products (replace aten::convolution / convolution_backward) -----------------------
- * stats: float[2*C] (sum, sum of squares per output channel, ACCUMULATED into - zero it first) or NULL */
+ * stats (optional): partial per-channel sums for the BatchNorm that follows, float[slots][2][C] written without
+ * atomics by the GEMM epilogue; *stats_slots receives the slot count to hand to jck_bn_finalize.  The buffer must
+ * hold jck_stats_floats(output pixels, C, nyrep) floats (nyrep = 16 for jck_g1_fwd, else 1). */
+size_t jck_stats_floats(long long pixels, int C, int nyrep);
 /* small = Conv2d_k4s2p1(big)            model/DCGAN.py:10-22 forward; dgrad of model/DCGAN.py:46-58 */
-int jck_conv_down(int prec, const void* big, const void* w_hi, const void* w_lo, void* small_out, float* stats,
+int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                   int N, int Hb, int Wb, int Cb, int Cs, void* stream);
 /* big = ConvTranspose2d_k4s2p1(small)   model/DCGAN.py:46-58 forward; dgrad of model/DCGAN.py:10-22.  epi_tanh=1 fuses model/DCGAN.py:66 */
-int jck_conv_up(int prec, const void* small_in, const void* w_hi, const void* w_lo, void* big_out, float* stats,
+int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                 int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream);
 /* grad[Cs][Cb][4][4] (+)= sum small (x) gather(big)     weight gradient of either layer kind */
 size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs);
 int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes, float* grad,
                    int accumulate, int N, int Hb, int Wb, int Cb, int Cs, void* stream);
 /* out[B][16*Co] = z[B][CiPad] x W   (NHWC [B,4,4,Co]); stats over Co channels   model/DCGAN.py:42,62 */
-int jck_g1_fwd(int prec, const void* z, const void* w_hi, const void* w_lo, void* out, float* stats, int B, int CiPad,
+int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B, int CiPad,
                int Co, void* stream);
 size_t jck_g1_wgrad_ws_bytes(int B, int CiPad, int Co);
 int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, size_t ws_bytes, float* grad, int accumulate, int B,
@@ -76,9 +80,9 @@ int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, size_t ws_b
 
 /* ---- BatchNorm2d (training mode) + ReLU / LeakyReLU  (model/DCGAN.py:11-24,43-56; aten::native_batch_norm*) ----
  * aux: float[4*C] = scale(gamma*invstd) | shift | mean | invstd, produced by jck_bn_finalize */
-int jck_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* aux, int C,
-                    void* stream);
+int jck_bn_finalize(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                    float* aux, int C, void* stream);
 int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void* a, long long rows, int C, void* stream);
 /* sums: float[2*C] zeroed by the caller; g_y may alias g_a */
 int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,

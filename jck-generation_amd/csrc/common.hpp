@@ -1,5 +1,5 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the DCGAN/CGAN hot path.
-// Wave = 64 lanes, MFMA v_mfma_f32_16x16x32_bf16, LDS tiles with 16-byte padded rows.
+// Wave = 64 lanes; MFMA v_mfma_f32_16x16x32_bf16 (fast) / v_mfma_f32_16x16x4_f32 (parity); padded LDS rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,11 +14,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define JCK_WAVE 64
 
 // ---- precision tags -----------------------------------------------------------------------------
-// Bf16 : activations stored bf16, one MFMA per product           (fast mode)
-// F32  : activations stored f32, every operand split hi+lo bf16, three MFMAs per product
-//        (a*b ~= ah*bh + ah*bl + al*bh, relative error ~2^-16)   (parity mode)
-struct PrecBf16 { typedef bf16_t T; static constexpr int NPLANE = 1; };
-struct PrecF32  { typedef float  T; static constexpr int NPLANE = 2; };
+// Bf16 : activations, gradients and GEMM operands bf16 in HBM/LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulate (fast)
+// F32  : everything fp32 in HBM/LDS, v_mfma_f32_16x16x4_f32 = exact fp32 products and accumulation (parity;
+//        1/16 of the bf16 MFMA rate)
+struct PrecBf16 { typedef bf16_t T; typedef bf16_t W; static constexpr bool IS_F32 = false; };
+struct PrecF32  { typedef float  T; typedef float  W; static constexpr bool IS_F32 = true; };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {                  // RNE, NaN stays NaN (v_cvt_pk_bf16_f32)
@@ -27,11 +27,6 @@ __device__ __forceinline__ bf16_t f2bf(float f) {                  // RNE, NaN s
 }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-}
-// split f into hi + lo bf16 (lo = rne(f - hi))
-__device__ __forceinline__ void split_bf(float f, bf16_t& hi, bf16_t& lo) {
-  hi = f2bf(f);
-  lo = f2bf(f - bf2f(hi));
 }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
@@ -129,6 +124,27 @@ __device__ __forceinline__ bf16x8 join_tr(short4v a, short4v b) {
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> { u32x4 v; };
 template <> struct Raw8<float> { f32x4 a, b; };
+__device__ __forceinline__ void zero_raw(Raw8<bf16_t>& r) { r.v = u32x4{0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ void zero_raw(Raw8<float>& r) { r.a = f32x4{0.f, 0.f, 0.f, 0.f}; r.b = r.a; }
+__device__ __forceinline__ void ldraw(const bf16_t* p, Raw8<bf16_t>& r) { r.v = *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void ldraw(const float* p, Raw8<float>& r) {
+  r.a = *reinterpret_cast<const f32x4*>(p);
+  r.b = *reinterpret_cast<const f32x4*>(p + 4);
+}
+// half = 4 elements (one 4-channel pixel) into slot h of the 8-element unit
+__device__ __forceinline__ void ldraw_half(const bf16_t* p, Raw8<bf16_t>& r, int h) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  if (h == 0) { r.v[0] = t[0]; r.v[1] = t[1]; } else { r.v[2] = t[0]; r.v[3] = t[1]; }
+}
+__device__ __forceinline__ void ldraw_half(const float* p, Raw8<float>& r, int h) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  if (h == 0) r.a = t; else r.b = t;
+}
+__device__ __forceinline__ void straw(bf16_t* p, const Raw8<bf16_t>& r) { *reinterpret_cast<u32x4*>(p) = r.v; }
+__device__ __forceinline__ void straw(float* p, const Raw8<float>& r) {
+  *reinterpret_cast<f32x4*>(p) = r.a;
+  *reinterpret_cast<f32x4*>(p + 4) = r.b;
+}
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

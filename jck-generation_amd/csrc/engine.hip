@@ -78,7 +78,7 @@ struct Carver {
   }
 };
 
-struct BnBuf { float *stats, *sums, *aux; };
+struct BnBuf { float *stats, *sums, *aux; int slots; };
 
 }  // namespace
 
@@ -93,9 +93,9 @@ struct jck_engine {
   float *dp = nullptr, *dg = nullptr, *dm = nullptr, *dv = nullptr, *dbn = nullptr;
   int64_t *gnbt = nullptr, *dnbt = nullptr;
   // packed weights
-  void *d_down_hi[4], *d_down_lo[4], *d_up_hi[4], *d_up_lo[4];
+  void *d_down[4], *d_up[4];
   float *d_head_wp, *d_head_dwp;
-  void *g1_hi, *g1_lo, *g_up_hi[4], *g_up_lo[4], *g_down_hi[4], *g_down_lo[4];
+  void *g1_w, *g_up[4], *g_down[4];
   // activations
   void *d_y[4], *d_a[4], *d_g[4], *d_gx;
   void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
@@ -112,18 +112,14 @@ struct jck_engine {
     const size_t e = esz;
     auto bytes = [&](size_t n) { return n * e; };
     for (int i = 0; i < 4; ++i) {
-      const size_t nd = (size_t)jck_pad_rows(D_CS[i]) * 16 * jck_pad_chan(D_CB[i]);
-      d_down_hi[i] = c.take<bf16_t>(nd); d_down_lo[i] = c.take<bf16_t>(nd);
-      const size_t nu = (size_t)4 * jck_pad_rows(D_CB[i]) * 4 * D_CS[i];
-      d_up_hi[i] = c.take<bf16_t>(nu); d_up_lo[i] = c.take<bf16_t>(nu);
+      d_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(D_CS[i]) * 16 * jck_pad_chan(D_CB[i])));
+      d_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(D_CB[i]) * 4 * D_CS[i]));
     }
     d_head_wp = c.take<float>(8192); d_head_dwp = c.take<float>(8192);
-    g1_hi = c.take<bf16_t>((size_t)16 * G_C1 * Z_PAD); g1_lo = c.take<bf16_t>((size_t)16 * G_C1 * Z_PAD);
+    g1_w = c.take<unsigned char>(bytes((size_t)16 * G_C1 * Z_PAD));
     for (int i = 0; i < 4; ++i) {
-      const size_t nu = (size_t)4 * jck_pad_rows(G_CB[i]) * 4 * G_CS[i];
-      g_up_hi[i] = c.take<bf16_t>(nu); g_up_lo[i] = c.take<bf16_t>(nu);
-      const size_t nd = (size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i]);
-      g_down_hi[i] = c.take<bf16_t>(nd); g_down_lo[i] = c.take<bf16_t>(nd);
+      g_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(G_CB[i]) * 4 * G_CS[i]));
+      g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i])));
     }
     const size_t img = (size_t)B * 64 * 64 * 4;
     for (int i = 0; i < 4; ++i) {
@@ -144,14 +140,21 @@ struct jck_engine {
     {
       size_t start = c.off;
       zero_d = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) { d_bn[i].stats = c.take<float>(2 * D_CS[i]); d_bn[i].sums = c.take<float>(2 * D_CS[i]); }
+      for (int i = 0; i < 4; ++i) d_bn[i].sums = c.take<float>(2 * D_CS[i]);
       zero_d_bytes = c.off - start;
-      for (int i = 0; i < 4; ++i) d_bn[i].aux = c.take<float>(4 * D_CS[i]);
+      for (int i = 0; i < 4; ++i) {
+        d_bn[i].aux = c.take<float>(4 * D_CS[i]);
+        d_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
+      }
       start = c.off;
       zero_g = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) { const int C = 512 >> i; g_bn[i].stats = c.take<float>(2 * C); g_bn[i].sums = c.take<float>(2 * C); }
+      for (int i = 0; i < 4; ++i) g_bn[i].sums = c.take<float>(2 * (512 >> i));
       zero_g_bytes = c.off - start;
-      for (int i = 0; i < 4; ++i) g_bn[i].aux = c.take<float>(4 * (512 >> i));
+      for (int i = 0; i < 4; ++i) {
+        const int C = 512 >> i, h = 4 << i;
+        g_bn[i].aux = c.take<float>(4 * C);
+        g_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * h * h, C, i == 0 ? 16 : 1));
+      }
     }
     acc = c.take<float>(16); scal_out = c.take<float>(8);
     prob = c.take<float>(B); ds = c.take<float>(B); norms = c.take<float>(B);
@@ -225,16 +228,16 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
   if (net == 1) {
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LD, e->dp, NAMES_CW[i]);
-      JCK_TRY(jck_pack_down(w, D_CS[i], D_CB[i], e->d_down_hi[i], e->d_down_lo[i], stream));
-      JCK_TRY(jck_pack_up(w, D_CS[i], D_CB[i], e->d_up_hi[i], e->d_up_lo[i], stream));
+      JCK_TRY(jck_pack_down(e->prec, w, D_CS[i], D_CB[i], e->d_down[i], stream));
+      JCK_TRY(jck_pack_up(e->prec, w, D_CS[i], D_CB[i], e->d_up[i], stream));
     }
     JCK_TRY(jck_pack_head(e->P(e->LD, e->dp, NAMES_CW[4]), 512, e->d_head_wp, stream));
   } else {
-    JCK_TRY(jck_pack_g1(e->P(e->LG, e->gp, NAMES_CW[0]), Z_DIM, G_C1, Z_PAD, e->g1_hi, e->g1_lo, stream));
+    JCK_TRY(jck_pack_g1(e->prec, e->P(e->LG, e->gp, NAMES_CW[0]), Z_DIM, G_C1, Z_PAD, e->g1_w, stream));
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
-      JCK_TRY(jck_pack_up(w, G_CS[i], G_CB[i], e->g_up_hi[i], e->g_up_lo[i], stream));
-      JCK_TRY(jck_pack_down(w, G_CS[i], G_CB[i], e->g_down_hi[i], e->g_down_lo[i], stream));
+      JCK_TRY(jck_pack_up(e->prec, w, G_CS[i], G_CB[i], e->g_up[i], stream));
+      JCK_TRY(jck_pack_down(e->prec, w, G_CS[i], G_CB[i], e->g_down[i], stream));
     }
   }
   return JCK_OK;
@@ -250,9 +253,9 @@ static int d_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
   const void* in = x_in;
   for (int i = 0; i < 4; ++i) {
     const int hb = D_HB[i], cs = D_CS[i];
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down_hi[i], e->d_down_lo[i], e->d_y[i], e->d_bn[i].stats, B, hb, hb, D_CB[i], cs, st));
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], e->d_y[i], e->d_bn[i].stats, &e->d_bn[i].slots, B, hb, hb, D_CB[i], cs, st));
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn_finalize(e->d_bn[i].stats, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
+    JCK_TRY(jck_bn_finalize(e->d_bn[i].stats, e->d_bn[i].slots, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
                             e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
                             e->dnbt + i, BN_MOM, BN_EPS, e->d_bn[i].aux, cs, st));
     JCK_TRY(jck_bn_act_fwd(e->prec, e->d_y[i], e->d_bn[i].aux, LRELU, e->d_a[i], rows, cs, st));
@@ -274,9 +277,9 @@ static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, b
     if (want_wgrad)
       JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
     if (i > 0)
-      JCK_TRY(jck_conv_up(e->prec, e->d_g[i], e->d_up_hi[i], e->d_up_lo[i], e->d_g[i - 1], nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+      JCK_TRY(jck_conv_up(e->prec, e->d_g[i], e->d_up[i], e->d_g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
     else if (want_xgrad)
-      JCK_TRY(jck_conv_up(e->prec, e->d_g[0], e->d_up_hi[0], e->d_up_lo[0], e->d_gx, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+      JCK_TRY(jck_conv_up(e->prec, e->d_g[0], e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
   return JCK_OK;
 }
@@ -292,18 +295,18 @@ static int g_forward(jck_engine* e, const float* z, int B, bool update_running, 
   HIPCHK(hipMemsetAsync(e->zero_g, 0, e->zero_g_bytes, st));
   if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, e->g_z, st); else launch_pad_rows<float>(z, B, e->g_z, st);
   HIPCHK(hipGetLastError());
-  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_hi, e->g1_lo, e->g_y[0], e->g_bn[0].stats, B, Z_PAD, G_C1, st));
+  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, Z_PAD, G_C1, st));
   for (int i = 0; i < 4; ++i) {
     const int h = 4 << i, C = 512 >> i;
     const long long rows = (long long)B * h * h;
-    JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, (float)rows, e->P(e->LG, e->gp, NAMES_NW[i]), e->P(e->LG, e->gp, NAMES_NB[i]),
+    JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NAMES_NW[i]), e->P(e->LG, e->gp, NAMES_NB[i]),
                             e->gbn + find(e->LG, NAMES_RM[i])->offset, e->gbn + find(e->LG, NAMES_RV[i])->offset,
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
     JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
     if (i < 3)
-      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up_hi[i], e->g_up_lo[i], e->g_y[i + 1], e->g_bn[i + 1].stats, 0, B, h, h, G_CS[i], G_CB[i], st));
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, 0, B, h, h, G_CS[i], G_CB[i], st));
     else
-      JCK_TRY(jck_conv_up(e->prec, e->g_a[3], e->g_up_hi[3], e->g_up_lo[3], e->fake_raw, nullptr, 1, B, 32, 32, 64, 3, st));
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[3], e->g_up[3], e->fake_raw, nullptr, nullptr, 1, B, 32, 32, 64, 3, st));
   }
   return JCK_OK;
 }
@@ -316,7 +319,7 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st) 
     const int hs = G_HS[i], cs = G_CS[i], cb = G_CB[i];
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, st));
-    JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down_hi[i], e->g_down_lo[i], e->g_gr[i], nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
+    JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
     const long long rows = (long long)B * hs * hs;
     JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
                            e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));

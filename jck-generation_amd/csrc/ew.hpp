@@ -117,19 +117,34 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, i
 // ------------------------------------------------------------------------------------------------------
 // BatchNorm (training mode always - the reference never switches G/D to eval)
 // ------------------------------------------------------------------------------------------------------
-// stats[0..C) = sum, stats[C..2C) = sum of squares over `count` elements per channel.
+// stats: [slots][2][C] partial sums / sums of squares written by the GEMM epilogue (every slot complete).
 // aux layout (floats): [0,C) scale = gamma*invstd   [C,2C) shift = beta - mean*scale
 //                      [2C,3C) mean                 [3C,4C) invstd
-static __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ nbt, float momentum,
-                                   float eps, float* __restrict__ aux, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  const float mean = stats[c] / count;
-  float var = stats[C + c] / count - mean * mean;
-  var = fmaxf(var, 0.f);
+// One workgroup per 16 channels: 16 slot-lanes x 16 channels, double accumulation, LDS tree over the slot lanes.
+static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int slots, float count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 long long* __restrict__ nbt, float momentum, float eps,
+                                                                 float* __restrict__ aux, int C) {
+  __shared__ double sh[2][16][16];
+  const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cc;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int k = sl; k < slots; k += 16) {
+      s += (double)stats[(long long)k * 2 * C + c];
+      q += (double)stats[(long long)k * 2 * C + C + c];
+    }
+  sh[0][sl][cc] = s;
+  sh[1][sl][cc] = q;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (sl != 0 || c >= C) return;
+  for (int k = 1; k < 16; ++k) { s += sh[0][k][cc]; q += sh[1][k][cc]; }
+  const double meand = s / (double)count;
+  double vard = q / (double)count - meand * meand;
+  if (vard < 0.0) vard = 0.0;
+  const float mean = (float)meand, var = (float)vard;
   const float invstd = 1.0f / sqrtf(var + eps);
   const float sc = gamma[c] * invstd;
   aux[c] = sc;
@@ -315,11 +330,11 @@ static __global__ void adam_kernel(float* __restrict__ p, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------------
-// weight packing (fp32 PyTorch layout [Cs][Cb][4][4] -> bf16 GEMM layouts, hi (+lo) planes)
+// weight packing (fp32 PyTorch layout [Cs][Cb][4][4] -> GEMM operand layouts in bf16 (fast) or fp32 (parity))
 // ------------------------------------------------------------------------------------------------------
 // down: wp[cs][ (kh*4+kw)*CbPad + cb ]   rows cs in [0, CsPad)
-static __global__ void pack_down_kernel(const float* __restrict__ w, int Cs, int Cb, int CsPad, int logCbPad,
-                                 bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+template <typename W>
+__global__ void pack_down_kernel(const float* __restrict__ w, int Cs, int Cb, int CsPad, int logCbPad, W* __restrict__ wp) {
   const long long K = 16ll << logCbPad, total = (long long)CsPad * K;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cs = (int)(i / K);
@@ -327,18 +342,15 @@ static __global__ void pack_down_kernel(const float* __restrict__ w, int Cs, int
     const int t = k >> logCbPad, cb = k & ((1 << logCbPad) - 1);
     float v = 0.f;
     if (cs < Cs && cb < Cb) v = w[((long long)cs * Cb + cb) * 16 + t];
-    bf16_t h, l;
-    split_bf(v, h, l);
-    hi[i] = h;
-    if (lo) lo[i] = l;
+    stf(wp + i, v);
   }
 }
 
 // up: wp[phase][cb][ (th*2+tw)*Cs + cs ], rows cb in [0, CbPad); phase = ph*2+pw;
 // output row 2q+ph takes input rows q + DY[ph][th] through kernel rows KH[ph][th]
 static __device__ __constant__ int c_up_k[2][2] = {{1, 3}, {0, 2}};
-static __global__ void pack_up_kernel(const float* __restrict__ w, int Cs, int Cb, int CbPad, bf16_t* __restrict__ hi,
-                               bf16_t* __restrict__ lo) {
+template <typename W>
+__global__ void pack_up_kernel(const float* __restrict__ w, int Cs, int Cb, int CbPad, W* __restrict__ wp) {
   const long long K = 4ll * Cs, per = (long long)CbPad * K, total = 4 * per;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int phase = (int)(i / per);
@@ -349,16 +361,13 @@ static __global__ void pack_up_kernel(const float* __restrict__ w, int Cs, int C
     const int kh = c_up_k[phase >> 1][t >> 1], kw = c_up_k[phase & 1][t & 1];
     float v = 0.f;
     if (cb < Cb) v = w[((long long)cs * Cb + cb) * 16 + kh * 4 + kw];
-    bf16_t h, l;
-    split_bf(v, h, l);
-    hi[i] = h;
-    if (lo) lo[i] = l;
+    stf(wp + i, v);
   }
 }
 
 // G.conv1 (ConvTranspose on a 1x1 input): wp[(kh*4+kw)*Co + co][ci], ci in [0, CiPad)
-static __global__ void pack_g1_kernel(const float* __restrict__ w, int Ci, int Co, int CiPad, bf16_t* __restrict__ hi,
-                               bf16_t* __restrict__ lo) {
+template <typename W>
+__global__ void pack_g1_kernel(const float* __restrict__ w, int Ci, int Co, int CiPad, W* __restrict__ wp) {
   const long long total = 16ll * Co * CiPad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ci = (int)(i % CiPad);
@@ -366,10 +375,7 @@ static __global__ void pack_g1_kernel(const float* __restrict__ w, int Ci, int C
     const int co = (int)(r % Co), t = (int)(r / Co);
     float v = 0.f;
     if (ci < Ci) v = w[((long long)ci * Co + co) * 16 + t];
-    bf16_t h, l;
-    split_bf(v, h, l);
-    hi[i] = h;
-    if (lo) lo[i] = l;
+    stf(wp + i, v);
   }
 }
 

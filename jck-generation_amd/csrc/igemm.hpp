@@ -7,22 +7,24 @@
 //     (blockIdx.z), each a 2x2-tap stride-1 product - no zero insertion, no col2im atomics
 //   * ConvTranspose2d k4 s1 p0 on a 1x1 input (G.conv1) and plain row-major GEMMs: 1 tap
 //
-// Tiling for CDNA4: 256 threads = 4 waves, v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the MFMA
-// A operand (rows = output channels) and the gathered activations as B (cols = pixels), so a lane
-// ends up with 4 consecutive channels of one pixel (one 8/16-byte NHWC store).  Both operands are
-// staged through registers into K-contiguous LDS rows padded by 16 B; global loads for k-step i+1
-// are issued before the MFMAs of step i (double-buffered LDS, one barrier per k-step).
-// Optional epilogue: per-channel sum / sum-of-squares for the BatchNorm that follows (wavefront
-// shuffles over the 16 pixel lanes, then one atomic per channel per wave) and tanh.
+// Tiling for CDNA4: 256 threads = 4 waves; the WEIGHTS are the MFMA A operand (rows = output
+// channels) and the gathered activations B (cols = pixels), so a lane ends up with 4 consecutive
+// channels of one pixel (one 8/16-byte NHWC store).  Both operands are staged through registers into
+// K-contiguous padded LDS rows; global loads for k-step i+1 are issued before the MFMAs of step i
+// (double-buffered LDS, one barrier per k-step).
+//   PrecBf16: bf16 tiles, v_mfma_f32_16x16x32_bf16          (fast path)
+//   PrecF32 : fp32 tiles, v_mfma_f32_16x16x4_f32 - exact fp32 products and accumulation (parity path)
+// Optional epilogue: per-channel sum / sum-of-squares of the fp32 accumulators for the BatchNorm that
+// follows - reduced over the 16 pixel lanes with wavefront shuffles and stored (no atomics) into a
+// per-(tile, wave) slot that jck_bn_finalize sums - and tanh.
 #pragma once
 #include "common.hpp"
 
 struct IgemmParams {
   const void* act;        // gathered NHWC tensor, element type T
-  const bf16_t* w_hi;     // packed weights [Z][NchPad][K]  (K contiguous, K % 64 == 0)
-  const bf16_t* w_lo;     // low halves (PrecF32 only)
+  const void* w;          // packed weights [Z][NchPad][K]  (K contiguous, K % 64 == 0), bf16 or fp32
   void* out;              // NHWC output, element type T
-  float* stats;           // [2][cstat] sum, sumsq (or nullptr)
+  float* stats;           // [slots][2][cstat] partial sum, sumsq (or nullptr)
   int M;                  // pixel rows per phase
   int NchStore;           // channels physically stored per output pixel (multiple of 4)
   int K;                  // ntaps << logC
@@ -35,36 +37,40 @@ struct IgemmParams {
   long long osN;          // output offset = n*osN + oy*osY + ox*osX + obase[z]   (elements)
   int osY, osX;
   int obase[4];
-  int cstat_mask;         // stats channel = ch & cstat_mask
-  int cstat;              // number of stats channels
+  int cstat;              // number of stats channels; stats channel = ch % cstat (cstat power of two)
+  int ytiles_per_cset;    // channel tiles (blockIdx.y) that cover one set of cstat channels
   int epi;                // 0 none, 1 tanh
   long long w_phase_stride;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
 #define IG_BK 64
-#define IG_LD 72          // padded LDS row (elements)
 
 template <class P, int BCH, int BPIX> struct IgemmCfg {
+  static constexpr bool F32 = P::IS_F32;
   static constexpr int WCH = (BCH >= 64) ? 2 : 1;
   static constexpr int WPIX = 4 / WCH;
   static constexpr int FM = BCH / WCH / 16;
   static constexpr int FN = BPIX / WPIX / 16;
-  static constexpr int NPL = P::NPLANE;
   static constexpr int WPASS = (BCH + 31) / 32;
   static constexpr int APASS = BPIX / 32;
-  static constexpr int BUF_ELEMS = NPL * (BCH + BPIX) * IG_LD;
-  static constexpr int LDS_BYTES = 2 * BUF_ELEMS * 2 + 64;
+  static constexpr int LD = F32 ? (IG_BK + 4) : (IG_BK + 8);           // padded LDS row (elements)
+  static constexpr int ESZ = F32 ? 4 : 2;
+  static constexpr int BUF_BYTES = (BCH + BPIX) * LD * ESZ;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 64;
+  // slots of partial statistics written by one launch = gridDim.x * gridDim.z * (gridDim.y / ytiles_per_cset) * WPIX
 };
 
 template <class P, int BCH, int BPIX, int NSUB>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  typedef typename P::T T;
+  typedef typename P::T T;        // activation storage type
+  typedef typename P::W W;        // LDS / packed-weight element type (bf16_t or float)
   typedef IgemmCfg<P, BCH, BPIX> C;
-  constexpr int NPL = C::NPL, FM = C::FM, FN = C::FN;
+  constexpr bool F32 = C::F32;
+  constexpr int FM = C::FM, FN = C::FN, LD = C::LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* toff = reinterpret_cast<int*>(smem_raw);                    // 16 ints
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem_raw + 64);
+  unsigned char* lds = smem_raw + 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int z = blockIdx.z;
@@ -94,93 +100,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     rmask[ps] = mk;
   }
-  const bf16_t* whi = p.w_hi + (long long)z * p.w_phase_stride;
-  const bf16_t* wlo = (NPL == 2) ? p.w_lo + (long long)z * p.w_phase_stride : nullptr;
+  const W* wsrc = reinterpret_cast<const W*>(p.w) + (long long)z * p.w_phase_stride;
   __syncthreads();   // toff visible
 
   Raw8<T> areg[C::APASS];
-  u32x4 wreg[NPL][C::WPASS];
+  Raw8<W> wreg[C::WPASS];
 
   auto load_tiles = [&](int kc) {
     const int k = kc * IG_BK + unit * 8;
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
-      if (BCH >= 32 || r < BCH) {
-        const long long o = (long long)(ch0 + r) * p.K + k;
-        wreg[0][ps] = *reinterpret_cast<const u32x4*>(whi + o);
-        if (NPL == 2) wreg[NPL - 1][ps] = *reinterpret_cast<const u32x4*>(wlo + o);
-      }
+      if (BCH >= 32 || r < BCH) ldraw(wsrc + (long long)(ch0 + r) * p.K + k, wreg[ps]);
     }
 #pragma unroll
     for (int ps = 0; ps < C::APASS; ++ps) {
       if constexpr (NSUB == 1) {
         const int t = k >> p.logC, c = k & (Cc - 1);
-        const bool ok = (rmask[ps] >> t) & 1u;
-        const T* src = actp + (rowbase[ps] + toff[t] + c);
-        if constexpr (sizeof(T) == 2) {
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (ok) v = *reinterpret_cast<const u32x4*>(src);
-          areg[ps].v = v;
-        } else {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-          if (ok) { a = *reinterpret_cast<const f32x4*>(src); b = *reinterpret_cast<const f32x4*>(src + 4); }
-          areg[ps].a = a; areg[ps].b = b;
-        }
+        zero_raw(areg[ps]);
+        if ((rmask[ps] >> t) & 1u) ldraw(actp + (rowbase[ps] + toff[t] + c), areg[ps]);
       } else {   // C == 4: the 8-element unit spans two taps (pixels)
         const int t0 = k >> 2, t1 = t0 + 1;
-        const bool ok0 = (rmask[ps] >> t0) & 1u, ok1 = (rmask[ps] >> t1) & 1u;
-        const T* s0 = actp + (rowbase[ps] + toff[t0]);
-        const T* s1 = actp + (rowbase[ps] + toff[t1]);
-        if constexpr (sizeof(T) == 2) {
-          u32x2 a = {0u, 0u}, b = {0u, 0u};
-          if (ok0) a = *reinterpret_cast<const u32x2*>(s0);
-          if (ok1) b = *reinterpret_cast<const u32x2*>(s1);
-          u32x4 v = {a[0], a[1], b[0], b[1]};
-          areg[ps].v = v;
-        } else {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-          if (ok0) a = *reinterpret_cast<const f32x4*>(s0);
-          if (ok1) b = *reinterpret_cast<const f32x4*>(s1);
-          areg[ps].a = a; areg[ps].b = b;
-        }
+        zero_raw(areg[ps]);
+        if ((rmask[ps] >> t0) & 1u) ldraw_half(actp + (rowbase[ps] + toff[t0]), areg[ps], 0);
+        if ((rmask[ps] >> t1) & 1u) ldraw_half(actp + (rowbase[ps] + toff[t1]), areg[ps], 1);
       }
     }
   };
 
   auto store_tiles = [&](int buf) {
-    bf16_t* base = lds + buf * C::BUF_ELEMS;
-    bf16_t* wt = base;                                   // [NPL][BCH][LD]
-    bf16_t* at = base + NPL * BCH * IG_LD;               // [NPL][BPIX][LD]
+    W* wt = reinterpret_cast<W*>(lds + buf * C::BUF_BYTES);      // [BCH][LD]
+    W* at = wt + BCH * LD;                                        // [BPIX][LD]
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
-      if (BCH >= 32 || r < BCH) {
-        *reinterpret_cast<u32x4*>(wt + r * IG_LD + unit * 8) = wreg[0][ps];
-        if (NPL == 2) *reinterpret_cast<u32x4*>(wt + (BCH + r) * IG_LD + unit * 8) = wreg[NPL - 1][ps];
-      }
+      if (BCH >= 32 || r < BCH) straw(wt + r * LD + unit * 8, wreg[ps]);
     }
 #pragma unroll
-    for (int ps = 0; ps < C::APASS; ++ps) {
-      const int r = ps * 32 + lrow;
-      if constexpr (sizeof(T) == 2) {
-        *reinterpret_cast<u32x4*>(at + r * IG_LD + unit * 8) = areg[ps].v;
-      } else {
-        float f[8] = {areg[ps].a[0], areg[ps].a[1], areg[ps].a[2], areg[ps].a[3],
-                      areg[ps].b[0], areg[ps].b[1], areg[ps].b[2], areg[ps].b[3]};
-        u32x4 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bf16_t h0, l0, h1, l1;
-          split_bf(f[2 * i], h0, l0);
-          split_bf(f[2 * i + 1], h1, l1);
-          hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-          lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        *reinterpret_cast<u32x4*>(at + r * IG_LD + unit * 8) = hi;
-        *reinterpret_cast<u32x4*>(at + (BPIX + r) * IG_LD + unit * 8) = lo;
-      }
-    }
+    for (int ps = 0; ps < C::APASS; ++ps) straw(at + (ps * 32 + lrow) * LD + unit * 8, areg[ps]);
   };
 
   const int wch = (C::WCH == 2) ? (wave >> 1) : 0;
@@ -198,32 +155,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   for (int kc = 0; kc < nk; ++kc) {
     const bool more = kc + 1 < nk;
     if (more) load_tiles(kc + 1);
-    const bf16_t* base = lds + (kc & 1) * C::BUF_ELEMS;
-    const bf16_t* wt = base + (wch * FM * 16 + (lane & 15)) * IG_LD + (lane >> 4) * 8;
-    const bf16_t* at = base + NPL * BCH * IG_LD + (wpix * FN * 16 + (lane & 15)) * IG_LD + (lane >> 4) * 8;
+    const W* wt0 = reinterpret_cast<const W*>(lds + (kc & 1) * C::BUF_BYTES);
+    const W* at0 = wt0 + BCH * LD;
+    if constexpr (!F32) {
+      const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD + (lane >> 4) * 8;
+      const bf16_t* at = at0 + (wpix * FN * 16 + (lane & 15)) * LD + (lane >> 4) * 8;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[NPL][FM], b[NPL][FN];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[FM], b[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        a[0][i] = lds_frag(wt + i * 16 * IG_LD + ks * 32);
-        if (NPL == 2) a[NPL - 1][i] = lds_frag(wt + (BCH + i * 16) * IG_LD + ks * 32);
+        for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + ks * 32);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + ks * 32);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
       }
+    } else {
+      // v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k = l>>4], B[k = l>>4][col l&15]
+      const float* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD + (lane >> 4);
+      const float* at = at0 + (wpix * FN * 16 + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll 4
+      for (int kk = 0; kk < IG_BK / 4; ++kk) {
+        float a[FM], b[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        b[0][j] = lds_frag(at + j * 16 * IG_LD + ks * 32);
-        if (NPL == 2) b[NPL - 1][j] = lds_frag(at + (BPIX + j * 16) * IG_LD + ks * 32);
+        for (int i = 0; i < FM; ++i) a[i] = wt[i * 16 * LD + kk * 4];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = at[j * 16 * LD + kk * 4];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if (NPL == 2) {   // small terms first
-            acc[i][j] = mfma16(a[NPL - 1][i], b[0][j], acc[i][j]);
-            acc[i][j] = mfma16(a[0][i], b[NPL - 1][j], acc[i][j]);
-          }
-          acc[i][j] = mfma16(a[0][i], b[0][j], acc[i][j]);
-        }
     }
     if (more) store_tiles((kc + 1) & 1);
     __syncthreads();
@@ -231,6 +195,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   // ---- epilogue --------------------------------------------------------------------------------------
   if (p.stats) {
+    // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
+    const int yrep = blockIdx.y / p.ytiles_per_cset, nyrep = gridDim.y / p.ytiles_per_cset;
+    const long long slot = (((long long)z * gridDim.x + blockIdx.x) * nyrep + yrep) * C::WPIX + wpix;
+    float* sp = p.stats + slot * 2 * p.cstat;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -243,11 +211,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       if ((lane & 15) == 0) {
         const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
         if (ch < p.NchStore) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(p.stats + ((ch + r) & p.cstat_mask), s[r]);
-            atomicAdd(p.stats + p.cstat + ((ch + r) & p.cstat_mask), q[r]);
-          }
+          const int cc = ch & (p.cstat - 1);
+          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
+          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
         }
       }
     }

@@ -12,6 +12,13 @@ extern "C" int jck_pad_chan(int c) { return c == 3 ? 4 : c; }
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+#define DISPATCH_T(prec, CALL)                                  \
+  do {                                                          \
+    if ((prec) == JCK_PREC_BF16) { typedef bf16_t T; CALL; }    \
+    else if ((prec) == JCK_PREC_F32) { typedef float T; CALL; } \
+    else JCK_FAIL(JCK_E_ARG, "bad prec");                       \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------------------
 // optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's roofline
 // leg).  Off by default: zero cost in the timed region.
@@ -31,12 +38,12 @@ struct ProfScope {
   ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
     if (!on) return;
     r.variant = variant; r.flops = flops;
-    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-    hipEventRecord(r.e0, st);
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(r.e1, st);
+    (void)hipEventRecord(r.e1, st);
     g_prof.push_back(r);
   }
 };
@@ -51,11 +58,11 @@ extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, 
   constexpr int NV = sizeof(PROF_NAMES) / sizeof(PROF_NAMES[0]);
   int cnt[NV] = {0}; double ms[NV] = {0}, fl[NV] = {0};
   for (auto& r : g_prof) {
-    hipEventSynchronize(r.e1);
+    (void)hipEventSynchronize(r.e1);
     float t = 0.f;
-    hipEventElapsedTime(&t, r.e0, r.e1);
+    (void)hipEventElapsedTime(&t, r.e0, r.e1);
     if (r.variant >= 0 && r.variant < NV) { cnt[r.variant]++; ms[r.variant] += t; fl[r.variant] += r.flops; }
-    hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
   int n = 0;
@@ -68,9 +75,9 @@ extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, 
 // gather-GEMM dispatch
 // ---------------------------------------------------------------------------------------------------------
 template <class P, int BCH, int BPIX, int NSUB>
-static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStream_t st) {
+static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   typedef IgemmCfg<P, BCH, BPIX> C;
-  constexpr int variant = (P::NPLANE == 2 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
+  constexpr int variant = (P::IS_F32 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
   ProfScope prof(variant, p.flops, st);
   auto kern = igemm_kernel<P, BCH, BPIX, NSUB>;
   static bool attr_done = false;
@@ -79,68 +86,78 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  IgemmParams q = p;
+  if (q.stats) {
+    if (q.cstat % BCH != 0 && BCH % q.cstat != 0) JCK_FAIL(JCK_E_ARG, "igemm: stats channel count incompatible with the tile");
+    q.ytiles_per_cset = std::max(1, q.cstat / BCH);
+    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * C::WPIX);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
 
 template <class P>
-static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st) {
+static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   if (nch_pad % 128 == 0) {
     if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4-channel gather with >=128 output rows unsupported");
     // keep >= ~256 workgroups in flight: halve the pixel tile for small pixel counts
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
-    if (wgs >= 256) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st);
-    return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st);
+    if (wgs >= 256) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st, slots);
+    return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
-    if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st);
-    return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st);
+    if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
+    return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 16) {
     if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4->4 channel product unsupported");
-    return launch_igemm_t<P, 16, 256, 1>(p, nch_pad, phases, st);
+    return launch_igemm_t<P, 16, 256, 1>(p, nch_pad, phases, st, slots);
   }
   JCK_FAIL(JCK_E_ARG, "igemm: unsupported padded row count " + std::to_string(nch_pad));
 }
 
-int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st) {
+int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   if (p.K % IG_BK != 0) JCK_FAIL(JCK_E_ARG, "igemm: K must be a multiple of 64, got " + std::to_string(p.K));
   if (p.M <= 0) JCK_FAIL(JCK_E_ARG, "igemm: empty problem");
-  if (prec == JCK_PREC_BF16) return launch_igemm_p<PrecBf16>(p, nch_pad, phases, nsub, st);
-  if (prec == JCK_PREC_F32) {
-    if (!p.w_lo) JCK_FAIL(JCK_E_ARG, "igemm: JCK_PREC_F32 needs the low weight plane");
-    return launch_igemm_p<PrecF32>(p, nch_pad, phases, nsub, st);
-  }
+  if (p.stats && !slots) JCK_FAIL(JCK_E_ARG, "igemm: stats requested without a slot-count output");
+  if (prec == JCK_PREC_BF16) return launch_igemm_p<PrecBf16>(p, nch_pad, phases, nsub, st, slots);
+  if (prec == JCK_PREC_F32) return launch_igemm_p<PrecF32>(p, nch_pad, phases, nsub, st, slots);
   JCK_FAIL(JCK_E_ARG, "bad prec");
 }
 
-extern "C" int jck_conv_down(int prec, const void* big, const void* w_hi, const void* w_lo, void* small_out, float* stats,
+extern "C" size_t jck_stats_floats(long long pixels, int C, int nyrep) {
+  return (size_t)(pixels / 32 + 16) * (size_t)std::max(1, nyrep) * 2 * (size_t)C;
+}
+extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)elems * (prec == JCK_PREC_F32 ? 4 : 2); }
+
+extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                              int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
   const int cbp = jck_pad_chan(Cb);
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_down: shapes must be powers of two (Hb,Wb,Cb) and Cs % 4 == 0");
   if ((long long)N * Hb * Wb * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_down: tensor exceeds 2^31 elements");
   IgemmParams p = {};
-  p.act = big; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = small_out; p.stats = stats;
+  p.act = big; p.w = w; p.out = small_out; p.stats = stats;
   const int OH = Hb / 2, OW = Wb / 2;
   p.M = N * OH * OW; p.NchStore = Cs; p.logC = ilog2(cbp); p.K = 16 << p.logC;
   p.H = Hb; p.W = Wb; p.logOW = ilog2(OW); p.logOHW = ilog2(OH * OW); p.sy = p.sx = 2; p.ntaps = 16;
   for (int t = 0; t < 16; ++t) { p.dy[0][t] = (signed char)(t / 4 - 1); p.dx[0][t] = (signed char)(t % 4 - 1); }
   p.osN = (long long)OH * OW * Cs; p.osY = OW * Cs; p.osX = Cs; p.obase[0] = 0;
-  p.cstat = Cs; p.cstat_mask = 0x7fffffff; p.epi = 0; p.w_phase_stride = 0;
+  p.cstat = Cs; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
+  if (stats && !is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
-  return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream);
+  return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream, stats_slots);
 }
 
-extern "C" int jck_conv_up(int prec, const void* small_in, const void* w_hi, const void* w_lo, void* big_out, float* stats,
+extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                            int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
   const int cbp = jck_pad_chan(Cb);
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_up: shapes must be powers of two (Hs,Ws,Cs>=16)");
   if ((long long)N * Hs * Ws * 4 * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_up: tensor exceeds 2^31 elements");
   IgemmParams p = {};
-  p.act = small_in; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = big_out; p.stats = stats;
+  p.act = small_in; p.w = w; p.out = big_out; p.stats = stats;
   p.M = N * Hs * Ws; p.NchStore = cbp; p.logC = ilog2(Cs); p.K = 4 << p.logC;
   p.H = Hs; p.W = Ws; p.logOW = ilog2(Ws); p.logOHW = ilog2(Hs * Ws); p.sy = p.sx = 1; p.ntaps = 4;
   static const int DI[2][2] = {{0, -1}, {1, 0}};          // input offset of tap th for output parity ph
@@ -151,27 +168,29 @@ extern "C" int jck_conv_up(int prec, const void* small_in, const void* w_hi, con
       p.obase[z] = (ph * 2 * Ws + pw) * cbp;
     }
   p.osN = (long long)4 * Hs * Ws * cbp; p.osY = 2 * 2 * Ws * cbp; p.osX = 2 * cbp;
-  p.cstat = cbp; p.cstat_mask = 0x7fffffff; p.epi = epi_tanh ? 1 : 0;
+  p.cstat = cbp; p.ytiles_per_cset = 1; p.epi = epi_tanh ? 1 : 0;
+  if (stats && !is_pow2(cbp)) JCK_FAIL(JCK_E_ARG, "conv_up: BN statistics need a power-of-two channel count");
   const int rows = jck_pad_rows(Cb);
   p.w_phase_stride = (long long)rows * p.K;
   if (p.K % 64 != 0) JCK_FAIL(JCK_E_ARG, "conv_up: 4*Cs must be a multiple of 64");
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
-  return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream);
+  return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
 }
 
-extern "C" int jck_g1_fwd(int prec, const void* z, const void* w_hi, const void* w_lo, void* out, float* stats, int B,
+extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
                           int CiPad, int Co, void* stream) {
   if (!is_pow2(CiPad) || CiPad < 64 || !is_pow2(Co) || (16 * Co) % 128 != 0)
     JCK_FAIL(JCK_E_ARG, "g1_fwd: CiPad must be a power of two >= 64, Co a power of two");
   IgemmParams p = {};
-  p.act = z; p.w_hi = (const bf16_t*)w_hi; p.w_lo = (const bf16_t*)w_lo; p.out = out; p.stats = stats;
+  p.act = z; p.w = w; p.out = out; p.stats = stats;
   p.M = B; p.NchStore = 16 * Co; p.logC = ilog2(CiPad); p.K = CiPad;
   p.H = 1; p.W = 1; p.logOW = 0; p.logOHW = 0; p.sy = p.sx = 1; p.ntaps = 1;
   p.dy[0][0] = 0; p.dx[0][0] = 0;
   p.osN = (long long)16 * Co; p.osY = 0; p.osX = 0; p.obase[0] = 0;
-  p.cstat = Co; p.cstat_mask = Co - 1; p.epi = 0; p.w_phase_stride = 0;
+  p.cstat = Co; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
+  if (Co < 128) JCK_FAIL(JCK_E_ARG, "g1_fwd: Co must be >= 128");
   p.flops = 2.0 * B * 16.0 * Co * CiPad;
-  return launch_igemm(prec, p, 16 * Co, 1, 1, (hipStream_t)stream);
+  return launch_igemm(prec, p, 16 * Co, 1, 1, (hipStream_t)stream, stats_slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -201,9 +220,9 @@ static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
 
 template <class P, int BG, int BS, int NSUB>
 static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-  constexpr int variant = 10 + (P::NPLANE == 2 ? 4 : 0) + (BG == 128 ? (BS == 128 ? 0 : 1) : (NSUB == 2 ? 2 : 3));
+  constexpr int variant = 10 + (P::IS_F32 ? 4 : 0) + (BG == 128 ? (BS == 128 ? 0 : 1) : (NSUB == 2 ? 2 : 3));
   ProfScope prof(variant, p.flops, st);
-  constexpr int LDSB = 2 * P::NPLANE * WG_BKP * ((BG + 16) + (BS + 16)) * 2;
+  constexpr int LDSB = WgradCfg<P, BG, BS>::LDS_BYTES;
   auto kern = wgrad_kernel<P, BG, BS, NSUB>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -281,27 +300,27 @@ extern "C" int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, 
 // ---------------------------------------------------------------------------------------------------------
 static unsigned ew_grid(long long n, int per_block = 256) { return (unsigned)std::max<long long>(1, std::min<long long>((n + per_block - 1) / per_block, 8192)); }
 
-extern "C" int jck_pack_down(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream) {
+extern "C" int jck_pack_down(int prec, const float* w, int Cs, int Cb, void* wp, void* stream) {
   const int cbp = jck_pad_chan(Cb), rows = jck_pad_rows(Cs);
   if (!is_pow2(cbp)) JCK_FAIL(JCK_E_ARG, "pack_down: Cb must be 3 or a power of two");
   const long long total = (long long)rows * 16 * cbp;
-  hipLaunchKernelGGL(pack_down_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows, ilog2(cbp),
-                     (bf16_t*)hi, (bf16_t*)lo);
+  DISPATCH_T(prec, hipLaunchKernelGGL(pack_down_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb,
+                                      rows, ilog2(cbp), (T*)wp));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
-extern "C" int jck_pack_up(const float* w, int Cs, int Cb, void* hi, void* lo, void* stream) {
+extern "C" int jck_pack_up(int prec, const float* w, int Cs, int Cb, void* wp, void* stream) {
   const int rows = jck_pad_rows(Cb);
   const long long total = 4ll * rows * 4 * Cs;
-  hipLaunchKernelGGL(pack_up_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows, (bf16_t*)hi,
-                     (bf16_t*)lo);
+  DISPATCH_T(prec, hipLaunchKernelGGL(pack_up_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows,
+                                      (T*)wp));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
-extern "C" int jck_pack_g1(const float* w, int Ci, int Co, int CiPad, void* hi, void* lo, void* stream) {
+extern "C" int jck_pack_g1(int prec, const float* w, int Ci, int Co, int CiPad, void* wp, void* stream) {
   const long long total = 16ll * Co * CiPad;
-  hipLaunchKernelGGL(pack_g1_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Ci, Co, CiPad, (bf16_t*)hi,
-                     (bf16_t*)lo);
+  DISPATCH_T(prec, hipLaunchKernelGGL(pack_g1_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Ci, Co, CiPad,
+                                      (T*)wp));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -314,21 +333,16 @@ extern "C" int jck_pack_head(const float* w, int C, float* wp, void* stream) {
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int jck_bn_finalize(const float* stats, float count, const float* gamma, const float* beta, float* running_mean,
-                               float* running_var, int64_t* nbt, float momentum, float eps, float* aux, int C,
-                               void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, count, gamma, beta,
+extern "C" int jck_bn_finalize(const float* stats, int slots, float count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* aux,
+                               int C, void* stream) {
+  if (slots < 1) JCK_FAIL(JCK_E_ARG, "bn_finalize: slots must be >= 1");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
                      running_mean, running_var, (long long*)nbt, momentum, eps, aux, C);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
 
-#define DISPATCH_T(prec, CALL)                                  \
-  do {                                                          \
-    if ((prec) == JCK_PREC_BF16) { typedef bf16_t T; CALL; }    \
-    else if ((prec) == JCK_PREC_F32) { typedef float T; CALL; } \
-    else JCK_FAIL(JCK_E_ARG, "bad prec");                       \
-  } while (0)
 
 extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void* a, long long rows, int C,
                               void* stream) {

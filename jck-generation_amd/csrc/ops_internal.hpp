@@ -33,4 +33,4 @@ void jck_set_error(const std::string& s);
     if (rc_ != JCK_OK) return rc_; \
   } while (0)
 
-int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st);
+int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots);

@@ -6,9 +6,12 @@
 // large-image side (D: the conv input; G: grad of the ConvTranspose output) - one kernel serves
 // Conv2d and ConvTranspose2d because both store weights as [C_small][C_big][kh][kw].
 //
-// The contraction runs over the PIXEL index, which is the slow index of both NHWC operands, so both
-// MFMA operands need K along LDS rows: tiles are stored [pixel][channel] exactly as they arrive from
-// HBM (16-byte coalesced loads) and read with ds_read_b64_tr_b16, CDNA4's transposing LDS read.
+// The contraction runs over the PIXEL index, the slow index of both NHWC operands.  Tiles are stored
+// [pixel][channel] exactly as they arrive from HBM (16-byte coalesced loads):
+//   PrecBf16: fragments are read with ds_read_b64_tr_b16, CDNA4's transposing LDS read, and feed
+//             v_mfma_f32_16x16x32_bf16
+//   PrecF32 : v_mfma_f32_16x16x4_f32 takes ONE element per lane (A[row l&15][k l>>4]), which is a plain
+//             row read of the [pixel][channel] tile - exact fp32
 // MFMA A = gathered side (rows = (tap, cb) columns of dW), B = S side (cols = cs): a lane then owns
 // 4 consecutive (tap, cb) entries of one cs row -> one float4 store into a split-K partial slab
 // part[z][cs][ncols].  `wgrad_reduce_kernel` sums the slabs and transposes into the PyTorch weight
@@ -36,18 +39,26 @@ struct WgradParams {
 
 #define WG_BKP 32
 
+template <class P, int BG, int BS> struct WgradCfg {
+  static constexpr bool F32 = P::IS_F32;
+  static constexpr int PAD = F32 ? 4 : 16;
+  static constexpr int LDG = BG + PAD, LDSS = BS + PAD;            // padded rows (elements)
+  static constexpr int ESZ = F32 ? 4 : 2;
+  static constexpr int BUF_BYTES = WG_BKP * (LDG + LDSS) * ESZ;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
+
 template <class P, int BG, int BS, int NSUB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   typedef typename P::T T;
-  constexpr int NPL = P::NPLANE;
-  constexpr int LDG = BG + 16, LDS_ = BS + 16;                 // padded rows (elements), 32 B pad
+  typedef WgradCfg<P, BG, BS> C;
+  constexpr bool F32 = C::F32;
+  constexpr int LDG = C::LDG, LDSS = C::LDSS;
   constexpr int WG_ = (BG >= 64) ? 2 : 1, WS_ = 4 / WG_;
   constexpr int FM = BG / WG_ / 16, FN = BS / WS_ / 16;
   constexpr int UG = BG / 8, RG = 256 / UG, PG = (WG_BKP + RG - 1) / RG;   // loader geometry, G tile
   constexpr int US = BS / 8, RS = 256 / US, PS = (WG_BKP + RS - 1) / RS;
-  constexpr int GT = NPL * WG_BKP * LDG, ST = NPL * WG_BKP * LDS_;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem_raw);              // 2 x (G tile, S tile)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = blockIdx.x * BG, s0 = blockIdx.y * BS;
@@ -79,88 +90,40 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       const int n = m >> p.logOHW;
       const int rem = m & ((1 << p.logOHW) - 1);
       const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
+      zero_raw(greg[ps]);
       if constexpr (NSUB == 1) {
         const int iy = iy0 + dy0, ix = ix0 + dx0;
-        const bool ok = rok && tv0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const T* src = bigp + ((((long long)n * p.H + iy) * p.W + ix) << p.logCb) + cb0;
-        if constexpr (sizeof(T) == 2) {
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (ok) v = *reinterpret_cast<const u32x4*>(src);
-          greg[ps].v = v;
-        } else {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-          if (ok) { a = *reinterpret_cast<const f32x4*>(src); b = *reinterpret_cast<const f32x4*>(src + 4); }
-          greg[ps].a = a; greg[ps].b = b;
-        }
+        if (rok && tv0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          ldraw(bigp + ((((long long)n * p.H + iy) * p.W + ix) << p.logCb) + cb0, greg[ps]);
       } else {
         const int iya = iy0 + dy0, ixa = ix0 + dx0, iyb = iy0 + dy1, ixb = ix0 + dx1;
-        const bool oka = rok && tv0 && (unsigned)iya < (unsigned)p.H && (unsigned)ixa < (unsigned)p.W;
-        const bool okb = rok && tv1 && (unsigned)iyb < (unsigned)p.H && (unsigned)ixb < (unsigned)p.W;
-        const T* sa = bigp + ((((long long)n * p.H + iya) * p.W + ixa) << 2);
-        const T* sb = bigp + ((((long long)n * p.H + iyb) * p.W + ixb) << 2);
-        if constexpr (sizeof(T) == 2) {
-          u32x2 a = {0u, 0u}, b = {0u, 0u};
-          if (oka) a = *reinterpret_cast<const u32x2*>(sa);
-          if (okb) b = *reinterpret_cast<const u32x2*>(sb);
-          u32x4 v = {a[0], a[1], b[0], b[1]};
-          greg[ps].v = v;
-        } else {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-          if (oka) a = *reinterpret_cast<const f32x4*>(sa);
-          if (okb) b = *reinterpret_cast<const f32x4*>(sb);
-          greg[ps].a = a; greg[ps].b = b;
-        }
+        if (rok && tv0 && (unsigned)iya < (unsigned)p.H && (unsigned)ixa < (unsigned)p.W)
+          ldraw_half(bigp + ((((long long)n * p.H + iya) * p.W + ixa) << 2), greg[ps], 0);
+        if (rok && tv1 && (unsigned)iyb < (unsigned)p.H && (unsigned)ixb < (unsigned)p.W)
+          ldraw_half(bigp + ((((long long)n * p.H + iyb) * p.W + ixb) << 2), greg[ps], 1);
       }
     }
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
       const int r = ps * RS + sr;
       const int m = mbase + r;
-      const bool ok = (r < WG_BKP) && (m < mz1) && (s0 + su * 8 < p.CsStride);
-      const T* src = sp + (long long)m * p.CsStride + s0 + su * 8;
-      if constexpr (sizeof(T) == 2) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const u32x4*>(src);
-        sreg[ps].v = v;
-      } else {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (ok) { a = *reinterpret_cast<const f32x4*>(src); b = *reinterpret_cast<const f32x4*>(src + 4); }
-        sreg[ps].a = a; sreg[ps].b = b;
-      }
-    }
-  };
-
-  auto put = [&](bf16_t* tile, int ld, int rows_total, int r, int u, const Raw8<T>& rg) {
-    if constexpr (sizeof(T) == 2) {
-      *reinterpret_cast<u32x4*>(tile + r * ld + u * 8) = rg.v;
-    } else {
-      float f[8] = {rg.a[0], rg.a[1], rg.a[2], rg.a[3], rg.b[0], rg.b[1], rg.b[2], rg.b[3]};
-      u32x4 hi, lo;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16_t h0, l0, h1, l1;
-        split_bf(f[2 * i], h0, l0);
-        split_bf(f[2 * i + 1], h1, l1);
-        hi[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lo[i] = (unsigned)l0 | ((unsigned)l1 << 16);
-      }
-      *reinterpret_cast<u32x4*>(tile + r * ld + u * 8) = hi;
-      *reinterpret_cast<u32x4*>(tile + (rows_total + r) * ld + u * 8) = lo;
+      zero_raw(sreg[ps]);
+      if ((r < WG_BKP) && (m < mz1) && (s0 + su * 8 < p.CsStride)) ldraw(sp + (long long)m * p.CsStride + s0 + su * 8, sreg[ps]);
     }
   };
 
   auto store_tiles = [&](int buf) {
-    bf16_t* gt = lds + buf * (GT + ST);
-    bf16_t* st = gt + GT;
+    T* gt = reinterpret_cast<T*>(smem_raw + buf * C::BUF_BYTES);   // [WG_BKP][LDG]
+    T* st = gt + WG_BKP * LDG;                                     // [WG_BKP][LDSS]
 #pragma unroll
     for (int ps = 0; ps < PG; ++ps) {
       const int r = ps * RG + gr;
-      if (r < WG_BKP) put(gt, LDG, WG_BKP, r, gu, greg[ps]);
+      if (r < WG_BKP) straw(gt + r * LDG + gu * 8, greg[ps]);
     }
 #pragma unroll
     for (int ps = 0; ps < PS; ++ps) {
       const int r = ps * RS + sr;
-      if (r < WG_BKP) put(st, LDS_, WG_BKP, r, su, sreg[ps]);
+      if (r < WG_BKP) straw(st + r * LDSS + su * 8, sreg[ps]);
     }
   };
 
@@ -178,38 +141,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     store_tiles(0);
   }
   __syncthreads();
-  // transposed-read lane addressing: group g = lane>>4 covers pixels 8g..8g+7 of the 32-pixel step;
+  // bf16 transposed-read lane addressing: group g = lane>>4 covers pixels 8g..8g+7 of the 32-pixel step;
   // lane i = lane&15 supplies &tile[8g + (i>>2)][col0 + 4*(i&3)] and receives column col0 + i.
   const int trow = (lane >> 4) * 8 + ((lane & 15) >> 2), tcol = (lane & 3) * 4;
   for (int kc = 0; kc < nk; ++kc) {
     const bool more = kc + 1 < nk;
     if (more) load_tiles(mz0 + (kc + 1) * WG_BKP);
-    const bf16_t* gt = lds + (kc & 1) * (GT + ST);
-    const bf16_t* st = gt + GT;
-    bf16x8 a[NPL][FM], b[NPL][FN];
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
+    const T* gt = reinterpret_cast<const T*>(smem_raw + (kc & 1) * C::BUF_BYTES);
+    const T* st = gt + WG_BKP * LDG;
+    if constexpr (!F32) {
+      bf16x8 a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const bf16_t* q = gt + (pl * WG_BKP + trow) * LDG + wg * FM * 16 + i * 16 + tcol;
-        a[pl][i] = join_tr(lds_tr4(q), lds_tr4(q + 4 * LDG));
+        const bf16_t* q = gt + trow * LDG + wg * FM * 16 + i * 16 + tcol;
+        a[i] = join_tr(lds_tr4(q), lds_tr4(q + 4 * LDG));
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const bf16_t* q = st + (pl * WG_BKP + trow) * LDS_ + ws * FN * 16 + j * 16 + tcol;
-        b[pl][j] = join_tr(lds_tr4(q), lds_tr4(q + 4 * LDS_));
+        const bf16_t* q = st + trow * LDSS + ws * FN * 16 + j * 16 + tcol;
+        b[j] = join_tr(lds_tr4(q), lds_tr4(q + 4 * LDSS));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    } else {
+      const float* ga = gt + (lane >> 4) * LDG + wg * FM * 16 + (lane & 15);
+      const float* sb = st + (lane >> 4) * LDSS + ws * FN * 16 + (lane & 15);
+#pragma unroll 4
+      for (int kk = 0; kk < WG_BKP / 4; ++kk) {
+        float a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = ga[kk * 4 * LDG + i * 16];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = sb[kk * 4 * LDSS + j * 16];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        if constexpr (NPL == 2) {
-          acc[i][j] = mfma16(a[1][i], b[0][j], acc[i][j]);
-          acc[i][j] = mfma16(a[0][i], b[1][j], acc[i][j]);
-        }
-        acc[i][j] = mfma16(a[0][i], b[0][j], acc[i][j]);
-      }
     if (more) store_tiles((kc + 1) & 1);
     __syncthreads();
   }
@@ -230,7 +201,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
 // grad[cs][cb][t] (+)= sum_z part[z][cs][t*CbPad + cb]      (cs < Cs, cb < Cb)
 static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int CsRows, int ncols, int Cs, int Cb,
-                                    int logCbPad, int ntaps, float* __restrict__ grad, int accumulate) {
+                                           int logCbPad, int ntaps, float* __restrict__ grad, int accumulate) {
   const long long total = (long long)Cs * Cb * ntaps;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int t = (int)(i % ntaps);

@@ -22,18 +22,20 @@ PROTOS = {
     "jck_version": (i32, []),
     "jck_pad_rows": (i32, [i32]),
     "jck_pad_chan": (i32, [i32]),
-    "jck_pack_down": (i32, [vp, i32, i32, vp, vp, vp]),
-    "jck_pack_up": (i32, [vp, i32, i32, vp, vp, vp]),
-    "jck_pack_g1": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "jck_packed_bytes": (sz, [i32, i64]),
+    "jck_stats_floats": (sz, [i64, i32, i32]),
+    "jck_pack_down": (i32, [i32, vp, i32, i32, vp, vp]),
+    "jck_pack_up": (i32, [i32, vp, i32, i32, vp, vp]),
+    "jck_pack_g1": (i32, [i32, vp, i32, i32, i32, vp, vp]),
     "jck_pack_head": (i32, [vp, i32, vp, vp]),
-    "jck_conv_down": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "jck_conv_up": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jck_conv_down": (i32, [i32, vp, vp, vp, vp, C.POINTER(i32), i32, i32, i32, i32, i32, vp]),
+    "jck_conv_up": (i32, [i32, vp, vp, vp, vp, C.POINTER(i32), i32, i32, i32, i32, i32, i32, vp]),
     "jck_conv_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32]),
     "jck_conv_wgrad": (i32, [i32, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "jck_g1_fwd": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "jck_g1_fwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(i32), i32, i32, i32, vp]),
     "jck_g1_wgrad_ws_bytes": (sz, [i32, i32, i32]),
     "jck_g1_wgrad": (i32, [i32, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, vp]),
-    "jck_bn_finalize": (i32, [vp, f32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
+    "jck_bn_finalize": (i32, [vp, i32, f32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
     "jck_bn_act_fwd": (i32, [i32, vp, vp, f32, vp, i64, i32, vp]),
     "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),

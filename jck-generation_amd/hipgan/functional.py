@@ -1,0 +1,284 @@
+"""Autograd bridge: the reference's nn.Module forward/backward (model/DCGAN.py:29-35,61-67) expressed as
+torch.autograd.Functions over the C-ABI kernels.  Tensors between stages are NHWC in the library's element type
+(bf16 or fp32, `prec`); NCHW fp32 exists only at the module boundary.
+
+First-order only: double backward (the reference's CGAN gradient penalty) is not provided by these Functions and
+raises.  No CPU path: every Function requires device tensors.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import PREC_BF16, PREC_F32, JckError, cur_stream, lib
+
+_PREC = {"bf16": PREC_BF16, "f32": PREC_F32}
+_DT = {PREC_BF16: torch.bfloat16, PREC_F32: torch.float32}
+BN_MOMENTUM, BN_EPS = 0.1, 1e-5
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise JckError(f"{what}: got a {t.device} tensor - the MI355X path has no CPU fallback; move the module and its "
+                       f"inputs to the GPU")
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _pack(kind, w, prec, *dims):
+    """fp32 parameter -> GEMM operand of the precision's element type (include/jckgan.h, weight packing)."""
+    a, b = w.shape[0], w.shape[1]
+    if kind == "down":
+        n = lib.jck_pad_rows(a) * 16 * lib.jck_pad_chan(b)
+    elif kind == "up":
+        n = 4 * lib.jck_pad_rows(b) * 4 * a
+    else:  # g1
+        n = 16 * b * dims[0]
+    wp = torch.empty(n, dtype=_DT[prec], device=w.device)
+    wf = _f32(w)
+    if kind == "down":
+        lib.jck_pack_down(prec, wf, a, b, wp, cur_stream())
+    elif kind == "up":
+        lib.jck_pack_up(prec, wf, a, b, wp, cur_stream())
+    else:
+        lib.jck_pack_g1(prec, wf, a, b, dims[0], wp, cur_stream())
+    return wp
+
+
+def _stats_buf(pixels, c, nyrep, dev):
+    return torch.empty(lib.jck_stats_floats(pixels, c, nyrep), dtype=torch.float32, device=dev)
+
+
+class _ToNHWC(Function):
+    """NCHW fp32 image -> NHWC4 T."""
+
+    @staticmethod
+    def forward(ctx, x, prec):
+        ctx.prec = prec
+        n, c, h, w = x.shape
+        out = torch.empty(n, h, w, 4, dtype=_DT[prec], device=x.device)
+        lib.jck_img_prep(prec, _f32(x), None, 1.0, 0.0, out, n, h * w, cur_stream())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, h, w, _ = g.shape
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=g.device)
+        lib.jck_nhwc4_to_nchw(ctx.prec, g.contiguous(), out, n, h * w, cur_stream())
+        return out, None
+
+
+class _ToNCHW(Function):
+    """NHWC4 T -> NCHW fp32 image."""
+
+    @staticmethod
+    def forward(ctx, x, prec):
+        ctx.prec = prec
+        n, h, w, _ = x.shape
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=x.device)
+        lib.jck_nhwc4_to_nchw(prec, x.contiguous(), out, n, h * w, cur_stream())
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, c, h, w = g.shape
+        out = torch.empty(n, h, w, 4, dtype=_DT[ctx.prec], device=g.device)
+        lib.jck_img_prep(ctx.prec, _f32(g), None, 1.0, 0.0, out, n, h * w, cur_stream())
+        return out, None
+
+
+class _ConvBnAct(Function):
+    """One stage: {Conv2d k4s2p1 | ConvTranspose2d k4s2p1 | ConvTranspose2d k4s1p0 on 1x1} -> BatchNorm2d(train) ->
+    ReLU/LeakyReLU.  BN statistics come out of the GEMM epilogue; running stats are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rm, rv, nbt, kind, slope, prec):
+        dev = x.device
+        st = cur_stream()
+        x = x.contiguous()
+        if kind == "down":          # x [N,Hb,Wb,CbPad] -> [N,Hb/2,Wb/2,Cs]
+            n, hb, wb, _ = x.shape
+            cs, cb = w.shape[0], w.shape[1]
+            oshape, rows, c = (n, hb // 2, wb // 2, cs), n * (hb // 2) * (wb // 2), cs
+        elif kind == "up":          # x [N,Hs,Ws,Cs] -> [N,2Hs,2Ws,Cb]
+            n, hs, ws_, cs = x.shape
+            cb = w.shape[1]
+            oshape, rows, c = (n, 2 * hs, 2 * ws_, cb), n * 4 * hs * ws_, cb
+        else:                       # g1: x [B,CiPad] -> [B,4,4,Co]
+            n, cip = x.shape
+            c = w.shape[1]
+            oshape, rows = (n, 4, 4, c), n * 16
+        y = torch.empty(oshape, dtype=_DT[prec], device=dev)
+        stats = _stats_buf(rows, c, 16 if kind == "g1" else 1, dev)
+        slots = ctypes.c_int(0)
+        if kind == "down":
+            lib.jck_conv_down(prec, x, _pack("down", w, prec), y, stats, ctypes.byref(slots), n, hb, wb, cb, cs, st)
+        elif kind == "up":
+            lib.jck_conv_up(prec, x, _pack("up", w, prec), y, stats, ctypes.byref(slots), 0, n, hs, ws_, cs, cb, st)
+        else:
+            lib.jck_g1_fwd(prec, x, _pack("g1", w, prec, cip), y, stats, ctypes.byref(slots), n, cip, c, st)
+        aux = torch.empty(4 * c, dtype=torch.float32, device=dev)
+        lib.jck_bn_finalize(stats, slots.value, float(rows), _f32(gamma), _f32(beta), rm, rv, nbt, BN_MOMENTUM, BN_EPS, aux, c,
+                            st)
+        a = torch.empty_like(y)
+        lib.jck_bn_act_fwd(prec, y, aux, slope, a, rows, c, st)
+        ctx.save_for_backward(x, w, y, aux)
+        ctx.meta = (kind, slope, prec, rows, c)
+        return a
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga):
+        x, w, y, aux = ctx.saved_tensors
+        kind, slope, prec, rows, c = ctx.meta
+        dev, st = x.device, cur_stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        sums = torch.zeros(2 * c, **f32)
+        dgam, dbet = torch.zeros(c, **f32), torch.zeros(c, **f32)
+        gy = torch.empty_like(y)
+        lib.jck_bn_act_bwd(prec, ga.contiguous(), y, aux, slope, sums, gy, dgam, dbet, rows, c, st)
+        gw = gx = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if kind == "down":
+            n, hb, wb, _ = x.shape
+            cs, cb = w.shape[0], w.shape[1]
+            if need_w:
+                nb = lib.jck_conv_wgrad_ws_bytes(n, hb, wb, cb, cs)
+                ws = torch.empty(nb // 4, **f32)
+                gw = torch.empty(w.shape, **f32)
+                lib.jck_conv_wgrad(prec, gy, x, ws, nb, gw, 0, n, hb, wb, cb, cs, st)
+            if need_x:
+                gx = torch.empty_like(x)
+                lib.jck_conv_up(prec, gy, _pack("up", w, prec), gx, None, None, 0, n, hb // 2, wb // 2, cs, cb, st)
+        elif kind == "up":
+            n, hs, ws_, cs = x.shape
+            cb = w.shape[1]
+            if need_w:
+                nb = lib.jck_conv_wgrad_ws_bytes(n, 2 * hs, 2 * ws_, cb, cs)
+                ws = torch.empty(nb // 4, **f32)
+                gw = torch.empty(w.shape, **f32)
+                lib.jck_conv_wgrad(prec, x, gy, ws, nb, gw, 0, n, 2 * hs, 2 * ws_, cb, cs, st)
+            if need_x:
+                gx = torch.empty_like(x)
+                lib.jck_conv_down(prec, gy, _pack("down", w, prec), gx, None, None, n, 2 * hs, 2 * ws_, cb, cs, st)
+        else:
+            n, cip = x.shape
+            ci = w.shape[0]
+            if need_w:
+                nb = lib.jck_g1_wgrad_ws_bytes(n, cip, c)
+                ws = torch.empty(nb // 4, **f32)
+                gw = torch.empty(w.shape, **f32)
+                lib.jck_g1_wgrad(prec, x, gy, ws, nb, gw, 0, n, ci, cip, c, st)
+            if need_x:
+                raise JckError("gradient w.r.t. the latent input of G.conv1 is not provided")
+        return gx, gw, dgam, dbet, None, None, None, None, None, None
+
+
+class _UpTanh(Function):
+    """G.conv5 + tanh (model/DCGAN.py:58-59,66): [N,32,32,64] -> NHWC4 image in (-1,1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, prec):
+        n, hs, ws_, cs = x.shape
+        cb = w.shape[1]
+        x = x.contiguous()
+        y = torch.empty(n, 2 * hs, 2 * ws_, lib.jck_pad_chan(cb), dtype=_DT[prec], device=x.device)
+        lib.jck_conv_up(prec, x, _pack("up", w, prec), y, None, None, 1, n, hs, ws_, cs, cb, cur_stream())
+        ctx.save_for_backward(x, w, y)
+        ctx.prec = prec
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        prec, st = ctx.prec, cur_stream()
+        n, hs, ws_, cs = x.shape
+        cb = w.shape[1]
+        graw = torch.empty_like(y)
+        lib.jck_tanh_bwd(prec, g.contiguous(), y, 1.0, graw, y.numel(), st)
+        gw = gx = None
+        if ctx.needs_input_grad[1]:
+            nb = lib.jck_conv_wgrad_ws_bytes(n, 2 * hs, 2 * ws_, cb, cs)
+            ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+            gw = torch.empty(w.shape, dtype=torch.float32, device=x.device)
+            lib.jck_conv_wgrad(prec, x, graw, ws, nb, gw, 0, n, 2 * hs, 2 * ws_, cb, cs, st)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            lib.jck_conv_down(prec, graw, _pack("down", w, prec), gx, None, None, n, 2 * hs, 2 * ws_, cb, cs, st)
+        return gx, gw, None
+
+
+class _HeadSigmoid(Function):
+    """D.conv5 + sigmoid (model/DCGAN.py:26-27,34): [N,4,4,512] -> [N,1,1,1] probability (fp32)."""
+
+    @staticmethod
+    def forward(ctx, a4, w, prec):
+        n = a4.shape[0]
+        c = w.shape[1]
+        dev = a4.device
+        a4 = a4.contiguous()
+        wp = torch.empty(16 * c, dtype=torch.float32, device=dev)
+        lib.jck_pack_head(_f32(w), c, wp, cur_stream())
+        prob = torch.empty(n, dtype=torch.float32, device=dev)
+        dsig = torch.empty(n, dtype=torch.float32, device=dev)          # p(1-p)
+        lib.jck_head_fwd(prec, a4, wp, n, 16 * c, 0.0, 1, prob, dsig, None, -1, -1, cur_stream())
+        ctx.save_for_backward(a4, wp, dsig)
+        ctx.meta = (prec, c)
+        return prob.view(n, 1, 1, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gp):
+        a4, wp, dsig = ctx.saved_tensors
+        prec, c = ctx.meta
+        n = a4.shape[0]
+        ds = (gp.reshape(n).to(torch.float32) * dsig).contiguous()
+        ga = torch.empty_like(a4) if ctx.needs_input_grad[0] else None
+        gw = None
+        dwp = torch.empty(16 * c, dtype=torch.float32, device=a4.device) if ctx.needs_input_grad[1] else None
+        lib.jck_head_bwd(prec, ds, wp, a4, n, 16 * c, ga, dwp, 0, cur_stream())
+        if dwp is not None:
+            gw = torch.empty(1, c, 4, 4, dtype=torch.float32, device=a4.device)
+            lib.jck_head_unpack_grad(dwp, c, gw, 0, cur_stream())
+        return ga, gw, None
+
+
+def _stage(mod, i, x, kind, slope, prec):
+    conv, norm = getattr(mod, f"conv{i}"), getattr(mod, f"norm{i}")
+    return _ConvBnAct.apply(x, conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                            norm.num_batches_tracked, kind, slope, prec)
+
+
+def dcgan_discriminator(mod, x, prec="bf16"):
+    """model/DCGAN.py:29-35 on the HIP path.  x: NCHW fp32 [B,3,64,64] on the GPU -> [B,1,1,1] fp32."""
+    _need_cuda(x, "Discriminator.forward")
+    if x.dim() != 4 or x.shape[1:] != (3, 64, 64):
+        raise JckError(f"Discriminator expects [B,3,64,64], got {tuple(x.shape)}")
+    p = _PREC[prec]
+    h = _ToNHWC.apply(x, p)
+    for i in (1, 2, 3, 4):
+        h = _stage(mod, i, h, "down", 0.2, p)
+    return _HeadSigmoid.apply(h, mod.conv5.weight, p)
+
+
+def dcgan_generator(mod, z, prec="bf16"):
+    """model/DCGAN.py:61-67 on the HIP path.  z: [B,100,1,1] fp32 on the GPU -> NCHW fp32 [B,3,64,64]."""
+    _need_cuda(z, "Generator.forward")
+    if z.dim() != 4 or z.shape[1:] != (mod.conv1.weight.shape[0], 1, 1):
+        raise JckError(f"Generator expects [B,{mod.conv1.weight.shape[0]},1,1], got {tuple(z.shape)}")
+    p = _PREC[prec]
+    b, ci = z.shape[0], z.shape[1]
+    cip = 128 if ci <= 128 else 256
+    zp = torch.zeros(b, cip, dtype=_DT[p], device=z.device)
+    zp[:, :ci] = z.reshape(b, ci).to(_DT[p])
+    h = _stage(mod, 1, zp, "g1", 0.0, p)
+    for i in (2, 3, 4):
+        h = _stage(mod, i, h, "up", 0.0, p)
+    img = _UpTanh.apply(h, mod.conv5.weight, p)
+    return _ToNCHW.apply(img, p)

@@ -5,8 +5,8 @@ from hipgan import PREC_BF16, PREC_F32, lib  # noqa: F401
 from hipgan._lib import cur_stream  # noqa: F401
 
 DT = {PREC_BF16: torch.bfloat16, PREC_F32: torch.float32}
-# relative-to-max tolerances per precision: F32 = split-bf16 x3 (2^-16 per product), BF16 = bf16 storage (2^-9)
-TOL = {PREC_F32: 3e-5, PREC_BF16: 1.5e-2}
+# relative-to-max tolerances per precision: F32 = exact fp32 MFMA (summation order only), BF16 = bf16 storage (2^-9)
+TOL = {PREC_F32: 3e-6, PREC_BF16: 1.5e-2}
 
 
 def to_nhwc(x_nchw, prec, cpad=None):
@@ -33,20 +33,27 @@ def rnd(x, prec):
 
 def pack_down(w, prec):
     cs, cb = w.shape[0], w.shape[1]
-    rows, cbp = lib.jck_pad_rows(cs), lib.jck_pad_chan(cb)
-    hi = torch.empty(rows * 16 * cbp, dtype=torch.bfloat16, device="cuda")
-    lo = torch.empty_like(hi)
-    lib.jck_pack_down(w.cuda().contiguous(), cs, cb, hi, lo, cur_stream())
-    return hi, lo
+    wp = torch.empty(lib.jck_pad_rows(cs) * 16 * lib.jck_pad_chan(cb), dtype=DT[prec], device="cuda")
+    lib.jck_pack_down(prec, w.cuda().contiguous(), cs, cb, wp, cur_stream())
+    return wp
 
 
 def pack_up(w, prec):
     cs, cb = w.shape[0], w.shape[1]
-    rows = lib.jck_pad_rows(cb)
-    hi = torch.empty(4 * rows * 4 * cs, dtype=torch.bfloat16, device="cuda")
-    lo = torch.empty_like(hi)
-    lib.jck_pack_up(w.cuda().contiguous(), cs, cb, hi, lo, cur_stream())
-    return hi, lo
+    wp = torch.empty(4 * lib.jck_pad_rows(cb) * 4 * cs, dtype=DT[prec], device="cuda")
+    lib.jck_pack_up(prec, w.cuda().contiguous(), cs, cb, wp, cur_stream())
+    return wp
+
+
+def stats_buf(pixels, c, nyrep=1):
+    import ctypes
+    return torch.full((lib.jck_stats_floats(pixels, c, nyrep),), float("nan"), device="cuda"), ctypes.c_int(0)
+
+
+def stats_sum(buf, slots, c):
+    """[slots][2][C] partials -> (sum[C], sumsq[C]) on the CPU."""
+    v = buf[:slots.value * 2 * c].view(slots.value, 2, c).double().sum(0).float().cpu()
+    return v[0], v[1]
 
 
 def check(got, ref, tol, what=""):

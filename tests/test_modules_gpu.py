@@ -1,0 +1,62 @@
+"""Drop-in nn.Modules (jck-generation_amd/model/DCGAN.py) on the GPU against the module-level golden captured from the
+reference's own classes (tests/golden/modules.json) and against the CPU oracle: same constructor, same state-dict keys,
+same init, same forward outputs and first-order gradients.  Tolerances: f32 path = exact-fp32 MFMA, differences are
+summation order only (1e-5 rel on digests); bf16 path 3e-2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B):
+    from util import synth_images
+    gen = torch.Generator().manual_seed(77)
+    z = torch.randn(B, 100, 1, 1, generator=gen)
+    x = synth_images(B, seed=99)
+    rg = torch.randn(B, 3, 64, 64, generator=gen)
+    rd = torch.randn(B, generator=gen)
+    return z, x, rg, rd
+
+
+@pytest.mark.parametrize("prec,rtol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_dcgan_modules_vs_golden(prec, rtol):
+    from model import DCGAN
+    from util import check_digest, check_digest_dict, load_golden
+    gold = load_golden("modules")["dcgan"]
+    torch.manual_seed(12345)
+    g, d = DCGAN.Generator(), DCGAN.Discriminator()
+    g.apply(DCGAN.weights_init)
+    d.apply(DCGAN.weights_init)
+    check_digest_dict(dict(g.state_dict()), gold["init_g"], 0, 0, "init_g")
+    check_digest_dict(dict(d.state_dict()), gold["init_d"], 0, 0, "init_d")
+    assert list(g.state_dict().keys()) == list(gold["init_g"].keys())
+    assert list(d.state_dict().keys()) == list(gold["init_d"].keys())
+    g, d = g.cuda(), d.cuda()
+    g.prec = d.prec = prec
+    z, x, rg, rd = _inputs(4)
+    xg = x.cuda().requires_grad_(True)
+    fake = g(z.cuda())
+    dout = d(xg).view(-1)
+    assert fake.shape == (4, 3, 64, 64) and fake.dtype == torch.float32
+    (fake * rg.cuda()).sum().backward()
+    (dout * rd.cuda()).sum().backward()
+    check_digest(fake, gold["g_out"], rtol, 1e-6, "g_out")
+    ref_d = torch.tensor(gold["d_out"]["vals"])
+    assert (dout.detach().cpu().double() - ref_d).abs().max() < rtol
+    check_digest_dict({k: p.grad for k, p in g.named_parameters()}, gold["g_grads"], rtol * 5, 1e-6, "g_grads")
+    check_digest_dict({k: p.grad for k, p in d.named_parameters()}, gold["d_grads"], rtol * 5, 1e-6, "d_grads")
+    check_digest(xg.grad, gold["d_xgrad"], rtol * 5, 1e-7, "d_xgrad")
+    # BN running statistics and num_batches_tracked moved exactly like the reference's modules
+    check_digest_dict(dict(g.state_dict()), {k: v for k, v in gold["g_post"].items() if "running" in k or "num_b" in k},
+                      max(rtol, 1e-3) if prec == "bf16" else 1e-5, 1e-6, "g_post")
+    check_digest_dict(dict(d.state_dict()), {k: v for k, v in gold["d_post"].items() if "running" in k or "num_b" in k},
+                      max(rtol, 1e-3) if prec == "bf16" else 1e-5, 1e-6, "d_post")
+
+
+def test_modules_reject_cpu_tensors():
+    from hipgan import JckError
+    from model import DCGAN
+    with pytest.raises(JckError):
+        DCGAN.Generator()(torch.randn(2, 100, 1, 1))
+    with pytest.raises(JckError):
+        DCGAN.Discriminator()(torch.randn(2, 3, 64, 64))
