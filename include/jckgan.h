@@ -84,7 +84,9 @@ int jck_bn_finalize(const float* stats, int slots, float count, const float* gam
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                     float* aux, int C, void* stream);
 int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void* a, long long rows, int C, void* stream);
-/* sums: float[2*C] zeroed by the caller; g_y may alias g_a */
+/* sums: scratch of jck_bn_bwd_ws_floats(C) floats (first 2*C = final sum g_z, sum g_z*xhat; no zeroing needed);
+ * g_y may alias g_a; dgamma/dbeta (optional) are accumulated into */
+size_t jck_bn_bwd_ws_floats(int C);
 int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                    float* dgamma, float* dbeta, long long rows, int C, void* stream);
 

@@ -140,7 +140,7 @@ struct jck_engine {
     {
       size_t start = c.off;
       zero_d = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) d_bn[i].sums = c.take<float>(2 * D_CS[i]);
+      for (int i = 0; i < 4; ++i) d_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(D_CS[i]));
       zero_d_bytes = c.off - start;
       for (int i = 0; i < 4; ++i) {
         d_bn[i].aux = c.take<float>(4 * D_CS[i]);
@@ -148,7 +148,7 @@ struct jck_engine {
       }
       start = c.off;
       zero_g = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) g_bn[i].sums = c.take<float>(2 * (512 >> i));
+      for (int i = 0; i < 4; ++i) g_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(512 >> i));
       zero_g_bytes = c.off - start;
       for (int i = 0; i < 4; ++i) {
         const int C = 512 >> i, h = 4 << i;
@@ -249,7 +249,6 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
 static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
 static int d_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
-  HIPCHK(hipMemsetAsync(e->zero_d, 0, e->zero_d_bytes, st));
   const void* in = x_in;
   for (int i = 0; i < 4; ++i) {
     const int hb = D_HB[i], cs = D_CS[i];
@@ -292,7 +291,6 @@ static void launch_pad_rows(const float* z, int B, void* out, hipStream_t st) {
 
 static int g_forward(jck_engine* e, const float* z, int B, bool update_running, hipStream_t st) {
   (void)update_running;
-  HIPCHK(hipMemsetAsync(e->zero_g, 0, e->zero_g_bytes, st));
   if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, e->g_z, st); else launch_pad_rows<float>(z, B, e->g_z, st);
   HIPCHK(hipGetLastError());
   JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, Z_PAD, G_C1, st));

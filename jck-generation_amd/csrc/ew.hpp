@@ -120,29 +120,39 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, i
 // stats: [slots][2][C] partial sums / sums of squares written by the GEMM epilogue (every slot complete).
 // aux layout (floats): [0,C) scale = gamma*invstd   [C,2C) shift = beta - mean*scale
 //                      [2C,3C) mean                 [3C,4C) invstd
-// One workgroup per 16 channels: 16 slot-lanes x 16 channels, double accumulation, LDS tree over the slot lanes.
+// One workgroup per 4 channels: 256 slot-lanes, 16-byte loads, double accumulation, wavefront + LDS reduction.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int slots, float count,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                  long long* __restrict__ nbt, float momentum, float eps,
                                                                  float* __restrict__ aux, int C) {
-  __shared__ double sh[2][16][16];
-  const int cc = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cc;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int k = sl; k < slots; k += 16) {
-      s += (double)stats[(long long)k * 2 * C + c];
-      q += (double)stats[(long long)k * 2 * C + C + c];
-    }
-  sh[0][sl][cc] = s;
-  sh[1][sl][cc] = q;
+  __shared__ double sh[4][8];
+  const int c0 = blockIdx.x * 4;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  for (int k = threadIdx.x; k < slots; k += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + C + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] += (double)a[i]; q[i] += (double)b[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s[i] = wave_sum_d(s[i]); q[i] = wave_sum_d(q[i]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[threadIdx.x >> 6][i] = s[i]; sh[threadIdx.x >> 6][4 + i] = q[i]; }
+  }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  if (sl != 0 || c >= C) return;
-  for (int k = 1; k < 16; ++k) { s += sh[0][k][cc]; q += sh[1][k][cc]; }
-  const double meand = s / (double)count;
-  double vard = q / (double)count - meand * meand;
+  if (threadIdx.x >= 4) return;
+  const int i = threadIdx.x, c = c0 + i;
+  const double sd = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], qd = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
+  const double meand = sd / (double)count;
+  double vard = qd / (double)count - meand * meand;
   if (vard < 0.0) vard = 0.0;
   const float mean = (float)meand, var = (float)vard;
   const float invstd = 1.0f / sqrtf(var + eps);
@@ -175,41 +185,71 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
   }
 }
 
-// sums[0..C) += sum g_z,  sums[C..2C) += sum g_z * xhat   with g_z = g_a * act'(z)
+// stage 1: partial[blk][0..C) = sum g_z,  partial[blk][C..2C) = sum g_z * xhat over this workgroup's rows,
+// g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics.
+#define BN_BWD_MAX_BLOCKS 256
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
-                                                            float* __restrict__ sums, long long rows, int C) {
-  extern __shared__ float lsum[];                         // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.f;
-  __syncthreads();
+                                                            float* __restrict__ partial, long long rows, int C) {
+  extern __shared__ float lsum[];                         // [rstep][2][C]
   const int upr = C >> 3;                                 // 8-channel units per row
   const int u = threadIdx.x % upr, r0 = threadIdx.x / upr, rstep = 256 / upr;
   const int c = u * 8;
-  if (r0 < rstep) {
-    float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = aux[c + k]; sh[k] = aux[C + c + k]; mu[k] = aux[2 * C + c + k]; is[k] = aux[3 * C + c + k];
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
+    float vg[8], vy[8];
+    ld8(ga + r * C + c, vg);
+    ld8(y + r * C + c, vy);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      sc[k] = aux[c + k]; sh[k] = aux[C + c + k]; mu[k] = aux[2 * C + c + k]; is[k] = aux[3 * C + c + k];
-      s1[k] = 0.f; s2[k] = 0.f;
+      const float z = vy[k] * sc[k] + sh[k];
+      const float gz = z > 0.f ? vg[k] : slope * vg[k];
+      s1[k] += gz;
+      s2[k] += gz * ((vy[k] - mu[k]) * is[k]);
     }
-    for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
-      float vg[8], vy[8];
-      ld8(ga + r * C + c, vg);
-      ld8(y + r * C + c, vy);
+  }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float z = vy[k] * sc[k] + sh[k];
-        const float gz = z > 0.f ? vg[k] : slope * vg[k];
-        s1[k] += gz;
-        s2[k] += gz * ((vy[k] - mu[k]) * is[k]);
-      }
-    }
+  for (int k = 0; k < 8; ++k) { lsum[(r0 * 2) * C + c + k] = s1[k]; lsum[(r0 * 2 + 1) * C + c + k] = s2[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rstep; ++r) t += lsum[r * 2 * C + i];
+    partial[(long long)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// stage 2: sums[0..2C) = sum over workgroups; dgamma += s2, dbeta += s1 (when given).  One workgroup per 4 channels.
+static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  __shared__ float sh[4][8];
+  const int c0 = blockIdx.x * 4;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  for (int k = threadIdx.x; k < nblk; k += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (long long)k * 2 * C + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (long long)k * 2 * C + C + c0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { atomicAdd(&lsum[c + k], s1[k]); atomicAdd(&lsum[C + c + k], s2[k]); }
+    for (int i = 0; i < 4; ++i) { s[i] += a[i]; q[i] += b[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s[i] = wave_sum(s[i]); q[i] = wave_sum(q[i]); }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[threadIdx.x >> 6][i] = s[i]; sh[threadIdx.x >> 6][4 + i] = q[i]; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, lsum[i]);
+  if (threadIdx.x >= 4) return;
+  const int i = threadIdx.x, c = c0 + i;
+  const float s1 = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], s2 = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
+  sums[c] = s1;
+  sums[C + c] = s2;
+  if (dgamma) dgamma[c] += s2;
+  if (dbeta) dbeta[c] += s1;
 }
 
 // g_y = scale * (g_z - s1/n - xhat * s2/n)
@@ -232,12 +272,6 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restric
     }
     st8(gy + i * 8, vg);
   }
-}
-
-// dgamma += s2, dbeta += s1
-static __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) { dgamma[c] += sums[C + c]; dbeta[c] += sums[c]; }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -293,22 +327,30 @@ __global__ void head_dgrad_kernel(const float* __restrict__ ds, const float* __r
   }
 }
 
-// dw[k] (+)= sum_n ds[n] * a4[n][k]       (packed (h,w,c) order)
+// dw[k] += sum_n ds[n] * a4[n][k]       (packed (h,w,c) order; dw pre-zeroed or accumulating)
+// grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup, images strided over lanes and gridDim.y
 template <typename T>
-__global__ void head_wgrad_kernel(const float* __restrict__ ds, const T* __restrict__ a4, int B, int K,
-                                  float* __restrict__ dw, int accumulate) {
-  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (k >= K) return;
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ ds, const T* __restrict__ a4, int B, int K,
+                                                         float* __restrict__ dw) {
+  __shared__ float red[4][64][9];
+  const int u = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int k = (blockIdx.x * 64 + u) * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int n = 0; n < B; ++n) {
-    float v[8];
-    ld8(a4 + (long long)n * K + k, v);
-    const float d = ds[n];
+  if (k < K)
+    for (int n = blockIdx.y * 4 + ln; n < B; n += gridDim.y * 4) {
+      float v[8];
+      ld8(a4 + (long long)n * K + k, v);
+      const float d = ds[n];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] += d * v[j];
+      for (int j = 0; j < 8; ++j) s[j] += d * v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ln][u][j] = s[j];
+  __syncthreads();
+  if (ln == 0 && k < K) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dw + k + j, red[0][u][j] + red[1][u][j] + red[2][u][j] + red[3][u][j]);
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dw[k + j] = accumulate ? dw[k + j] + s[j] : s[j];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -361,6 +403,24 @@ __global__ void pack_up_kernel(const float* __restrict__ w, int Cs, int Cb, int 
     const int kh = c_up_k[phase >> 1][t >> 1], kw = c_up_k[phase & 1][t & 1];
     float v = 0.f;
     if (cb < Cb) v = w[((long long)cs * Cb + cb) * 16 + kh * 4 + kw];
+    stf(wp + i, v);
+  }
+}
+
+// up, 3/4-channel output (G.conv5, dgrad of D.conv1): all four output parities in ONE 16-row operand,
+// wp[phase*4 + c][ (dyi*3+dxi)*Cs + cs ] over the 9 input offsets dy,dx in {-1,0,1}; unused (phase, offset) pairs are 0
+template <typename W>
+__global__ void pack_up16_kernel(const float* __restrict__ w, int Cs, int Cb, W* __restrict__ wp) {
+  const long long K = 9ll * Cs, total = 16 * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), k = (int)(i % K);
+    const int phase = r >> 2, c = r & 3, t9 = k / Cs, cs = k % Cs;
+    const int dy = t9 / 3 - 1, dx = t9 % 3 - 1, ph = phase >> 1, pw = phase & 1;
+    // output row 2q+ph reads input row q+dy through kernel row kh:  ph=0: (0 -> 1), (-1 -> 3);  ph=1: (+1 -> 0), (0 -> 2)
+    const int kh = ph == 0 ? (dy == 0 ? 1 : (dy == -1 ? 3 : -1)) : (dy == 1 ? 0 : (dy == 0 ? 2 : -1));
+    const int kw = pw == 0 ? (dx == 0 ? 1 : (dx == -1 ? 3 : -1)) : (dx == 1 ? 0 : (dx == 0 ? 2 : -1));
+    float v = 0.f;
+    if (c < Cb && kh >= 0 && kw >= 0) v = w[((long long)cs * Cb + c) * 16 + kh * 4 + kw];
     stf(wp + i, v);
   }
 }

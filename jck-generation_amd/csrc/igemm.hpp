@@ -40,6 +40,7 @@ struct IgemmParams {
   int cstat;              // number of stats channels; stats channel = ch % cstat (cstat power of two)
   int ytiles_per_cset;    // channel tiles (blockIdx.y) that cover one set of cstat channels
   int epi;                // 0 none, 1 tanh
+  int rows_are_phases;    // 1: MFMA row r = phase*4 + channel (4-channel outputs, all four parities in one tile)
   long long w_phase_stride;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
@@ -57,7 +58,7 @@ template <class P, int BCH, int BPIX> struct IgemmCfg {
   static constexpr int LD = F32 ? (IG_BK + 4) : (IG_BK + 8);           // padded LDS row (elements)
   static constexpr int ESZ = F32 ? 4 : 2;
   static constexpr int BUF_BYTES = (BCH + BPIX) * LD * ESZ;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 64;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 128;
   // slots of partial statistics written by one launch = gridDim.x * gridDim.z * (gridDim.y / ytiles_per_cset) * WPIX
 };
 
@@ -69,20 +70,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr bool F32 = C::F32;
   constexpr int FM = C::FM, FN = C::FN, LD = C::LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int* toff = reinterpret_cast<int*>(smem_raw);                    // 16 ints
-  unsigned char* lds = smem_raw + 64;
+  int* toff = reinterpret_cast<int*>(smem_raw);                    // 16 ints: element offset of each tap
+  int* tdyx = toff + 16;                                           // 16 ints: (dy << 16) | (dx & 0xffff)
+  unsigned char* lds = smem_raw + 128;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int z = blockIdx.z;
   const int m0 = blockIdx.x * BPIX;
   const int ch0 = blockIdx.y * BCH;
   const int Cc = 1 << p.logC;
-  if (tid < 16) toff[tid] = (tid < p.ntaps) ? (((int)p.dy[z][tid] * p.W + (int)p.dx[z][tid]) << p.logC) : 0;
+  if (tid < 16) {
+    const int dyv = tid < p.ntaps ? (int)p.dy[z][tid] : 0, dxv = tid < p.ntaps ? (int)p.dx[z][tid] : 0;
+    toff[tid] = (dyv * p.W + dxv) << p.logC;
+    tdyx[tid] = tid < p.ntaps ? ((dyv << 16) | (dxv & 0xffff)) : (0x4000 << 16);      // padding taps never validate
+  }
 
   // ---- per-thread gather rows ---------------------------------------------------------------------
   const int lrow = tid >> 3, unit = tid & 7;
   int rowbase[C::APASS];
-  unsigned rmask[C::APASS];
+  int ryx[C::APASS];                                               // (iy0 << 16) | ix0 ; rows past M get iy0 = 0x4000
   const T* actp = reinterpret_cast<const T*>(p.act);
 #pragma unroll
   for (int ps = 0; ps < C::APASS; ++ps) {
@@ -91,15 +97,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int rem = m & ((1 << p.logOHW) - 1);
     const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
     rowbase[ps] = ((n * p.H + iy0) * p.W + ix0) << p.logC;
-    unsigned mk = 0;
-    if (m < p.M) {
-      for (int t = 0; t < p.ntaps; ++t) {
-        const int iy = iy0 + p.dy[z][t], ix = ix0 + p.dx[z][t];
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t;
-      }
-    }
-    rmask[ps] = mk;
+    ryx[ps] = ((m < p.M ? iy0 : 0x4000) << 16) | ix0;
   }
+  // bounds test of tap t for a gathered row, evaluated at the load (no 16-tap mask loop up front)
+  auto tap_ok = [&](int r, int t) -> bool {
+    const int d = tdyx[t];
+    const int iy = (r >> 16) + (d >> 16), ix = (r & 0xffff) + (int)(short)(d & 0xffff);
+    return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+  };
   const W* wsrc = reinterpret_cast<const W*>(p.w) + (long long)z * p.w_phase_stride;
   __syncthreads();   // toff visible
 
@@ -118,12 +123,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       if constexpr (NSUB == 1) {
         const int t = k >> p.logC, c = k & (Cc - 1);
         zero_raw(areg[ps]);
-        if ((rmask[ps] >> t) & 1u) ldraw(actp + (rowbase[ps] + toff[t] + c), areg[ps]);
+        if (tap_ok(ryx[ps], t)) ldraw(actp + (rowbase[ps] + toff[t] + c), areg[ps]);
       } else {   // C == 4: the 8-element unit spans two taps (pixels)
         const int t0 = k >> 2, t1 = t0 + 1;
         zero_raw(areg[ps]);
-        if ((rmask[ps] >> t0) & 1u) ldraw_half(actp + (rowbase[ps] + toff[t0]), areg[ps], 0);
-        if ((rmask[ps] >> t1) & 1u) ldraw_half(actp + (rowbase[ps] + toff[t1]), areg[ps], 1);
+        if (tap_ok(ryx[ps], t0)) ldraw_half(actp + (rowbase[ps] + toff[t0]), areg[ps], 0);
+        if (tap_ok(ryx[ps], t1)) ldraw_half(actp + (rowbase[ps] + toff[t1]), areg[ps], 1);
       }
     }
   };
@@ -225,12 +230,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     if (m >= p.M) continue;
     const int n = m >> p.logOHW;
     const int rem = m & ((1 << p.logOHW) - 1);
-    const long long off = (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY +
-                          (long long)(rem & ((1 << p.logOW) - 1)) * p.osX + p.obase[z];
+    const long long off0 = (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY +
+                           (long long)(rem & ((1 << p.logOW) - 1)) * p.osX;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
+      int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
       if (ch >= p.NchStore) continue;
+      long long off = off0 + p.obase[z];
+      if (p.rows_are_phases) { off = off0 + p.obase[ch >> 2]; ch = 0; }
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (p.epi == 1) {
 #pragma unroll

@@ -160,6 +160,20 @@ extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* 
   p.act = small_in; p.w = w; p.out = big_out; p.stats = stats;
   p.M = N * Hs * Ws; p.NchStore = cbp; p.logC = ilog2(Cs); p.K = 4 << p.logC;
   p.H = Hs; p.W = Ws; p.logOW = ilog2(Ws); p.logOHW = ilog2(Hs * Ws); p.sy = p.sx = 1; p.ntaps = 4;
+  if (cbp == 4) {
+    // 3/4-channel output: one launch, the four output parities are the 16 MFMA rows, 9 input offsets as taps; every
+    // workgroup then writes whole contiguous output rows instead of interleaved 8-byte pixels
+    if (Cs % 64) JCK_FAIL(JCK_E_ARG, "conv_up: Cs % 64 != 0 for a <=4-channel output");
+    if (stats) JCK_FAIL(JCK_E_ARG, "conv_up: statistics are not provided for <=4-channel outputs");
+    p.ntaps = 9; p.K = 9 * Cs; p.NchStore = 16; p.rows_are_phases = 1;
+    for (int t = 0; t < 9; ++t) { p.dy[0][t] = (signed char)(t / 3 - 1); p.dx[0][t] = (signed char)(t % 3 - 1); }
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) p.obase[ph * 2 + pw] = (ph * 2 * Ws + pw) * cbp;
+    p.osN = (long long)4 * Hs * Ws * cbp; p.osY = 2 * 2 * Ws * cbp; p.osX = 2 * cbp;
+    p.cstat = 4; p.ytiles_per_cset = 1; p.epi = epi_tanh ? 1 : 0; p.w_phase_stride = 0;
+    p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
+    return launch_igemm(prec, p, 16, 1, 1, (hipStream_t)stream, nullptr);
+  }
   static const int DI[2][2] = {{0, -1}, {1, 0}};          // input offset of tap th for output parity ph
   for (int ph = 0; ph < 2; ++ph)
     for (int pw = 0; pw < 2; ++pw) {
@@ -251,6 +265,20 @@ static int run_wgrad(int prec, WgradParams& p, const WgradPlan& pl, int nsub, fl
   JCK_FAIL(JCK_E_ARG, "bad prec");
 }
 
+static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, int Cs, int Cb, int logCbPad, float* grad,
+                               int accumulate, hipStream_t st) {
+  if (Cb % 64 == 0 && (1 << logCbPad) == Cb) {
+    hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3(Cb / 64, Cs), dim3(256), 0, st, ws, Z, CsRows, ncols, Cb, logCbPad, grad,
+                       accumulate);
+  } else {
+    const long long total = (long long)Cs * Cb * 16;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, ws,
+                       Z, CsRows, ncols, Cs, Cb, logCbPad, 16, grad, accumulate);
+  }
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 extern "C" size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs) {
   return plan_wgrad((long long)N * (Hb / 2) * (Wb / 2), 16 * jck_pad_chan(Cb), Cs).ws;
 }
@@ -268,10 +296,7 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
   p.flops = 2.0 * p.Mtot * Cs * 16.0 * Cb;
   int rc = run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
   if (rc) return rc;
-  const long long total = (long long)Cs * Cb * 16;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, ws, pl.Z, pl.CsRows, pl.ncols, Cs, Cb, p.logCb, 16, grad, accumulate);
-  HIPCHK(hipGetLastError());
+  JCK_TRY(launch_wgrad_reduce(ws, pl.Z, pl.CsRows, pl.ncols, Cs, Cb, p.logCb, grad, accumulate, (hipStream_t)stream));
   return JCK_OK;
 }
 
@@ -288,10 +313,7 @@ extern "C" int jck_g1_wgrad(int prec, const void* z, const void* dy, float* ws, 
   p.flops = 2.0 * B * Ci * 16.0 * Co;
   int rc = run_wgrad(prec, p, pl, 1, ws, ws_bytes, (hipStream_t)stream);
   if (rc) return rc;
-  const long long total = (long long)Ci * Co * 16;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, ws, pl.Z, pl.CsRows, pl.ncols, Ci, Co, p.logCb, 16, grad, accumulate);
-  HIPCHK(hipGetLastError());
+  JCK_TRY(launch_wgrad_reduce(ws, pl.Z, pl.CsRows, pl.ncols, Ci, Co, p.logCb, grad, accumulate, (hipStream_t)stream));
   return JCK_OK;
 }
 
@@ -310,6 +332,14 @@ extern "C" int jck_pack_down(int prec, const float* w, int Cs, int Cb, void* wp,
   return JCK_OK;
 }
 extern "C" int jck_pack_up(int prec, const float* w, int Cs, int Cb, void* wp, void* stream) {
+  if (Cb <= 4) {     // thin outputs: four parities as rows of one operand (see jck_conv_up)
+    if (Cs % 64) JCK_FAIL(JCK_E_ARG, "pack_up: Cs % 64 != 0 for a <=4-channel output");
+    const long long total16 = 16ll * 9 * Cs;
+    DISPATCH_T(prec, hipLaunchKernelGGL(pack_up16_kernel<T>, dim3(ew_grid(total16)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb,
+                                        (T*)wp));
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   const int rows = jck_pad_rows(Cb);
   const long long total = 4ll * rows * 4 * Cs;
   DISPATCH_T(prec, hipLaunchKernelGGL(pack_up_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, Cs, Cb, rows,
@@ -337,7 +367,8 @@ extern "C" int jck_bn_finalize(const float* stats, int slots, float count, const
                                float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* aux,
                                int C, void* stream) {
   if (slots < 1) JCK_FAIL(JCK_E_ARG, "bn_finalize: slots must be >= 1");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
+  if (C % 4) JCK_FAIL(JCK_E_ARG, "bn_finalize: C % 4 != 0");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, stats, slots, count, gamma, beta,
                      running_mean, running_var, (long long*)nbt, momentum, eps, aux, C);
   HIPCHK(hipGetLastError());
   return JCK_OK;
@@ -354,23 +385,25 @@ extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float s
   return JCK_OK;
 }
 
+extern "C" size_t jck_bn_bwd_ws_floats(int C) { return (size_t)(2 + 2 * BN_BWD_MAX_BLOCKS) * C; }
+
 extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
                               void* g_y, float* dgamma, float* dbeta, long long rows, int C, void* stream) {
   if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C must be a power of two in [8, 2048]");
-  const int rstep = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
-  if (C / 8 > 256) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C too large");
-  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((rows + rstep * 8 - 1) / (rstep * 8), 1024));
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks), dim3(256), 2 * C * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, sums, rows, C));
+  const int rstep = 256 / (C / 8);
+  if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C too large");
+  // stage 1: per-workgroup partial sums -> sums[2C + blk*2C ..];  stage 2: reduce to sums[0..2C) (+ dgamma/dbeta)
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  float* partial = sums + 2 * C;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C));
   HIPCHK(hipGetLastError());
-  if (dgamma && dbeta) {
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, dgamma, dbeta, C);
-    HIPCHK(hipGetLastError());
-  }
   return JCK_OK;
 }
 
@@ -434,8 +467,9 @@ extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const vo
     HIPCHK(hipGetLastError());
   }
   if (dwp) {
-    DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64)), dim3(64), 0, (hipStream_t)stream, ds,
-                                        (const T*)a4, B, K, dwp, accumulate));
+    if (!accumulate) HIPCHK(hipMemsetAsync(dwp, 0, (size_t)K * sizeof(float), (hipStream_t)stream));
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), 8), dim3(256), 0, (hipStream_t)stream, ds,
+                                        (const T*)a4, B, K, dwp));
     HIPCHK(hipGetLastError());
   }
   return JCK_OK;

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // grad[cs][cb][t] (+)= sum_z part[z][cs][t*CbPad + cb]      (cs < Cs, cb < Cb)
+// generic fallback (image layers with CbPad = 4, head): one thread per output element
 static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z, int CsRows, int ncols, int Cs, int Cb,
                                            int logCbPad, int ntaps, float* __restrict__ grad, int accumulate) {
   const long long total = (long long)Cs * Cb * ntaps;
@@ -213,4 +214,26 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z
     for (int z = 0; z < Z; ++z) s += part[(long long)z * CsRows * ncols + src];
     grad[i] = accumulate ? grad[i] + s : s;
   }
+}
+
+// 16-tap layers with Cb % 64 == 0: one workgroup per (cs, 64-channel chunk).  Reads are 256-byte runs along cb
+// (float4 per thread, summed over the Z slabs in registers), the [16][64] -> [64][16] transpose goes through LDS,
+// the 4 KB result is written as one contiguous run.
+static __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __restrict__ part, int Z, int CsRows, int ncols,
+                                                                    int Cb, int logCbPad, float* __restrict__ grad,
+                                                                    int accumulate) {
+  __shared__ float tile[64][17];
+  const int cs = blockIdx.y, cb0 = blockIdx.x * 64;
+  const int t = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  const float* src = part + (long long)cs * ncols + ((long long)t << logCbPad) + cb0 + c4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < Z; ++z) s += *reinterpret_cast<const f32x4*>(src + (long long)z * CsRows * ncols);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tile[c4 + k][t] = s[k];
+  __syncthreads();
+  const int cbl = threadIdx.x >> 2, t4 = (threadIdx.x & 3) * 4;
+  float* dst = grad + ((long long)cs * Cb + cb0 + cbl) * 16 + t4;
+  f32x4 o = {tile[cbl][t4], tile[cbl][t4 + 1], tile[cbl][t4 + 2], tile[cbl][t4 + 3]};
+  if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+  *reinterpret_cast<f32x4*>(dst) = o;
 }

@@ -37,6 +37,7 @@ PROTOS = {
     "jck_g1_wgrad": (i32, [i32, vp, vp, vp, sz, vp, i32, i32, i32, i32, i32, vp]),
     "jck_bn_finalize": (i32, [vp, i32, f32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
     "jck_bn_act_fwd": (i32, [i32, vp, vp, f32, vp, i64, i32, vp]),
+    "jck_bn_bwd_ws_floats": (sz, [i32]),
     "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),

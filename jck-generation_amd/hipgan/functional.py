@@ -138,7 +138,7 @@ class _ConvBnAct(Function):
         kind, slope, prec, rows, c = ctx.meta
         dev, st = x.device, cur_stream()
         f32 = dict(dtype=torch.float32, device=dev)
-        sums = torch.zeros(2 * c, **f32)
+        sums = torch.empty(lib.jck_bn_bwd_ws_floats(c), **f32)
         dgam, dbet = torch.zeros(c, **f32), torch.zeros(c, **f32)
         gy = torch.empty_like(y)
         lib.jck_bn_act_bwd(prec, ga.contiguous(), y, aux, slope, sums, gy, dgam, dbet, rows, c, st)

@@ -168,7 +168,7 @@ def test_bn_act(G, prec, cfg):
                           G.cur_stream())
     ad = torch.empty_like(yd)
     G.lib.jck_bn_act_fwd(prec, yd, aux, slope, ad, rows, c, G.cur_stream())
-    sums = torch.zeros(2 * c, device="cuda")
+    sums = torch.full((G.lib.jck_bn_bwd_ws_floats(c),), float("nan"), device="cuda")
     gy = torch.empty_like(yd)
     dgam, dbet = torch.ones(c, device="cuda"), torch.ones(c, device="cuda")
     G.lib.jck_bn_act_bwd(prec, G.to_nhwc(ga, prec), yd, aux, slope, sums, gy, dgam, dbet, rows, c, G.cur_stream())

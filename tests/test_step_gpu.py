@@ -51,14 +51,14 @@ def _rel(a, b):
     return abs(a - b) / max(abs(b), 1e-12)
 
 
-def _cmp_tensors(views, refs, tol, what, l2tol=None):
+def _cmp_tensors(views, refs, tol, what, l2tol=None, atol=0.0):
     bad = []
     for k, r in refs.items():
         g = views[k].detach().float().cpu().view(r.shape)
         scale = r.abs().max().item() + 1e-30
         err = (g - r).abs().max().item()
         l2 = ((g - r).norm() / (r.norm() + 1e-30)).item()
-        if err > tol * scale or (l2tol is not None and l2 > l2tol):
+        if err > tol * scale + atol or (l2tol is not None and l2 > l2tol):
             bad.append(f"{what}:{k}: max err {err:.3e} vs scale {scale:.3e} (tol {tol}), rel-l2 {l2:.3e} (tol {l2tol})")
     assert not bad, "\n".join(bad)
 
@@ -73,8 +73,10 @@ def test_step_parity_f32(B):
     ref, got, dgr, ggr = out[-1]
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 5e-3)
-    _cmp_tensors(eng.named_views("d"), {k: v for k, v in orc.d.items() if v.dtype == torch.float32}, 2e-4, "d_state")
-    _cmp_tensors(eng.named_views("g"), {k: v for k, v in orc.g.items() if v.dtype == torch.float32}, 2e-4, "g_state")
+    # post-Adam weights: Adam turns a gradient into ~lr*sign(g), so an element whose gradient is within rounding of 0 can
+    # move the other way (difference up to 2*lr per step).  Max-norm gets that absolute slack; relative L2 stays tight.
+    _cmp_tensors(eng.named_views("d"), {k: v for k, v in orc.d.items() if v.dtype == torch.float32}, 2e-4, "d_state", 2e-3, atol=4e-4)
+    _cmp_tensors(eng.named_views("g"), {k: v for k, v in orc.g.items() if v.dtype == torch.float32}, 2e-4, "g_state", 2e-4, atol=4e-4)
     assert int(eng.named_views("d")["norm1.num_batches_tracked"]) == int(orc.d["norm1.num_batches_tracked"])
     assert int(eng.named_views("g")["norm4.num_batches_tracked"]) == int(orc.g["norm4.num_batches_tracked"])
     fake = eng.tensor("fake").view(B, 64, 64, 4)[..., :3].permute(0, 3, 1, 2).float().cpu()
