@@ -55,7 +55,9 @@ template <class P, int BCH, int BPIX> struct IgemmCfg {
   static constexpr int FN = BPIX / WPIX / 16;
   static constexpr int WPASS = (BCH + 31) / 32;
   static constexpr int APASS = BPIX / 32;
-  static constexpr int LD = F32 ? (IG_BK + 4) : (IG_BK + 8);           // padded LDS row (elements)
+  // bf16: unpadded 128-byte rows, 16-byte chunk index XOR ((row >> 1) & 7): conflict-free for ds_read_b128's lane groups
+  // and for the 8-lane ds_write_b128 groups.  fp32: rows padded by 16 bytes.
+  static constexpr int LD = F32 ? (IG_BK + 4) : IG_BK;
   static constexpr int ESZ = F32 ? 4 : 2;
   static constexpr int BUF_BYTES = (BCH + BPIX) * LD * ESZ;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES + 128;
@@ -108,41 +110,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const W* wsrc = reinterpret_cast<const W*>(p.w) + (long long)z * p.w_phase_stride;
   __syncthreads();   // toff visible
 
-  Raw8<T> areg[C::APASS];
-  Raw8<W> wreg[C::WPASS];
+  struct Stage { Raw8<T> a[C::APASS]; Raw8<W> w[C::WPASS]; };
+  Stage sA, sB;                                                    // two register stages: global loads run 2 k-steps ahead
 
-  auto load_tiles = [&](int kc) {
+  auto load_tiles = [&](int kc, Stage& sg) {
     const int k = kc * IG_BK + unit * 8;
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
-      if (BCH >= 32 || r < BCH) ldraw(wsrc + (long long)(ch0 + r) * p.K + k, wreg[ps]);
+      if (BCH >= 32 || r < BCH) ldraw(wsrc + (long long)(ch0 + r) * p.K + k, sg.w[ps]);
     }
 #pragma unroll
     for (int ps = 0; ps < C::APASS; ++ps) {
       if constexpr (NSUB == 1) {
         const int t = k >> p.logC, c = k & (Cc - 1);
-        zero_raw(areg[ps]);
-        if (tap_ok(ryx[ps], t)) ldraw(actp + (rowbase[ps] + toff[t] + c), areg[ps]);
+        zero_raw(sg.a[ps]);
+        if (tap_ok(ryx[ps], t)) ldraw(actp + (rowbase[ps] + toff[t] + c), sg.a[ps]);
       } else {   // C == 4: the 8-element unit spans two taps (pixels)
         const int t0 = k >> 2, t1 = t0 + 1;
-        zero_raw(areg[ps]);
-        if (tap_ok(ryx[ps], t0)) ldraw_half(actp + (rowbase[ps] + toff[t0]), areg[ps], 0);
-        if (tap_ok(ryx[ps], t1)) ldraw_half(actp + (rowbase[ps] + toff[t1]), areg[ps], 1);
+        zero_raw(sg.a[ps]);
+        if (tap_ok(ryx[ps], t0)) ldraw_half(actp + (rowbase[ps] + toff[t0]), sg.a[ps], 0);
+        if (tap_ok(ryx[ps], t1)) ldraw_half(actp + (rowbase[ps] + toff[t1]), sg.a[ps], 1);
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  // LDS column (elements) of this thread's 8-element unit; rows ps*32 + lrow share ((row >> 1) & 7) because 32 % 16 == 0
+  const int wcol = F32 ? unit * 8 : ((unit ^ ((lrow >> 1) & 7)) * 8);
+  auto store_tiles = [&](int buf, const Stage& sg) {
     W* wt = reinterpret_cast<W*>(lds + buf * C::BUF_BYTES);      // [BCH][LD]
     W* at = wt + BCH * LD;                                        // [BPIX][LD]
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
-      if (BCH >= 32 || r < BCH) straw(wt + r * LD + unit * 8, wreg[ps]);
+      if (BCH >= 32 || r < BCH) straw(wt + r * LD + wcol, sg.w[ps]);
     }
 #pragma unroll
-    for (int ps = 0; ps < C::APASS; ++ps) straw(at + (ps * 32 + lrow) * LD + unit * 8, areg[ps]);
+    for (int ps = 0; ps < C::APASS; ++ps) straw(at + (ps * 32 + lrow) * LD + wcol, sg.a[ps]);
   };
 
   const int wch = (C::WCH == 2) ? (wave >> 1) : 0;
@@ -154,24 +158,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / IG_BK;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int kc = 0; kc < nk; ++kc) {
-    const bool more = kc + 1 < nk;
-    if (more) load_tiles(kc + 1);
-    const W* wt0 = reinterpret_cast<const W*>(lds + (kc & 1) * C::BUF_BYTES);
+  const int sw = ((lane & 15) >> 1) & 7;                           // read-side swizzle of this lane's rows
+  auto compute = [&](int buf) {
+    const W* wt0 = reinterpret_cast<const W*>(lds + buf * C::BUF_BYTES);
     const W* at0 = wt0 + BCH * LD;
     if constexpr (!F32) {
-      const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD + (lane >> 4) * 8;
-      const bf16_t* at = at0 + (wpix * FN * 16 + (lane & 15)) * LD + (lane >> 4) * 8;
+      const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD;
+      const bf16_t* at = at0 + (wpix * FN * 16 + (lane & 15)) * LD;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        const int col = (((lane >> 4) + ks * 4) ^ sw) * 8;
         bf16x8 a[FM], b[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + ks * 32);
+        for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + col);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + ks * 32);
+        for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + col);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -194,8 +195,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_tiles((kc + 1) & 1);
+  };
+
+  // software pipeline: LDS double buffer + two register stages (k-step kc computes from LDS while the loads of kc+2
+  // are in flight and kc+1 waits in registers for its LDS slot)
+  load_tiles(0, sA);
+  store_tiles(0, sA);
+  if (nk > 1) load_tiles(1, sA);
+  __syncthreads();
+  for (int kc = 0; kc < nk; kc += 2) {
+    if (kc + 2 < nk) load_tiles(kc + 2, sB);
+    compute(0);
+    if (kc + 1 < nk) store_tiles(1, sA);
     __syncthreads();
+    if (kc + 1 < nk) {
+      if (kc + 3 < nk) load_tiles(kc + 3, sA);
+      compute(1);
+      if (kc + 2 < nk) store_tiles(0, sB);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------

@@ -117,6 +117,8 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   JCK_FAIL(JCK_E_ARG, "igemm: unsupported padded row count " + std::to_string(nch_pad));
 }
 
+static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, int Cs, int Cb, int logCbPad, float* grad,
+                               int accumulate, hipStream_t st);
 int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   if (p.K % IG_BK != 0) JCK_FAIL(JCK_E_ARG, "igemm: K must be a multiple of 64, got " + std::to_string(p.K));
   if (p.M <= 0) JCK_FAIL(JCK_E_ARG, "igemm: empty problem");
@@ -221,7 +223,7 @@ static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
   pl.gy = cdiv(Cs, pl.BS);
   pl.CsRows = pl.gy * pl.BS;
   const int tiles = pl.gx * pl.gy;
-  long long Z = std::max(1, 1024 / tiles);
+  long long Z = std::max(1, (tiles >= 4 ? 1024 : 256) / tiles);
   const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
   Z = std::min(Z, maxZ);
   long long mchunk = (Mtot + Z - 1) / Z;
@@ -270,6 +272,8 @@ static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, in
   if (Cb % 64 == 0 && (1 << logCbPad) == Cb) {
     hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3(Cb / 64, Cs), dim3(256), 0, st, ws, Z, CsRows, ncols, Cb, logCbPad, grad,
                        accumulate);
+  } else if (logCbPad == 2 && ncols == 64) {
+    hipLaunchKernelGGL(wgrad_reduce_img_kernel, dim3(Cs), dim3(256), 0, st, ws, Z, CsRows, Cb, grad, accumulate);
   } else {
     const long long total = (long long)Cs * Cb * 16;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, st, ws,
@@ -475,10 +479,7 @@ extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const vo
   return JCK_OK;
 }
 extern "C" int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream) {
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(16 * C, 256)), dim3(256), 0, (hipStream_t)stream, dwp, 1, 1, 16 * C, 1, C,
-                     ilog2(C), 16, grad, accumulate);
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
+  return launch_wgrad_reduce(dwp, 1, 1, 16 * C, 1, C, ilog2(C), grad, accumulate, (hipStream_t)stream);
 }
 
 extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,

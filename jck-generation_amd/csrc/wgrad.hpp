@@ -216,6 +216,25 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z
   }
 }
 
+// image layers (CbPad = 4, ncols = 64): one workgroup per cs row; 64 columns x 4 slab lanes, LDS reduce over the lanes
+static __global__ __launch_bounds__(256) void wgrad_reduce_img_kernel(const float* __restrict__ part, int Z, int CsRows, int Cb,
+                                                                      float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4][64];
+  const int cs = blockIdx.x, col = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int z = zl; z < Z; z += 4) s += part[((long long)z * CsRows + cs) * 64 + col];
+  red[zl][col] = s;
+  __syncthreads();
+  if (zl == 0) {
+    const int t = col >> 2, cb = col & 3;
+    if (cb < Cb) {
+      const float v = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+      float* d = grad + ((long long)cs * Cb + cb) * 16 + t;
+      *d = accumulate ? *d + v : v;
+    }
+  }
+}
+
 // 16-tap layers with Cb % 64 == 0: one workgroup per (cs, 64-channel chunk).  Reads are 256-byte runs along cb
 // (float4 per thread, summed over the Z slabs in registers), the [16][64] -> [64][16] transpose goes through LDS,
 // the 4 KB result is written as one contiguous run.
