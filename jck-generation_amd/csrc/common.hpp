@@ -146,5 +146,30 @@ __device__ __forceinline__ void straw(float* p, const Raw8<float>& r) {
   *reinterpret_cast<f32x4*>(p + 4) = r.b;
 }
 
+// ---- buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset past num_records returns 0,
+// which is how out-of-image taps and rows past M become zero operands without a branch or a zero-fill
+#define JCK_OOB 0x80000000u
+__device__ __forceinline__ auto make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <class R> __device__ __forceinline__ void buf_ld8(R rs, unsigned off, Raw8<bf16_t>& r) {
+  r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+}
+template <class R> __device__ __forceinline__ void buf_ld8(R rs, unsigned off, Raw8<float>& r) {
+  const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16), 0, 0);
+  r.a = __builtin_bit_cast(f32x4, a);
+  r.b = __builtin_bit_cast(f32x4, b);
+}
+// 4 elements (one 4-channel pixel) into half h of the unit
+template <class R> __device__ __forceinline__ void buf_ld4(R rs, unsigned off, Raw8<bf16_t>& r, int h) {
+  const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+  if (h == 0) { r.v[0] = t[0]; r.v[1] = t[1]; } else { r.v[2] = t[0]; r.v[3] = t[1]; }
+}
+template <class R> __device__ __forceinline__ void buf_ld4(R rs, unsigned off, Raw8<float>& r, int h) {
+  const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+  if (h == 0) r.a = __builtin_bit_cast(f32x4, t); else r.b = __builtin_bit_cast(f32x4, t);
+}
+
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

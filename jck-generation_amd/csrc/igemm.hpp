@@ -41,6 +41,8 @@ struct IgemmParams {
   int ytiles_per_cset;    // channel tiles (blockIdx.y) that cover one set of cstat channels
   int epi;                // 0 none, 1 tanh
   int rows_are_phases;    // 1: MFMA row r = phase*4 + channel (4-channel outputs, all four parities in one tile)
+  int gx, gy, gz;         // logical grid: pixel tiles, channel tiles, phases (launched as a 1-D grid of gx*gy*gz)
+  unsigned act_bytes, w_bytes;   // sizes of the gathered tensor and of the packed weights (buffer descriptors)
   long long w_phase_stride;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
@@ -64,7 +66,7 @@ template <class P, int BCH, int BPIX> struct IgemmCfg {
   // slots of partial statistics written by one launch = gridDim.x * gridDim.z * (gridDim.y / ytiles_per_cset) * WPIX
 };
 
-template <class P, int BCH, int BPIX, int NSUB>
+template <class P, int BCH, int BPIX, int NSUB, int NST = 2>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   typedef typename P::T T;        // activation storage type
   typedef typename P::W W;        // LDS / packed-weight element type (bf16_t or float)
@@ -77,9 +79,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   unsigned char* lds = smem_raw + 128;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int z = blockIdx.z;
-  const int m0 = blockIdx.x * BPIX;
-  const int ch0 = blockIdx.y * BCH;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an XCD, each with its own
+  // 4 MB L2), so give every XCD a contiguous run of logical tiles, ordered channel-tile fastest, then phase, then
+  // pixel tile: the tiles that gather the same activation rows (other output channels, other parities, the halo of
+  // the next pixel tile) run on one L2.  Bijective for any grid size.
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bidy = wgid % p.gy;
+  const int z = (wgid / p.gy) % p.gz;
+  const int bidx = wgid / (p.gy * p.gz);
+  const int m0 = bidx * BPIX;
+  const int ch0 = bidy * BCH;
   const int Cc = 1 << p.logC;
   if (tid < 16) {
     const int dyv = tid < p.ntaps ? (int)p.dy[z][tid] : 0, dxv = tid < p.ntaps ? (int)p.dx[z][tid] : 0;
@@ -88,49 +102,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   // ---- per-thread gather rows ---------------------------------------------------------------------
+  // Loads are buffer loads with 32-bit byte offsets; an invalid tap / row selects JCK_OOB and reads zeros.
   const int lrow = tid >> 3, unit = tid & 7;
-  int rowbase[C::APASS];
-  int ryx[C::APASS];                                               // (iy0 << 16) | ix0 ; rows past M get iy0 = 0x4000
-  const T* actp = reinterpret_cast<const T*>(p.act);
+  constexpr unsigned ESZ = sizeof(T);
+  unsigned rowoff[C::APASS];                                       // byte offset of tap (0,0) of the row (+ this unit's channels)
+  int riy[C::APASS], rix[C::APASS];                                // iy0 (poisoned past M), ix0
 #pragma unroll
   for (int ps = 0; ps < C::APASS; ++ps) {
     const int m = m0 + ps * 32 + lrow;
     const int n = m >> p.logOHW;
     const int rem = m & ((1 << p.logOHW) - 1);
     const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
-    rowbase[ps] = ((n * p.H + iy0) * p.W + ix0) << p.logC;
-    ryx[ps] = ((m < p.M ? iy0 : 0x4000) << 16) | ix0;
+    rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC) + (NSUB == 1 ? unit * 8 : 0)) * ESZ;
+    riy[ps] = m < p.M ? iy0 : 0x40000000;
+    rix[ps] = ix0;
   }
-  // bounds test of tap t for a gathered row, evaluated at the load (no 16-tap mask loop up front)
-  auto tap_ok = [&](int r, int t) -> bool {
-    const int d = tdyx[t];
-    const int iy = (r >> 16) + (d >> 16), ix = (r & 0xffff) + (int)(short)(d & 0xffff);
-    return (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-  };
-  const W* wsrc = reinterpret_cast<const W*>(p.w) + (long long)z * p.w_phase_stride;
-  __syncthreads();   // toff visible
+  unsigned wrowoff[C::WPASS];
+#pragma unroll
+  for (int ps = 0; ps < C::WPASS; ++ps)
+    wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + lrow) * p.K + unit * 8) * sizeof(W));
+  const auto rs_act = make_rsrc(p.act, p.act_bytes);
+  const auto rs_w = make_rsrc(p.w, p.w_bytes);
+  __syncthreads();   // tap tables visible
 
+  // NST register stages: the loads of k-step kc + NST are issued while kc is computed, so NST tiles are in flight per
+  // workgroup - the loop is bound by (bytes in flight) / (L2 latency), not by MFMA issue, at these problem sizes
   struct Stage { Raw8<T> a[C::APASS]; Raw8<W> w[C::WPASS]; };
-  Stage sA, sB;                                                    // two register stages: global loads run 2 k-steps ahead
+  Stage st[NST];
 
   auto load_tiles = [&](int kc, Stage& sg) {
-    const int k = kc * IG_BK + unit * 8;
+    const int kbase = kc * IG_BK;                                  // wave-uniform
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
-      if (BCH >= 32 || r < BCH) ldraw(wsrc + (long long)(ch0 + r) * p.K + k, sg.w[ps]);
+      if (BCH >= 32 || r < BCH) buf_ld8(rs_w, wrowoff[ps] + kbase * (unsigned)sizeof(W), sg.w[ps]);
     }
+    if constexpr (NSUB == 1) {
+      // C >= 64: the whole 64-wide k-step lies in ONE tap -> tap index, its (dy, dx) and its offset are scalars
+      const int t = kbase >> p.logC;
+      const int dyv = p.dy[z][t], dxv = p.dx[z][t];
+      const int toffb = (((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * (int)ESZ;
 #pragma unroll
-    for (int ps = 0; ps < C::APASS; ++ps) {
-      if constexpr (NSUB == 1) {
-        const int t = k >> p.logC, c = k & (Cc - 1);
-        zero_raw(sg.a[ps]);
-        if (tap_ok(ryx[ps], t)) ldraw(actp + (rowbase[ps] + toff[t] + c), sg.a[ps]);
-      } else {   // C == 4: the 8-element unit spans two taps (pixels)
-        const int t0 = k >> 2, t1 = t0 + 1;
-        zero_raw(sg.a[ps]);
-        if (tap_ok(ryx[ps], t0)) ldraw_half(actp + (rowbase[ps] + toff[t0]), sg.a[ps], 0);
-        if (tap_ok(ryx[ps], t1)) ldraw_half(actp + (rowbase[ps] + toff[t1]), sg.a[ps], 1);
+      for (int ps = 0; ps < C::APASS; ++ps) {
+        const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
+        buf_ld8(rs_act, ok ? rowoff[ps] + (unsigned)toffb : JCK_OOB, sg.a[ps]);
+      }
+    } else {   // C == 4: the 8-element unit spans two taps (pixels), per-thread taps from the LDS tables
+      const int t0 = (kbase + unit * 8) >> 2, t1 = t0 + 1;
+      const int d0 = tdyx[t0], d1 = tdyx[t1], o0 = toff[t0] * (int)ESZ, o1 = toff[t1] * (int)ESZ;
+#pragma unroll
+      for (int ps = 0; ps < C::APASS; ++ps) {
+        const bool ok0 = (unsigned)(riy[ps] + (d0 >> 16)) < (unsigned)p.H && (unsigned)(rix[ps] + (int)(short)(d0 & 0xffff)) < (unsigned)p.W;
+        const bool ok1 = (unsigned)(riy[ps] + (d1 >> 16)) < (unsigned)p.H && (unsigned)(rix[ps] + (int)(short)(d1 & 0xffff)) < (unsigned)p.W;
+        buf_ld4(rs_act, ok0 ? rowoff[ps] + (unsigned)o0 : JCK_OOB, sg.a[ps], 0);
+        buf_ld4(rs_act, ok1 ? rowoff[ps] + (unsigned)o1 : JCK_OOB, sg.a[ps], 1);
       }
     }
   };
@@ -197,30 +222,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  // software pipeline: LDS double buffer + two register stages (k-step kc computes from LDS while the loads of kc+2
-  // are in flight and kc+1 waits in registers for its LDS slot)
-  load_tiles(0, sA);
-  store_tiles(0, sA);
-  if (nk > 1) load_tiles(1, sA);
+  // software pipeline: LDS double buffer + NST register stages; k-step k lives in stage k % NST
+  load_tiles(0, st[0]);
+  store_tiles(0, st[0]);
+#pragma unroll
+  for (int j = 1; j < NST; ++j)
+    if (j < nk) load_tiles(j, st[j]);
   __syncthreads();
-  for (int kc = 0; kc < nk; kc += 2) {
-    if (kc + 2 < nk) load_tiles(kc + 2, sB);
-    compute(0);
-    if (kc + 1 < nk) store_tiles(1, sA);
-    __syncthreads();
-    if (kc + 1 < nk) {
-      if (kc + 3 < nk) load_tiles(kc + 3, sA);
-      compute(1);
-      if (kc + 2 < nk) store_tiles(0, sB);
-      __syncthreads();
+  for (int kc = 0; kc < nk; kc += NST) {
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      const int k = kc + j;
+      if (k < nk) {
+        if (k + NST < nk) load_tiles(k + NST, st[j]);              // stage j held k-step k, already in LDS
+        compute(k & 1);
+        if (k + 1 < nk) store_tiles((k + 1) & 1, st[(j + 1) % NST]);
+        __syncthreads();
+      }
     }
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------
   if (p.stats) {
     // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
-    const int yrep = blockIdx.y / p.ytiles_per_cset, nyrep = gridDim.y / p.ytiles_per_cset;
-    const long long slot = (((long long)z * gridDim.x + blockIdx.x) * nyrep + yrep) * C::WPIX + wpix;
+    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
+    const long long slot = (((long long)z * p.gx + bidx) * nyrep + yrep) * C::WPIX + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {

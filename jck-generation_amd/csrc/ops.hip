@@ -1,6 +1,7 @@
 // C-ABI launchers for the per-op entry points of include/jckgan.h (host side; kernels in *.hpp).
 #include "ops_internal.hpp"
 
+#include <cstdlib>
 #include <string>
 
 static thread_local std::string g_err;
@@ -87,12 +88,13 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
   IgemmParams q = p;
+  q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
   if (q.stats) {
     if (q.cstat % BCH != 0 && BCH % q.cstat != 0) JCK_FAIL(JCK_E_ARG, "igemm: stats channel count incompatible with the tile");
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * C::WPIX);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, q);
+  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), C::LDS_BYTES, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -103,7 +105,8 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4-channel gather with >=128 output rows unsupported");
     // keep >= ~256 workgroups in flight: halve the pixel tile for small pixel counts
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
-    if (wgs >= 256) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st, slots);
+    static const long long min_wgs = getenv("JCK_IGEMM_MIN_WGS") ? atoll(getenv("JCK_IGEMM_MIN_WGS")) : 256;
+    if (wgs >= min_wgs) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
@@ -119,7 +122,18 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
 
 static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, int Cs, int Cb, int logCbPad, float* grad,
                                int accumulate, hipStream_t st);
-int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
+int launch_igemm(int prec, const IgemmParams& p0, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
+  IgemmParams p = p0;
+  const long long esz = prec == JCK_PREC_F32 ? 4 : 2;
+  if (nsub == 1 && p.logC < 6) JCK_FAIL(JCK_E_ARG, "igemm: the gathered tensor needs >= 64 channels (or exactly 4)");
+  {
+    // extent of the gathered tensor: rows (n, oy, ox) span N = M / (OH*OW) images of H x W x C
+    const long long nimg = ((long long)p.M + (1ll << p.logOHW) - 1) >> p.logOHW;
+    const long long ab = nimg * p.H * p.W * (1ll << p.logC) * esz;
+    const long long wb = (long long)phases * (p.w_phase_stride ? p.w_phase_stride : (long long)nch_pad * p.K) * esz;
+    if (ab >= (1ll << 31) || wb >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "igemm: operand exceeds 2 GiB (32-bit buffer offsets)");
+    p.act_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
+  }
   if (p.K % IG_BK != 0) JCK_FAIL(JCK_E_ARG, "igemm: K must be a multiple of 64, got " + std::to_string(p.K));
   if (p.M <= 0) JCK_FAIL(JCK_E_ARG, "igemm: empty problem");
   if (p.stats && !slots) JCK_FAIL(JCK_E_ARG, "igemm: stats requested without a slot-count output");
