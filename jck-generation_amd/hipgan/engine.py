@@ -40,22 +40,27 @@ class DcganEngine:
 
     family = 0
 
-    def __init__(self, batch, prec="bf16", device="cuda:0"):
+    def __init__(self, batch, prec="bf16", device="cuda:0", share=None):
+        """share: another DcganEngine whose arenas (weights, gradients, Adam moments, BN statistics) this one binds
+        too - used for the ragged last batch of an epoch, which needs its own workspace geometry but the same state."""
         if not torch.cuda.is_available():
             raise JckError("DcganEngine needs a GPU: the HIP path has no CPU fallback")
-        self.device = torch.device(device)
+        self.device = torch.device(device) if share is None else share.device
         torch.cuda.set_device(self.device)
-        self.prec = _PREC[prec]
+        self.prec = _PREC[prec] if share is None else share.prec
         self.batch = batch
-        self.t = 0                      # optimiser steps taken (Adam bias correction), D and G advance together
+        self._shared = share._shared if share is not None else {"t": 0, "version": 0}
+        self._packed_version = -1
         h = C.c_void_p()
         dll = load_library()
         if dll.jck_engine_create(C.byref(h), self.family, self.prec, batch) != 0:
             raise JckError(dll.jck_last_error().decode())
         self._h = h
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.arenas = {}
+        self.arenas = {} if share is None else share.arenas
         for net, tag in ((0, "g"), (1, "d")):
+            if share is not None:
+                break
             n, nb = dll.jck_engine_arena_numel(self.family, net, 0), dll.jck_engine_arena_numel(self.family, net, 1)
             for what in ("params", "grads", "m", "v"):
                 self.arenas[f"{tag}_{what}"] = torch.zeros(n, **f32)
@@ -70,9 +75,17 @@ class DcganEngine:
         # BN running_var starts at 1 (nn.BatchNorm2d)
         for tag in ("g", "d"):
             for name, kind, off, numel, shp in self.layout[tag]:
-                if kind == 2:
+                if kind == 2 and share is None:
                     a[f"{tag}_bn"][off:off + numel].fill_(1.0)
-        self._scal = None
+
+    # optimiser step count and weight version are shared by engines bound to the same arenas
+    @property
+    def t(self):
+        return self._shared["t"]
+
+    @t.setter
+    def t(self, v):
+        self._shared["t"] = v
 
     def __del__(self):
         try:
@@ -105,6 +118,7 @@ class DcganEngine:
                 if k not in views:
                     raise JckError(f"unexpected key {k}")
                 views[k].copy_(v.detach().to(self.device).view(views[k].shape))
+        self.mark_weights_changed()
         self.repack()
 
     def state_dicts(self):
@@ -123,8 +137,33 @@ class DcganEngine:
         return [(k, v[k]) for k in keys]
 
     def repack(self):
+        """Re-derive this engine's GEMM operand copies from the fp32 parameters (after any out-of-engine write)."""
         lib.jck_engine_repack(self._h, 0, cur_stream())
         lib.jck_engine_repack(self._h, 1, cur_stream())
+        self._packed_version = self._shared["version"]
+
+    def mark_weights_changed(self):
+        self._shared["version"] += 1
+
+    def adopt_modules(self, model_g, model_d):
+        """Moves the parameters / buffers of reference-shaped nn.Modules INTO the arenas (zero copy afterwards):
+        `module.state_dict()`, checkpoints and `.grad` then always show the live training state."""
+        for tag, mod in (("g", model_g), ("d", model_d)):
+            views, grads = self.named_views(tag), self.named_views(tag, "grads")
+            with torch.no_grad():
+                for name, p in mod.named_parameters():
+                    views[name].copy_(p.detach().to(self.device))
+                    p.data = views[name]
+                    p.grad = grads[name]
+                for name, b in list(mod.named_buffers()):
+                    views[name].copy_(b.detach().to(self.device))
+                    owner = mod
+                    *path, leaf = name.split(".")
+                    for part in path:
+                        owner = getattr(owner, part)
+                    owner._buffers[leaf] = views[name]
+        self.mark_weights_changed()
+        self.repack()
 
     # ---- the step ---------------------------------------------------------------------------------------
     def _inputs(self, real, noise, lr, grad_scale):
@@ -162,6 +201,8 @@ class DcganEngine:
         """Enqueues one full step on the current stream; no host sync.  `reduce_d/reduce_g(flat_grads)` are
         called between the loss and the optimiser phases (data-parallel gradient all-reduce)."""
         noise = noise if noise is not None else self.draw_noise()
+        if self._packed_version != self._shared["version"]:
+            self.repack()
         si, keep = self._inputs(real, noise, lr, grad_scale)
         st = cur_stream()
         h = self._h
@@ -177,7 +218,13 @@ class DcganEngine:
             handle()
         lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1
+        self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
+        self._packed_version = self._shared["version"]
         self._keep = keep
+
+    def scalars_view(self):
+        """Device view (float32[8]) of the step scalars - no sync."""
+        return self._ws_view(load_library().jck_engine_scalars(self._h), 8, torch.float32)
 
     def scalars(self):
         """Host copy of the eight step scalars (one device->host sync)."""
@@ -199,6 +246,8 @@ class DcganEngine:
     def sample(self, z):
         """G(z) with train-mode BatchNorm (train/dcgan_trainer.py:199-200) -> NCHW fp32 on the device."""
         n = z.shape[0]
+        if self._packed_version != self._shared["version"]:
+            self.repack()
         out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
         for i in range(0, n, self.batch):
             zc = z[i:i + self.batch].to(self.device, torch.float32).contiguous().view(-1, 100)

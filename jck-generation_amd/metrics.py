@@ -1,0 +1,131 @@
+"""Inception-Score / FID / intra-FID with the reference's interface (metrics.py:19-141): `Metrics(real_images)`,
+`.inception_score(loader, splits=10)`, `.fid(loader, intra_fid=False, label=0)`, `.intra_fid(tensor)`.
+
+The arithmetic is the reference's (100-d logits of a CIFAR-100 fine-tuned Inception-v3, softmax/KL per split, mean/cov +
+scipy sqrtm, 20 superclass FIDs summed and divided by 100).  The feature extractor is pluggable: by default it is built as
+the reference builds it (torchvision inception_v3 with a Linear(2048,100) head loaded from ./save/iception_v3/loss_bset.pt);
+when torchvision or the weights are missing, construction raises MetricsUnavailable and the trainer carries on without
+scores.  Fixes the reference's `.targets` defect for DCGAN (its loader has none): targets are optional."""
+import os
+import pickle
+
+import numpy as np
+import torch
+from scipy.linalg import sqrtm
+
+from utils import get_default_device
+
+SUPERCLASS_MEMBERS = (
+    (4, 30, 55, 72, 95), (1, 32, 67, 73, 91), (54, 62, 70, 82, 92), (9, 10, 16, 28, 61), (0, 51, 53, 57, 83),
+    (22, 39, 40, 86, 87), (5, 20, 25, 84, 94), (6, 7, 14, 18, 24), (3, 42, 43, 88, 97), (12, 17, 37, 68, 76),
+    (23, 33, 49, 60, 71), (15, 19, 21, 31, 38), (34, 63, 64, 66, 75), (26, 45, 77, 79, 99), (2, 11, 35, 46, 98),
+    (27, 29, 44, 78, 93), (36, 50, 65, 74, 80), (47, 52, 56, 59, 96), (8, 13, 48, 58, 90), (41, 69, 81, 85, 89))
+
+
+class MetricsUnavailable(RuntimeError):
+    pass
+
+
+def default_extractor(device, weights="./save/iception_v3/loss_bset.pt"):
+    try:
+        from torchvision import models
+    except Exception as e:
+        raise MetricsUnavailable(f"torchvision is not installed ({e})")
+    if not os.path.exists(weights):
+        raise MetricsUnavailable(f"fine-tuned Inception weights not found at {weights}")
+    net = models.inception_v3()
+    net.aux_logits = False
+    net.fc = torch.nn.Sequential(torch.nn.Linear(net.fc.in_features, 100))
+    net.load_state_dict(torch.load(weights, map_location="cpu"))
+    return net.to(device).eval()
+
+
+def fid_from_features(real, fake):
+    """Frechet distance between the Gaussians fitted to two feature matrices (reference metrics.py:120-129)."""
+    mu1, sigma1 = np.mean(real, axis=0), np.cov(real, rowvar=False)
+    mu2, sigma2 = np.mean(fake, axis=0), np.cov(fake, rowvar=False)
+    covmean = sqrtm(sigma1.dot(sigma2))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return float(np.sum((mu1 - mu2) ** 2.0) + np.trace(sigma1 + sigma2 - 2.0 * covmean))
+
+
+def inception_score_from_probs(preds, splits=10):
+    """exp(mean KL(p(y|x) || p(y))) per split, averaged (reference metrics.py:97-110; scipy.stats.entropy semantics)."""
+    n = preds.shape[0]
+    out = []
+    for k in range(splits):
+        part = preds[k * (n // splits):(k + 1) * (n // splits), :]
+        py = np.mean(part, axis=0)
+        pk = part / part.sum(axis=1, keepdims=True)
+        qk = py / py.sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            kl = np.where(pk > 0, pk * np.log(pk / qk), 0.0).sum(axis=1)
+        out.append(np.exp(np.mean(kl)))
+    return float(np.mean(out))
+
+
+class Metrics:
+    def __init__(self, real_images, extractor=None, real_features=None, cache="./data/metric_data.pikl"):
+        self.device = get_default_device()
+        self.class_to_superclass = {c: s for s, row in enumerate(SUPERCLASS_MEMBERS) for c in row}
+        self.inception_model = extractor if extractor is not None else (None if real_features is not None
+                                                                        else default_extractor(self.device))
+        real_targets = getattr(real_images, "targets", None)
+        fake_targets = [i for i in range(100) for _ in range(10)]
+        self.real_superclass_idx, self.fake_superclass_idx = {}, {}
+        for s in range(20):
+            self.fake_superclass_idx[s] = [i for i, t in enumerate(fake_targets) if self.class_to_superclass[t] == s]
+            if real_targets is not None:
+                self.real_superclass_idx[s] = [i for i, t in enumerate(real_targets) if self.class_to_superclass[int(t)] == s]
+        if real_features is not None:
+            self.real_features = np.asarray(real_features)
+        elif os.path.exists(cache):
+            with open(cache, "rb") as f:
+                self.real_features = pickle.load(f)
+        else:
+            loader = torch.utils.data.DataLoader(real_images, 128, shuffle=False, num_workers=0)
+            self.real_features = self._extract(loader, real=True)
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            with open(cache, "wb") as f:
+                pickle.dump(self.real_features, f, pickle.HIGHEST_PROTOCOL)
+
+    def _prep_real(self, image):
+        """real images arrive as uint8 [B,3,32,32]: Resize((299,299)) + ImageNet normalisation (reference preprocessor :44-47)."""
+        x = image.float() / 255.0 if image.dtype == torch.uint8 else image
+        if x.shape[-1] != 299:
+            x = torch.nn.functional.interpolate(x, size=[299, 299], mode="bilinear", align_corners=False)
+            mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+            x = (x - mean) / std
+        return x
+
+    def _extract(self, images, real=False, softmax=False):
+        feats = []
+        for image in images:
+            if real:
+                image = self._prep_real(image[0])
+            if self.inception_model is None:
+                feature = image if torch.is_tensor(image) else torch.as_tensor(image)     # pre-computed features
+            else:
+                with torch.no_grad():
+                    feature = self.inception_model(image.to(self.device))
+            if softmax:
+                feature = torch.nn.functional.softmax(feature.float(), dim=1)
+            feats.append(feature.detach().cpu().numpy())
+        return np.vstack(feats)
+
+    def inception_score(self, images, splits=10):
+        return inception_score_from_probs(self._extract(images, softmax=True), splits)
+
+    def fid(self, generated_images, intra_fid=False, label=0):
+        gen = self._extract(generated_images)
+        real = self.real_features[self.real_superclass_idx[label]] if intra_fid else self.real_features
+        return fid_from_features(real, gen)
+
+    def intra_fid(self, generated_images):
+        total = 0
+        for s in range(20):
+            sub = generated_images[self.fake_superclass_idx[s]]
+            total += self.fid(torch.utils.data.DataLoader(sub, 128, shuffle=False), intra_fid=True, label=s)
+        return total / 100

@@ -1,0 +1,241 @@
+"""DCGAN trainer for MI355X - drop-in for the reference's train/dcgan_trainer.py.
+
+Same constructor `DCGANTrainer(args, model_g, model_d, data_pre)`, same `train()`, `save_model(typ, iters, value, images)`,
+`compute_gradient_penalty(real, fake)`, same log line, same checkpoint dict {'model_g','model_d','optimizer_g','optimizer_d'}
+and file names.  What differs is the execution: one iteration (reference train/dcgan_trainer.py:155-189) is a single native
+schedule of gfx950 kernels (hipgan.engine.DcganEngine -> jck_engine_phase): the modules' parameters live in the engine's flat
+arenas (zero copy), the six logged scalars stay on the device and are read back only when a line is logged, the optimiser
+step is a fused flat Adam, and with torch.distributed initialised the D/G gradient arenas are all-reduced over RCCL (D's
+reduction overlapping the gradient-penalty pass).  No CPU fallback.
+"""
+import argparse
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from hipgan import JckError
+from hipgan.dist import GradReducer
+from hipgan.engine import SCALAR_NAMES, DcganEngine
+from hipgan.optim import EngineAdam
+from logger.main_logger import MainLogger
+from logger.utils import time_to_str
+from model.DCGAN import weights_init
+from train.trainer import Trainer
+from utils import require_gpu
+
+EVAL_EVERY, LOG_EVERY = 500, 100          # train/dcgan_trainer.py:198,191
+
+
+def _make_grid(images, nrow=8, padding=2, normalize=True):
+    """Minimal stand-in for torchvision.utils.make_grid (absent in this image): [N,3,H,W] -> [3,H',W']."""
+    x = images.detach().float().cpu()
+    if normalize:
+        lo, hi = float(x.min()), float(x.max())
+        x = (x - lo) / max(hi - lo, 1e-5)
+    n, c, h, w = x.shape
+    ncol = min(nrow, n)
+    nr = (n + ncol - 1) // ncol
+    grid = torch.zeros(c, nr * (h + padding) + padding, ncol * (w + padding) + padding)
+    for i in range(n):
+        r, q = divmod(i, ncol)
+        grid[:, padding + r * (h + padding):padding + r * (h + padding) + h,
+             padding + q * (w + padding):padding + q * (w + padding) + w] = x[i]
+    return grid
+
+
+def _save_png(path, chw, title=None):
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        plt.clf()
+        plt.axis("off")
+        if title:
+            plt.title(title)
+        plt.imshow(np.transpose(chw.numpy(), (1, 2, 0)))
+        plt.savefig(path)
+        plt.close("all")
+    except Exception as e:          # plotting is cosmetic; never take the run down
+        MainLogger().warning(f"could not write {path}: {e}")
+
+
+class DCGANTrainer(Trainer):
+    def __init__(self, args: argparse.Namespace, model_g: nn.Module, model_d: nn.Module, data_pre, prec=None):
+        self.logger = MainLogger(args)
+        self.device = require_gpu("DCGANTrainer")
+        self.epoch = args.epoch
+        self.max_lr = args.max_learning_rate
+        self.lambda_gp = 10.0
+        self.prec = prec or os.environ.get("JCKGAN_PREC", "bf16")
+
+        self.model_g = model_g.to(self.device)
+        self.model_d = model_d.to(self.device)
+        n_g = sum(p.numel() for p in self.model_g.parameters())
+        n_d = sum(p.numel() for p in self.model_d.parameters())
+        self.logger.debug(f"Generator: {n_g} parameters\n{self.model_g}")
+        self.logger.debug(f"Discriminator: {n_d} parameters\n{self.model_d}")
+        self.model_g.apply(weights_init)
+        self.model_d.apply(weights_init)
+        self.model_g.prec = self.model_d.prec = self.prec
+
+        self.data_pre = data_pre
+        self.train_loader, metric_loader = self.data_pre.get_data_loader()
+        self.metric = self._make_metrics(metric_loader)
+
+        # data parallel: identical initial weights on every rank, gradients all-reduced per step
+        self.world, self.rank = 1, 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world, self.rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        self.batch_size = int(getattr(args, "batch_size", 128))
+        self.engine = DcganEngine(batch=self.batch_size, prec=self.prec, device=self.device)
+        self.engine.adopt_modules(self.model_g, self.model_d)
+        if self.world > 1:
+            for key in ("g_params", "d_params", "g_bn", "d_bn"):
+                torch.distributed.broadcast(self.engine.arenas[key], src=0)
+            self.engine.mark_weights_changed()
+        self._tail_engines = {}
+        self.reducer = GradReducer(self.world) if self.world > 1 else None
+
+        self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
+        self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
+        self.criterion = nn.BCELoss()       # kept for API parity; the step uses the fused head kernel (same -100 clamp)
+
+        datetime_now = args.model_path if getattr(args, "model_path", "") != "" else datetime.now().strftime("%Y%m%d_%H%M%S")
+        self.model_save_path = os.path.join(".", "save", "dcgan", datetime_now)
+        os.makedirs(self.model_save_path, exist_ok=True)
+        self.logger.debug(f"save path: {self.model_save_path}")
+
+    # ------------------------------------------------------------------------------------------------------
+    def _make_metrics(self, metric_loader):
+        try:
+            from metrics import Metrics
+            return Metrics(metric_loader)
+        except Exception as e:
+            self.logger.warning(f"Inception-score / FID evaluation disabled: {e}")
+            return None
+
+    def _engine_for(self, b):
+        if b == self.batch_size:
+            return self.engine
+        if b not in self._tail_engines:
+            self._tail_engines[b] = DcganEngine(batch=b, share=self.engine)
+        return self._tail_engines[b]
+
+    # ------------------------------------------------------------------------------------------------------
+    def save_model(self, typ, iters, value, images):
+        if self.rank != 0:
+            return
+        save_path = os.path.join(self.model_save_path, typ)
+        os.makedirs(save_path, exist_ok=True)
+        for filename in os.listdir(save_path):
+            fp = os.path.join(save_path, filename)
+            if os.path.isfile(fp) and filename.endswith(".pt"):
+                os.remove(fp)
+        torch.save({"model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
+                    "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
+                    "optimizer_g": self.optimizer_g.state_dict(),
+                    "optimizer_d": self.optimizer_d.state_dict()},
+                   os.path.join(save_path, f"{iters}_{value:.04f}.pt"))
+        _save_png(os.path.join(save_path, f"{iters}_fake_image.png"), _make_grid(images, padding=2, normalize=True), "fake images")
+        self.logger.debug(f"{iters} model save")
+
+    def load_model(self, path):
+        """Resume from a checkpoint written by save_model() or by the reference (its load_model is commented out)."""
+        saved = torch.load(path, map_location="cpu", weights_only=False)
+        self.model_g.load_state_dict(saved["model_g"])
+        self.model_d.load_state_dict(saved["model_d"])
+        self.optimizer_g.load_state_dict(saved["optimizer_g"])
+        self.optimizer_d.load_state_dict(saved["optimizer_d"])
+        self.engine.mark_weights_changed()
+
+    def compute_gradient_penalty(self, real_data, fake_data):
+        """Stand-alone value of the penalty (reference :110-127) through the autograd Functions of the HIP path."""
+        alpha = torch.rand(real_data.size(0), 1, 1, 1, device=self.device)
+        inter = (alpha * real_data + ((1 - alpha) * fake_data)).detach().requires_grad_(True)
+        d_inter = self.model_d(inter)
+        grads = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=torch.ones_like(d_inter))[0]
+        grads = grads.view(grads.size(0), -1)
+        return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+
+    # ------------------------------------------------------------------------------------------------------
+    def _evaluate(self, fixed_noise, iters, best):
+        fake = self.engine.sample(fixed_noise)                      # train-mode BN, like the reference (:199-200)
+        if self.metric is None:
+            self.save_model("latest", iters, 0.0, fake.cpu())
+            return
+        fake = 0.5 * fake + 0.5
+        fake = torch.nn.functional.interpolate(fake, size=[299, 299], mode="bilinear", align_corners=False)
+        mean = torch.tensor([0.485, 0.456, 0.406], device=fake.device).view(1, 3, 1, 1)
+        std = torch.tensor([0.229, 0.224, 0.225], device=fake.device).view(1, 3, 1, 1)
+        fake = ((fake - mean) / std).cpu()
+        loader = torch.utils.data.DataLoader(fake, batch_size=64)
+        inception_score = self.metric.inception_score(loader)
+        fid = self.metric.fid(torch.utils.data.DataLoader(fake, batch_size=64))
+        self.logger.debug(f"inception score: {inception_score}\tfid: {fid}")
+        if best["fid"] > fid:
+            best["fid"] = fid
+            self.logger.debug(f"{iters} lowest fid")
+            self.save_model("fid", iters, fid, fake)
+        if best["is"] < inception_score:
+            best["is"] = inception_score
+            self.logger.debug(f"{iters} highest is")
+            self.save_model("is", iters, inception_score, fake)
+
+    def train(self):
+        loader = self.train_loader
+        n_iter = self.epoch * len(loader)
+        fixed_noise = torch.randn(64, 100, 1, 1, device=self.device)
+        best = {"fid": 1e10, "is": 0}
+        if self.rank == 0:
+            real_batch = next(iter(loader))
+            _save_png(os.path.join(self.model_save_path, "real_image.png"),
+                      _make_grid(real_batch[0][:64], padding=5, normalize=True), "real images")
+        history = torch.zeros(max(n_iter, 1), len(SCALAR_NAMES), device=self.device)     # every step's scalars, on the device
+        reduce = self.reducer.start if self.reducer else None
+        start = time.time()
+        self.logger.debug("train start")
+        iters = 0
+        for epoch in range(self.epoch):
+            for i, data in enumerate(loader):
+                real = data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
+                eng = self._engine_for(real.size(0))
+                eng.step_async(real, None, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
+                history[iters].copy_(eng.scalars_view(), non_blocking=True)
+                if i % LOG_EVERY == 0:
+                    s = eng.scalars()                                # the only host sync of the iteration
+                    self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
+                                      + f"\tD(x): {s['d_x']:.4f}\tD(G(z)): {s['d_gz1']:.4f} / {s['d_gz2']:.4f}")
+                if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
+                    self._evaluate(fixed_noise, iters, best)
+                iters += 1
+        torch.cuda.synchronize()
+        end = time.time()
+        self.logger.debug(f"train finish\ttiem: {time_to_str(end - start)}")
+        hist = history[:iters].cpu()
+        self.losses_d, self.losses_g = hist[:, 0].tolist(), hist[:, 1].tolist()
+        if self.rank == 0:
+            self._plot_losses()
+        return self.losses_d, self.losses_g
+
+    def _plot_losses(self):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            plt.clf()
+            plt.figure(figsize=(8, 6))
+            x = range(1, len(self.losses_g) + 1)
+            plt.plot(x, self.losses_d, label="Discriminator Loss")
+            plt.plot(x, self.losses_g, label="Generator Loss")
+            plt.title("Discriminator and Generator Loss")
+            plt.xlabel("Iterations")
+            plt.ylabel("Loss")
+            plt.legend()
+            plt.savefig(os.path.join(self.model_save_path, "loss.png"))
+            plt.close("all")
+        except Exception as e:
+            self.logger.warning(f"could not write loss.png: {e}")

@@ -1,0 +1,82 @@
+"""Two engine replicas as two processes on ONE GPU (gloo carries the CUDA tensors; RCCL needs one device per rank and is
+exercised by bench.py on the 8-GPU node): the native step with gradient exchange reproduces the N-replica CPU oracle."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _noise(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"n1": torch.randn(B, 3, 64, 64, generator=g), "z": torch.randn(B, 100, 1, 1, generator=g),
+            "n2": torch.randn(B, 3, 64, 64, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g)}
+
+
+def _worker(rank, world, port, q, steps, B):
+    for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hipgan.dist import GradReducer
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images
+    torch.manual_seed(12345)
+    g, d = build_params("dcgan")
+    eng = DcganEngine(batch=B, prec="f32", device="cuda:0")
+    eng.load_state(g, d)
+    red = GradReducer(world)
+    imgs = synth_images(B * world * steps)
+    out = []
+    for s in range(steps):
+        real = imgs[(s * world + rank) * B:(s * world + rank + 1) * B].cuda()
+        nz = {k: v.cuda() for k, v in _noise(B, 1000 + 10 * s + rank).items()}
+        eng.step_async(real, nz, 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
+        out.append(eng.scalars())
+    gs, ds = eng.state_dicts()
+    np_ = lambda sd: {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}      # numpy: no shared-memory handles
+    q.put((rank, out, np_(gs), np_(ds)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_replicas_match_ddp_oracle():
+    from oracle.gan_oracle import GanOracle, ddp_step
+    from util import synth_images
+    world, B, steps = 2, 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, steps, B)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, out, gs, ds = q.get(timeout=600)
+        got[r] = (out, {k: torch.from_numpy(v) for k, v in gs.items()}, {k: torch.from_numpy(v) for k, v in ds.items()})
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    reps = [GanOracle("dcgan", lr=2e-4, seed=12345) for _ in range(world)]
+    imgs = synth_images(B * world * steps)
+    for s in range(steps):
+        res = ddp_step(reps, [imgs[(s * world + r) * B:(s * world + r + 1) * B] for r in range(world)], None,
+                       [_noise(B, 1000 + 10 * s + r) for r in range(world)])
+        for r in range(world):
+            for k in ("loss_d", "loss_g", "gp"):
+                a, b = got[r][0][s][k], res[r][k]
+                assert abs(a - b) <= 1e-3 * abs(b), (s, r, k, a, b)
+    for r in range(world):
+        for k, v in reps[r].g.items():
+            if v.dtype == torch.float32 and "running" not in k:
+                e = (got[r][1][k] - v).norm() / (v.norm() + 1e-30)
+                assert e < 2e-3, ("g", r, k, float(e))
+    for k, v in got[0][1].items():
+        if v.dtype == torch.float32 and "running" not in k:
+            assert torch.equal(v, got[1][1][k]), k          # replicas in lock-step

@@ -1,0 +1,136 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute calls into the library)."""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import load_golden, rel
+
+
+def test_cli_flags_match_reference():
+    import main
+    a = main.get_arg_parse([])
+    # reference main.py:43-57: names and defaults
+    assert vars(a) == {"test": 0, "model_path": "", "log_file": 1, "model": main.ModelEnum.DCGAN, "num_worker": 0,
+                       "batch_size": 128, "epoch": 100, "max_learning_rate": 0.1, "min_learning_rate": 1e-4,
+                       "weight_decay": 5e-4, "nesterov": 1}
+    b = main.get_arg_parse(["-m", "CGAN", "-b", "256", "-e", "3", "-mlr", "0.0002", "-pm", "run1", "-lf", "0", "-w", "2"])
+    assert str(b.model) == "CGAN" and b.batch_size == 256 and b.epoch == 3 and b.max_learning_rate == 2e-4
+    assert b.model_path == "run1" and b.log_file == 0 and b.num_worker == 2
+    from change_randomseed import RANDOMSEED
+    assert RANDOMSEED == 12345
+
+
+def test_modules_have_reference_state_dict():
+    from model import DCGAN
+    gold = load_golden("dcgan_steps")["B8"]
+    g, d = DCGAN.Generator(), DCGAN.Discriminator()
+    assert list(g.state_dict().keys()) == gold["ckpt_g_keys"]
+    assert list(d.state_dict().keys()) == gold["ckpt_d_keys"]
+    assert sum(p.numel() for p in g.parameters()) == 3576704 and sum(p.numel() for p in d.parameters()) == 2765696
+    from train.trainer import Trainer
+    from train.dcgan_trainer import DCGANTrainer
+    assert issubclass(DCGANTrainer, Trainer)
+    with pytest.raises(TypeError):
+        Trainer()
+
+
+def test_trainer_refuses_cpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hipgan import JckError
+    from model import DCGAN
+    from train.dcgan_trainer import DCGANTrainer
+    args = argparse.Namespace(epoch=1, max_learning_rate=2e-4, model_path="x", log_file=0, save_path="/tmp/x", batch_size=4,
+                              num_worker=0)
+    with pytest.raises(JckError):
+        DCGANTrainer(args, DCGAN.Generator(), DCGAN.Discriminator(), None)
+
+
+def test_metrics_arithmetic_matches_reference_golden():
+    import metrics as M
+    gold = load_golden("metrics")
+    rng = np.random.default_rng(7)
+    real = (1.5 * rng.standard_normal((5000, 100)) + 0.2).astype(np.float32)
+    fake = rng.standard_normal((1000, 100)).astype(np.float32)
+    real_targets = rng.integers(0, 100, size=5000).tolist()
+    src = types.SimpleNamespace(targets=real_targets)
+    m = M.Metrics(src, real_features=real)
+    ft = torch.from_numpy(fake)
+    dl = torch.utils.data.DataLoader(ft, batch_size=128, shuffle=False)
+    assert rel(m.inception_score(dl), gold["is"]) < 1e-5
+    assert rel(m.fid(dl), gold["fid"]) < 1e-8
+    assert rel(m.intra_fid(ft), gold["intra_fid"]) < 1e-8
+    dl64 = torch.utils.data.DataLoader(ft[:64], batch_size=64)
+    assert rel(m.inception_score(dl64), gold["is64"]) < 1e-5
+    assert rel(m.fid(dl64), gold["fid64"]) < 1e-7
+    # the DCGAN path of the reference hands Metrics a source without .targets (its defect): accepted here
+    M.Metrics(object(), real_features=real).fid(dl)
+
+
+def test_metrics_unavailable_without_weights():
+    import metrics as M
+    with pytest.raises(M.MetricsUnavailable):
+        M.Metrics(types.SimpleNamespace(targets=[0]))
+
+
+def test_engine_adam_state_dict_is_torch_compatible():
+    """A checkpoint's optimizer entry must load into torch.optim.Adam built as the reference builds it - and back."""
+    from hipgan.optim import EngineAdam
+    from model import DCGAN
+    g = DCGAN.Generator()
+    views_m = {k: torch.full_like(p, 0.25) for k, p in g.named_parameters()}
+    views_v = {k: torch.full_like(p, 0.5) for k, p in g.named_parameters()}
+    eng = types.SimpleNamespace(t=7, named_views=lambda tag, what: views_m if what == "m" else views_v,
+                                arenas={"g_grads": torch.zeros(1)})
+    opt = EngineAdam(eng, "g", g.named_parameters(), 2e-4, betas=[0.5, 0.999])
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(g.parameters(), lr=0.1, betas=[0.5, 0.999])
+    ref.load_state_dict(sd)                                  # raises if the structure is not torch's
+    assert ref.param_groups[0]["lr"] == 2e-4 and tuple(ref.param_groups[0]["betas"]) == (0.5, 0.999)
+    st = ref.state[next(iter(g.parameters()))]
+    assert float(st["step"]) == 7 and float(st["exp_avg"].flatten()[0]) == 0.25 and float(st["exp_avg_sq"].flatten()[0]) == 0.5
+    # and the reverse: a torch-written state dict loads into the engine-backed optimiser
+    for p in g.parameters():
+        p.grad = torch.ones_like(p)
+    ref.step()
+    sd2 = ref.state_dict()
+    opt.load_state_dict(sd2)
+    assert eng.t == 8
+    assert torch.equal(views_m["conv1.weight"], sd2["state"][0]["exp_avg"])
+    assert set(sd["param_groups"][0].keys()) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+
+
+def test_synthetic_preprocessor_duck_type(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from logger.main_logger import MainLogger
+    MainLogger._instance, MainLogger._initialized = None, False
+    from preprocess.dcgan_data_preprocessor import DCGANDataPreprocessor
+    args = argparse.Namespace(batch_size=16, num_worker=0, log_file=0, save_path=str(tmp_path))
+    pre = DCGANDataPreprocessor(args, synthetic_size=40)
+    pre.transform_data()
+    loader, metric_src = pre.get_data_loader()
+    assert len(loader) == 3 and hasattr(metric_src, "targets") and len(metric_src.targets) == 40
+    batch = next(iter(loader))
+    assert batch[0].shape == (16, 3, 64, 64) and batch[0].dtype == torch.float32
+    assert float(batch[0].min()) >= -1.0 and float(batch[0].max()) <= 1.0
+    sizes = [b[0].shape[0] for b in loader]
+    assert sorted(sizes) == [8, 16, 16]                      # ragged last batch, like CIFAR's 50000 % 128
+
+
+def test_logger_and_time_format(tmp_path):
+    from logger.main_logger import MainLogger
+    from logger.utils import time_to_str
+    MainLogger._instance, MainLogger._initialized = None, False
+    a = MainLogger(argparse.Namespace(log_file=1, save_path=str(tmp_path)))
+    assert MainLogger(None) is a
+    a.debug("hello")
+    assert any(f.endswith(".log") for f in os.listdir(tmp_path))
+    assert time_to_str(3725.5) == "1.0h 2.0m 5.5"
+    import logging
+    logging.getLogger("main").handlers.clear()
+    MainLogger._instance, MainLogger._initialized = None, False
