@@ -46,6 +46,8 @@ class DcganEngine:
         if not torch.cuda.is_available():
             raise JckError("DcganEngine needs a GPU: the HIP path has no CPU fallback")
         self.device = torch.device(device) if share is None else share.device
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.prec = _PREC[prec] if share is None else share.prec
         self.batch = batch
@@ -244,14 +246,18 @@ class DcganEngine:
         return self.scalars()
 
     def sample(self, z):
-        """G(z) with train-mode BatchNorm (train/dcgan_trainer.py:199-200) -> NCHW fp32 on the device."""
+        """G(z) with train-mode BatchNorm (train/dcgan_trainer.py:199-200) -> NCHW fp32 on the device.  The whole z is ONE
+        BatchNorm batch (statistics and running-stat update over all n samples, as in the reference), so n <= batch."""
         n = z.shape[0]
+        if n > self.batch:
+            raise JckError(f"sample: {n} latent vectors exceed this engine's batch {self.batch}; bind an engine with batch >= n "
+                           f"(DcganEngine(batch=n, share=engine))")
         if self._packed_version != self._shared["version"]:
             self.repack()
         out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
-        for i in range(0, n, self.batch):
-            zc = z[i:i + self.batch].to(self.device, torch.float32).contiguous().view(-1, 100)
-            lib.jck_engine_sample(self._h, zc, zc.shape[0], out[i:i + zc.shape[0]], cur_stream())
+        zc = z.to(self.device, torch.float32).contiguous().view(-1, 100)
+        lib.jck_engine_sample(self._h, zc, n, out, cur_stream())
+        self._keep_z = zc
         return out
 
     def tensor(self, name):

@@ -64,7 +64,10 @@ def _save_png(path, chw, title=None):
 
 
 class DCGANTrainer(Trainer):
-    def __init__(self, args: argparse.Namespace, model_g: nn.Module, model_d: nn.Module, data_pre, prec=None):
+    def __init__(self, args: argparse.Namespace, model_g: nn.Module, model_d: nn.Module, data_pre, prec=None, host_rng=None):
+        """prec: "bf16" (fast, default) or "f32" (exact-fp32 parity path); env JCKGAN_PREC.
+        host_rng: draw every random tensor from the CPU generator in the reference's order and upload it (bit-identical
+        noise to a CPU run of the reference; env JCKGAN_HOST_RNG=1).  Default: Philox on the device."""
         self.logger = MainLogger(args)
         self.device = require_gpu("DCGANTrainer")
         self.epoch = args.epoch
@@ -72,14 +75,19 @@ class DCGANTrainer(Trainer):
         self.lambda_gp = 10.0
         self.prec = prec or os.environ.get("JCKGAN_PREC", "bf16")
 
+        self.host_rng = bool(int(os.environ.get("JCKGAN_HOST_RNG", "0"))) if host_rng is None else host_rng
+        if self.host_rng:       # weights_init must consume the CPU generator, as it does in a CPU run of the reference
+            model_g.apply(weights_init)
+            model_d.apply(weights_init)
         self.model_g = model_g.to(self.device)
         self.model_d = model_d.to(self.device)
         n_g = sum(p.numel() for p in self.model_g.parameters())
         n_d = sum(p.numel() for p in self.model_d.parameters())
         self.logger.debug(f"Generator: {n_g} parameters\n{self.model_g}")
         self.logger.debug(f"Discriminator: {n_d} parameters\n{self.model_d}")
-        self.model_g.apply(weights_init)
-        self.model_d.apply(weights_init)
+        if not self.host_rng:   # reference order (train/dcgan_trainer.py:46-55): move, then initialise on the device
+            self.model_g.apply(weights_init)
+            self.model_d.apply(weights_init)
         self.model_g.prec = self.model_d.prec = self.prec
 
         self.data_pre = data_pre
@@ -163,7 +171,7 @@ class DCGANTrainer(Trainer):
 
     # ------------------------------------------------------------------------------------------------------
     def _evaluate(self, fixed_noise, iters, best):
-        fake = self.engine.sample(fixed_noise)                      # train-mode BN, like the reference (:199-200)
+        fake = self._engine_for(fixed_noise.size(0)).sample(fixed_noise)     # one train-mode BN batch, like the reference (:199-200)
         if self.metric is None:
             self.save_model("latest", iters, 0.0, fake.cpu())
             return
@@ -188,7 +196,7 @@ class DCGANTrainer(Trainer):
     def train(self):
         loader = self.train_loader
         n_iter = self.epoch * len(loader)
-        fixed_noise = torch.randn(64, 100, 1, 1, device=self.device)
+        fixed_noise = torch.randn(64, 100, 1, 1).to(self.device) if self.host_rng else torch.randn(64, 100, 1, 1, device=self.device)
         best = {"fid": 1e10, "is": 0}
         if self.rank == 0:
             real_batch = next(iter(loader))
@@ -203,7 +211,12 @@ class DCGANTrainer(Trainer):
             for i, data in enumerate(loader):
                 real = data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
                 eng = self._engine_for(real.size(0))
-                eng.step_async(real, None, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
+                noise = None
+                if self.host_rng:           # reference order: train/dcgan_trainer.py:160,168,171,111
+                    b = real.size(0)
+                    noise = {"n1": torch.randn(b, 3, 64, 64), "z": torch.randn(b, 100, 1, 1), "n2": torch.randn(b, 3, 64, 64),
+                             "alpha": torch.rand(b, 1, 1, 1)}
+                eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 history[iters].copy_(eng.scalars_view(), non_blocking=True)
                 if i % LOG_EVERY == 0:
                     s = eng.scalars()                                # the only host sync of the iteration

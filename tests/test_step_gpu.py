@@ -126,7 +126,7 @@ def test_free_running_golden_f32():
         assert _rel(got["loss_g"], gold["losses_g"][s]) < tol * 3, (s, got["loss_g"], gold["losses_g"][s])
         assert _rel(got["gp"], gold["step"][s]["gp"]) < tol * 3
         if s == 0 or s == 2:
-            eng.sample(fixed.cuda())        # the eval branch moves G's BN running statistics
+            DcganEngine(batch=64, share=eng).sample(fixed.cuda())        # the eval branch moves G's BN running statistics
 
 
 def test_default_lr_clamp_plateau():
@@ -147,7 +147,7 @@ def test_default_lr_clamp_plateau():
               "alpha": torch.rand(B, 1, 1, 1)}
         got = eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: v.cuda() for k, v in nz.items()}, lr=0.1)
         if s == 0:
-            eng.sample(fixed.cuda())
+            DcganEngine(batch=64, share=eng).sample(fixed.cuda())
         assert _rel(got["loss_d"], gold["losses_d"][s]) < 1e-3, (s, got)
         assert _rel(got["loss_g"], gold["losses_g"][s]) < 1e-3, (s, got)
 
@@ -159,9 +159,15 @@ def test_sample_matches_oracle():
     eng = DcganEngine(batch=16, prec="f32")
     eng.load_state(orc.g, orc.d)
     z = torch.randn(40, 100, 1, 1, generator=torch.Generator().manual_seed(3))
-    got = eng.sample(z.cuda()).cpu()
-    ref = torch.cat([orc.sample(z[i:i + 16]) for i in range(0, 40, 16)])
+    with pytest.raises(Exception):
+        eng.sample(z.cuda())                       # 40 > batch: one BN batch cannot be split silently
+    big = DcganEngine(batch=40, share=eng)         # second workspace geometry on the same state
+    got = big.sample(z.cuda()).cpu()
+    ref = orc.sample(z)
     assert (got - ref).abs().max().item() < 2e-4
+    got2 = eng.sample(z[:12].cuda()).cpu()
+    assert (got2 - orc.sample(z[:12])).abs().max().item() < 2e-4
+    assert int(eng.named_views("g")["norm1.num_batches_tracked"]) == 2
 
 
 def test_bf16_trajectory_statistics():
