@@ -39,6 +39,29 @@ def step_flops_per_image(dead_wgrad=False):
     return 2 * mac
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json: rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as the gfx950 guide prescribes).  rocprofv3
+    cannot run inside the timed process, so the number is read back from the newest committed profile; None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        tr = json.load(f)
+    m = re.match(r"(igemm|wgrad)<(bf16|f32),(\d+),(\d+)(,img)?>", kernel)
+    if not m:
+        return None
+    kind, prec, a, b, img = m.groups()
+    pat = f"{kind}_kernel<{'PrecBf16' if prec == 'bf16' else 'PrecF32'}, {a}, {b}, {2 if img else 1}"
+    for name, v in tr.items():
+        if pat in name:
+            return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
+                    "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
+    return None
+
+
 def cpu_baseline(batch, seconds_budget=25.0):
     """The CPU oracle (a restatement of the reference's step, pinned to it by tests/golden) timed on the host cores."""
     import torch
@@ -164,7 +187,7 @@ def main():
             d = rows[0]
             out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                               "traffic": None, "avg_launch_ms": round(d["avg_ms"], 5),
+                               "traffic": pmc_traffic(d["kernel"]), "avg_launch_ms": round(d["avg_ms"], 5),
                                "launches_per_step": d["launches_per_step"],
                                "method": "HIP events around every launch on the launch stream, 3 extra steps after the timed region"}
             out["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
