@@ -107,12 +107,52 @@ int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out,
 /* D head: logit = <a4[n], wp>, p = sigmoid (model/DCGAN.py:34), BCELoss with the -100 clamp (train/dcgan_trainer.py:64,163);
  * mode 0: ds = dLoss/dlogit for mean BCE against `target`; scal[slot_loss] += sum loss_n; mode 1: ds = p(1-p) (GP pass).
  * scal[slot_p] += sum p.  slot < 0 disables. */
-int jck_head_fwd(int prec, const void* a4, const float* wp, int B, int K, float target, int mode, float* prob, float* ds,
-                 float* scal, int slot_loss, int slot_p, void* stream);
+int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias /* device scalar or NULL */, int B, int K,
+                 float target, int mode, float* prob, float* ds, float* scal, int slot_loss, int slot_p, void* stream);
 int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int B, int K, void* g_a4, float* dwp,
                  int accumulate, void* stream);
 /* grad[1][C][4][4] (+)= dwp (packed (h,w,c) order) */
 int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream);
+
+/* ---- CGAN pieces (model/CGAN.py:79-162, train/cgan_trainer.py:173-213) ---------------------------------------------
+ * Linear layers run on the gather-GEMM kernels as plain row-major products; our activation order is NHWC, so the
+ * first permC*permHW weight columns (the flattened conv features, NCHW order in the reference, model/CGAN.py:119-120)
+ * are permuted when packing and un-permuted when the gradient is written back. */
+int jck_pack_linear(int prec, const float* w, int N, int K, int rows, int cols, int transpose, int permC, int permHW, void* wp,
+                    void* stream);
+/* out[B][NStore] = x[B][Kpad] * wp^T (+ bias); ksplit > 1: fp32 partial slabs [ksplit][B][NStore] for jck_linear_finish */
+int jck_linear_fwd(int prec, const void* x, const void* wp, const float* bias, void* out, int B, int Kpad, int N, int NStore,
+                   int ksplit, void* stream);
+/* h = sum of slabs + bias; hd = h * mask * scale (nn.Dropout, model/CGAN.py:105); h or hd may be NULL */
+int jck_linear_finish(int prec, const float* slab, int Z, const float* bias, const float* mask, float scale, void* h, void* hd,
+                      int B, int N, void* stream);
+size_t jck_linear_wgrad_ws_bytes(int B, int Kpad, int N);
+int jck_linear_wgrad(int prec, const void* gy, int ldgy, const void* x, int Kpad, float* ws, size_t ws_bytes, float* gradp,
+                     int accumulate, int B, int N, void* stream);
+int jck_unperm_linear_grad(const float* gp, int N, int K, int ldp, int permC, int permHW, float* grad, int accumulate, void* stream);
+/* label path: e = LeakyReLU(Linear(100,200)(onehot.float())) written into columns [col0, col0+NO) of cbuf (model/CGAN.py:111) */
+int jck_label_embed_fwd(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI, int NO,
+                        void* cbuf, int ld, int col0, float* pre, void* stream);
+int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope, int B,
+                        int NI, int NO, float* dW, float* db, void* stream);
+/* torch.cat([flatten(a4), e], 1) (model/CGAN.py:117-120) and its backward split */
+int jck_concat_rows(int prec, const void* a4, int K0, void* cbuf, int ld, int B, void* stream);
+int jck_split_rows(int prec, const void* gc, int ld, int K0, void* ga4, int B, void* stream);
+int jck_dropout(int prec, const void* x, const float* mask, float scale, void* y, long long n, void* stream);
+int jck_colsum(int prec, const void* g, int B, int N, int ld, float* db, void* stream);
+int jck_sum_vec(const float* x, int n, float* out, void* stream);
+/* G input [z | one-hot] (model/CGAN.py:154-155) */
+int jck_cgan_z(int prec, const float* z, const int64_t* labels, int B, int NZ, int NL, int CiPad, void* out, void* stream);
+/* back-propagated gradient penalty (train/cgan_trainer.py:200-203): u = dL/dg, second-order BatchNorm and head terms;
+ * the closed form is derived and checked against autograd in tests/test_gp_double_backward_math.py */
+int jck_gp_grad(int prec, const void* g, const float* norms, float coef, int N, int HW, void* u, void* stream);
+int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, void* stream);
+size_t jck_bn2_ws_floats(int C);
+int jck_bn2_vchain(int prec, const void* v, const void* y, const void* gy, const float* aux, const float* s1, const float* gamma,
+                   float slope, float* ws, void* u, void* xdir, float* dgamma, long long rows, int C, void* stream);
+int jck_bn2_reverse(int prec, const void* ua, const void* y, const void* xdir, const float* aux, const float* gamma,
+                    const float* vsums, float slope, float* ws, void* uy, float* dgamma, float* dbeta, long long rows, int C,
+                    void* stream);
 
 /* ---- optimiser (torch.optim.Adam as built at train/dcgan_trainer.py:61-62) over a flat fp32 arena ---------- */
 int jck_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
@@ -120,7 +160,7 @@ int jck_adam(float* p, const float* g, float* m, float* v, long long n, double l
 
 /* ---- whole-step engine (train/dcgan_trainer.py:155-189 as one native schedule) --------------------------- */
 typedef struct jck_engine jck_engine;
-/* family 0 = DCGAN.  Layout queries let the host build flat parameter arenas with the reference's state-dict order. */
+/* family 0 = DCGAN, 1 = CGAN.  Layout queries let the host build flat parameter arenas with the reference's state-dict order. */
 int jck_engine_create(jck_engine** out, int family, int prec, int batch);
 void jck_engine_destroy(jck_engine*);
 int jck_engine_num_tensors(int family, int net /*0=G,1=D*/);
@@ -156,12 +196,15 @@ typedef struct jck_step_inputs {
   float lr;
   float grad_scale;        /* 1/world_size when grads were SUM-all-reduced, else 1 */
   int step;                /* 1-based optimiser step (Adam bias correction) */
+  /* family 1 (CGAN) only: */
+  const int64_t* labels;   /* [B,100] one-hot int64 (preprocess/cgan_data_preprocessor.py:11-16) */
+  const float* drop_mask[4]; /* [B,256] 0/1 keep masks of nn.Dropout(0.25) for the 4 D passes (real, fake, GP, G phase) */
 } jck_step_inputs;
 int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
 const float* jck_engine_scalars(const jck_engine*);
 /* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */
-int jck_engine_sample(jck_engine*, const float* z, int n, float* out_nchw, void* stream);
+int jck_engine_sample(jck_engine*, const float* z, const int64_t* labels /* family 1 */, int n, float* out_nchw, void* stream);
 /* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */
 const void* jck_engine_tensor(const jck_engine*, const char* name, long long* numel);
 

@@ -36,10 +36,12 @@ void add_bn(NetLayout& L, const char* wn, const char* bn, const char* rm, const 
 // channel plan (model/DCGAN.py:10-26, :42-58)
 const int D_CS[4] = {64, 128, 256, 512}, D_CB[4] = {3, 64, 128, 256}, D_HB[4] = {64, 32, 16, 8};
 const int G_CS[4] = {512, 256, 128, 64}, G_CB[4] = {256, 128, 64, 3}, G_HS[4] = {4, 8, 16, 32};   // conv2..conv5
-const int G_C1 = 512, Z_DIM = 100, Z_PAD = 128;
+const int G_C1 = 512;
+const int N_CLASS = 100, EMB = 200, L1_OUT = 256, FEAT = 8192, L1_K = FEAT + EMB, L1_KPAD = 8448, L1_KSPLIT = 12;   // model/CGAN.py:83,104
+inline int z_dim(int family) { return family == 1 ? 200 : 100; }      // model/CGAN.py:132: ConvTranspose2d(200, 512)
+inline int z_pad(int family) { return family == 1 ? 256 : 128; }
 
 NetLayout make_layout(int family, int net) {
-  (void)family;
   NetLayout L;
   static const char* CW[5] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight"};
   static const char* NW[4] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight"};
@@ -47,18 +49,29 @@ NetLayout make_layout(int family, int net) {
   static const char* RM[4] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean"};
   static const char* RV[4] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var"};
   if (net == 0) {
-    add_param(L, CW[0], Z_DIM, G_C1, 4, 4);
+    add_param(L, CW[0], z_dim(family), G_C1, 4, 4);
     add_bn(L, NW[0], NB[0], RM[0], RV[0], G_C1);
     for (int i = 0; i < 4; ++i) {
       add_param(L, CW[i + 1], G_CS[i], G_CB[i], 4, 4);
       if (i < 3) add_bn(L, NW[i + 1], NB[i + 1], RM[i + 1], RV[i + 1], G_CB[i]);
     }
   } else {
+    if (family == 1) {                                  // model/CGAN.py:83: registered first
+      add_param(L, "label_embedding.weight", EMB, N_CLASS, 1, 1);
+      add_param(L, "label_embedding.bias", EMB, 1, 1, 1);
+    }
     for (int i = 0; i < 4; ++i) {
       add_param(L, CW[i], D_CS[i], D_CB[i], 4, 4);
       add_bn(L, NW[i], NB[i], RM[i], RV[i], D_CS[i]);
     }
-    add_param(L, CW[4], 1, 512, 4, 4);
+    if (family == 0) {
+      add_param(L, CW[4], 1, 512, 4, 4);
+    } else {                                            // model/CGAN.py:104,106
+      add_param(L, "linear1.weight", L1_OUT, L1_K, 1, 1);
+      add_param(L, "linear1.bias", L1_OUT, 1, 1, 1);
+      add_param(L, "linear2.weight", 1, L1_OUT, 1, 1);
+      add_param(L, "linear2.bias", 1, 1, 1, 1);
+    }
   }
   return L;
 }
@@ -106,6 +119,14 @@ struct jck_engine {
   BnBuf d_bn[4], g_bn[4];
   float *acc, *scal_out, *prob, *ds, *norms;
   float* wg_ws; size_t wg_ws_bytes;
+  // family 1 (CGAN): Linear head, label path, second-order penalty buffers
+  void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
+  void *cbuf, *cbuf2;                 // [B][8448] concat(flatten(a4), e) ; [u4 | 0]
+  void *h_pre, *h_drop, *g_h, *g_hd, *gh_b1, *ughd, *gc;    // [B][256] x6, [B][8448]
+  float *pre_e, *l1_slab, *gw1p, *rs, *prob_gp;
+  void *d_v[4], *d_xdir[4], *d_u0;
+  float* bn2_ws[4]; float* bn2_ws_rev;
+  const int64_t* cur_labels = nullptr;
 
   void carve(unsigned char* base) {
     Carver c; c.base = base;
@@ -116,7 +137,7 @@ struct jck_engine {
       d_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(D_CB[i]) * 4 * D_CS[i]));
     }
     d_head_wp = c.take<float>(8192); d_head_dwp = c.take<float>(8192);
-    g1_w = c.take<unsigned char>(bytes((size_t)16 * G_C1 * Z_PAD));
+    g1_w = c.take<unsigned char>(bytes((size_t)16 * G_C1 * z_pad(family)));
     for (int i = 0; i < 4; ++i) {
       g_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(G_CB[i]) * 4 * G_CS[i]));
       g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i])));
@@ -127,7 +148,7 @@ struct jck_engine {
       d_y[i] = c.take<unsigned char>(bytes(n)); d_a[i] = c.take<unsigned char>(bytes(n)); d_g[i] = c.take<unsigned char>(bytes(n));
     }
     d_gx = c.take<unsigned char>(bytes(img));
-    g_z = c.take<unsigned char>(bytes((size_t)B * Z_PAD));
+    g_z = c.take<unsigned char>(bytes((size_t)B * z_pad(family)));
     // G layer i (0..3): output of conv(i+1) = [B, h, h, C] with (h, C) = (4,512), (8,256), (16,128), (32,64)
     for (int i = 0; i < 4; ++i) {
       const int h = 4 << i, C = 512 >> i;
@@ -163,9 +184,27 @@ struct jck_engine {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, G_HS[i] * 2, G_HS[i] * 2, G_CB[i], G_CS[i]));
     }
-    w = std::max(w, jck_g1_wgrad_ws_bytes(B, Z_PAD, G_C1));
+    w = std::max(w, jck_g1_wgrad_ws_bytes(B, z_pad(family), G_C1));
+    if (family == 1) w = std::max(w, jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT));
     wg_ws_bytes = w;
     wg_ws = c.take<float>(w / 4);
+    if (family == 1) {
+      l1_w = c.take<unsigned char>(bytes((size_t)L1_OUT * L1_KPAD)); l1_wT = c.take<unsigned char>(bytes((size_t)L1_KPAD * L1_OUT));
+      cbuf = c.take<unsigned char>(bytes((size_t)B * L1_KPAD)); cbuf2 = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
+      h_pre = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); h_drop = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
+      g_h = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); g_hd = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
+      gh_b1 = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); ughd = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
+      gc = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
+      pre_e = c.take<float>((size_t)B * EMB); l1_slab = c.take<float>((size_t)L1_KSPLIT * B * L1_OUT);
+      gw1p = c.take<float>((size_t)L1_OUT * L1_KPAD); rs = c.take<float>(B); prob_gp = c.take<float>(B);
+      for (int i = 0; i < 4; ++i) {
+        const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+        d_v[i] = c.take<unsigned char>(bytes(n)); d_xdir[i] = c.take<unsigned char>(bytes(n));
+        bn2_ws[i] = c.take<float>(jck_bn2_ws_floats(D_CS[i]));
+      }
+      bn2_ws_rev = c.take<float>(jck_bn2_ws_floats(512));
+      d_u0 = c.take<unsigned char>(bytes(img));
+    }
     ws_bytes = c.off;
   }
 
@@ -180,7 +219,7 @@ static const char* NAMES_RV[4] = {"norm1.running_var", "norm2.running_var", "nor
 
 extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int batch) {
   if (!out) JCK_FAIL(JCK_E_ARG, "null out");
-  if (family != 0) JCK_FAIL(JCK_E_ARG, "only family 0 (DCGAN) has a native step engine in this build");
+  if (family != 0 && family != 1) JCK_FAIL(JCK_E_ARG, "family must be 0 (DCGAN) or 1 (CGAN)");
   if (prec != JCK_PREC_BF16 && prec != JCK_PREC_F32) JCK_FAIL(JCK_E_ARG, "bad prec");
   if (batch < 1 || batch > 8192) JCK_FAIL(JCK_E_ARG, "batch must be in [1, 8192]");
   jck_engine* e = new jck_engine();
@@ -231,9 +270,15 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
       JCK_TRY(jck_pack_down(e->prec, w, D_CS[i], D_CB[i], e->d_down[i], stream));
       JCK_TRY(jck_pack_up(e->prec, w, D_CS[i], D_CB[i], e->d_up[i], stream));
     }
-    JCK_TRY(jck_pack_head(e->P(e->LD, e->dp, NAMES_CW[4]), 512, e->d_head_wp, stream));
+    if (e->family == 0) {
+      JCK_TRY(jck_pack_head(e->P(e->LD, e->dp, NAMES_CW[4]), 512, e->d_head_wp, stream));
+    } else {
+      const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
+      JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
+      JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
+    }
   } else {
-    JCK_TRY(jck_pack_g1(e->prec, e->P(e->LG, e->gp, NAMES_CW[0]), Z_DIM, G_C1, Z_PAD, e->g1_w, stream));
+    JCK_TRY(jck_pack_g1(e->prec, e->P(e->LG, e->gp, NAMES_CW[0]), z_dim(e->family), G_C1, z_pad(e->family), e->g1_w, stream));
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
       JCK_TRY(jck_pack_up(e->prec, w, G_CS[i], G_CB[i], e->g_up[i], stream));
@@ -248,7 +293,7 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
 // ---------------------------------------------------------------------------------------------------------
 static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
-static int d_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
+static int d_convs_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
   const void* in = x_in;
   for (int i = 0; i < 4; ++i) {
     const int hb = D_HB[i], cs = D_CS[i];
@@ -263,9 +308,55 @@ static int d_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
   return JCK_OK;
 }
 
-static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, bool want_xgrad, hipStream_t st) {
-  JCK_TRY(jck_head_bwd(e->prec, e->ds, e->d_head_wp, e->d_a[3], B, 8192, e->d_g[3], want_wgrad ? e->d_head_dwp : nullptr, 0, st));
-  if (want_wgrad) JCK_TRY(jck_head_unpack_grad(e->d_head_dwp, 512, e->P(e->LD, e->dg, NAMES_CW[4]), 1, st));
+// D forward up to (not including) the sigmoid head.  family 1: concat + Linear(8392,256) + Dropout (model/CGAN.py:117-122)
+static int d_forward(jck_engine* e, const void* x_in, int B, const float* drop_mask, hipStream_t st) {
+  JCK_TRY(d_convs_forward(e, x_in, B, st));
+  if (e->family == 1) {
+    if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
+    JCK_TRY(jck_concat_rows(e->prec, e->d_a[3], FEAT, e->cbuf, L1_KPAD, B, st));
+    JCK_TRY(jck_label_embed_fwd(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
+                                e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, FEAT, e->pre_e, st));
+    JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
+    JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
+                              e->h_drop, B, L1_OUT, st));
+  }
+  return JCK_OK;
+}
+
+// sigmoid head + loss (mode 0) or + d(sum p)/dlogit (mode 1); fills e->prob / e->ds
+static int d_head(jck_engine* e, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
+  if (e->family == 0)
+    return jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, e->prob, e->ds, e->acc, slot_loss, slot_p, st);
+  return jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, target,
+                      mode, e->prob, e->ds, e->acc, slot_loss, slot_p, st);
+}
+
+// head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
+static int d_head_backward(jck_engine* e, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
+  if (e->family == 0) {
+    JCK_TRY(jck_head_bwd(e->prec, ds, e->d_head_wp, e->d_a[3], B, FEAT, ga4_out, want_wgrad ? e->d_head_dwp : nullptr, 0, st));
+    if (want_wgrad) JCK_TRY(jck_head_unpack_grad(e->d_head_dwp, 512, e->P(e->LD, e->dg, NAMES_CW[4]), 1, st));
+    return JCK_OK;
+  }
+  // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds
+  JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), e->h_drop, B, L1_OUT, e->g_hd,
+                       want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, st));
+  if (want_wgrad) JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), st));
+  JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)B * L1_OUT, st));
+  if (want_wgrad) {
+    JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
+    JCK_TRY(jck_colsum(e->prec, e->g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
+  }
+  JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
+  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, FEAT, ga4_out, B, st));
+  if (want_wgrad)
+    JCK_TRY(jck_label_embed_bwd(e->prec, e->gc, L1_KPAD, FEAT, e->pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
+                                e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), st));
+  return JCK_OK;
+}
+
+static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask, hipStream_t st) {
+  JCK_TRY(d_head_backward(e, e->ds, B, want_wgrad, drop_mask, e->d_g[3], st));
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
@@ -283,17 +374,65 @@ static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, b
   return JCK_OK;
 }
 
-template <typename T>
-static void launch_pad_rows(const float* z, int B, void* out, hipStream_t st) {
-  const long long total = (long long)B * Z_PAD;
-  hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, B, Z_DIM, Z_PAD, (T*)out);
+// The back-propagated gradient penalty (train/cgan_trainer.py:200-203).  Precondition: the GP forward and first backward
+// have run (d_forward(xhat), d_head(mode 1), d_backward(wgrad=false, xgrad=true)), so d_g[i] = gy_i, d_bn[i].sums = first-
+// backward sums, g_h = gradient at the Linear(8392,256) output, d_gx = g_x, norms = ||g_x[n]||.  Accumulates
+// lambda * dGP/dtheta into D's gradient arena.  Derivation + fp64 check: tests/test_gp_double_backward_math.py.
+static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st) {
+  const size_t esz = e->esz;
+  HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->prob_gp, e->prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
+  JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, 64 * 64, e->d_u0, st));
+  // ---- v-chain: adjoint of the first backward, swept forward through D
+  const void* u = e->d_u0;
+  for (int i = 0; i < 4; ++i) {
+    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    // g_{a_{i-1}} = convT(gy_i; W_i):  dW_i += wgrad(gy_i, u_{i-1}),  v_i = conv(u_{i-1}; W_i)
+    JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    JCK_TRY(jck_conv_down(e->prec, u, e->d_down[i], e->d_v[i], nullptr, nullptr, B, hb, hb, cb, cs, st));
+    JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], e->d_y[i], e->d_g[i], e->d_bn[i].aux, e->d_bn[i].sums, e->P(e->LD, e->dp, NAMES_NW[i]),
+                           LRELU, e->bn2_ws[i], e->d_v[i], e->d_xdir[i], e->P(e->LD, e->dg, NAMES_NW[i]), rows, cs, st));
+    u = e->d_v[i];
+  }
+  // head: gc[:, :8192] = gh W1 -> adj(gh) = [u4 | 0] W1^T, dW1 += gh^T [u4 | 0]; gh = gh' * m/(1-p); gh' = ds w2; ds = p(1-p)
+  JCK_TRY(jck_concat_rows(e->prec, e->d_v[3], FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
+  JCK_TRY(jck_linear_wgrad(e->prec, e->gh_b1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
+  JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
+  JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
+  JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), e->prob_gp, B, L1_OUT, e->rs,
+                       e->P(e->LD, e->dg, "linear2.weight"), st));
+  // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
+  JCK_TRY(d_head_backward(e, e->rs, B, true, drop_mask, e->d_v[3], st));
+  for (int i = 3; i >= 0; --i) {
+    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], e->d_y[i], e->d_xdir[i], e->d_bn[i].aux, e->P(e->LD, e->dp, NAMES_NW[i]), e->bn2_ws[i],
+                            LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, st));
+    const void* big = i == 0 ? xhat : e->d_a[i - 1];
+    JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    if (i > 0)
+      JCK_TRY(jck_conv_up(e->prec, e->d_v[i], e->d_up[i], e->d_v[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+  }
+  return JCK_OK;
 }
 
-static int g_forward(jck_engine* e, const float* z, int B, bool update_running, hipStream_t st) {
-  (void)update_running;
-  if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, e->g_z, st); else launch_pad_rows<float>(z, B, e->g_z, st);
-  HIPCHK(hipGetLastError());
-  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, Z_PAD, G_C1, st));
+template <typename T>
+static void launch_pad_rows(const float* z, int B, int zd, int zp, void* out, hipStream_t st) {
+  const long long total = (long long)B * zp;
+  hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, B, zd, zp, (T*)out);
+}
+
+static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B, hipStream_t st) {
+  const int zp = z_pad(e->family);
+  if (e->family == 1) {
+    if (!labels) JCK_FAIL(JCK_E_ARG, "CGAN generator needs labels");
+    JCK_TRY(jck_cgan_z(e->prec, z, labels, B, 100, N_CLASS, zp, e->g_z, st));            // model/CGAN.py:154-155
+  } else {
+    if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, 100, zp, e->g_z, st); else launch_pad_rows<float>(z, B, 100, zp, e->g_z, st);
+    HIPCHK(hipGetLastError());
+  }
+  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, zp, G_C1, st));
   for (int i = 0; i < 4; ++i) {
     const int h = 4 << i, C = 512 >> i;
     const long long rows = (long long)B * h * h;
@@ -323,7 +462,8 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st) 
                            e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
     gbig = e->g_gr[i];
   }
-  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, Z_DIM, Z_PAD, G_C1, st));
+  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, z_dim(e->family),
+                       z_pad(e->family), G_C1, st));
   return JCK_OK;
 }
 
@@ -334,29 +474,39 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   if (!e || !e->bound || !in) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
   hipStream_t st = (hipStream_t)stream;
   const int B = e->B, HW = 64 * 64;
+  const bool cg = e->family == 1;
+  if (cg) {
+    if (!in->labels) JCK_FAIL(JCK_E_ARG, "CGAN phases need labels");
+    e->cur_labels = in->labels;
+  }
   switch (phase) {
     case JCK_PHASE_D_LOSS: {
       if (!in->real_nchw || !in->z) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw and z");
       HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
       HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
+      if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
       JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
-      JCK_TRY(d_forward(e, e->real_noisy, B, st));                                                // :162
-      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.9f, 0, e->prob, e->ds, e->acc, 0, 3, st));   // :163,165
-      JCK_TRY(d_backward(e, e->real_noisy, B, true, false, st));                                  // :164
-      JCK_TRY(g_forward(e, in->z, B, true, st));                                                  // :168-169
+      JCK_TRY(d_forward(e, e->real_noisy, B, in->drop_mask[0], st));                               // :162
+      JCK_TRY(d_head(e, B, 0.9f, 0, 0, 3, st));                                                   // :163,165
+      JCK_TRY(d_backward(e, e->real_noisy, B, true, false, in->drop_mask[0], st));                 // :164 (cgan :203)
+      JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                            // :168-169
       JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));     // :171
-      JCK_TRY(d_forward(e, e->fake, B, st));                                                      // :173
-      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.1f, 0, e->prob, e->ds, e->acc, 1, 4, st));   // :174,176
-      JCK_TRY(d_backward(e, e->fake, B, true, false, st));                                        // :175
+      JCK_TRY(d_forward(e, e->fake, B, in->drop_mask[1], st));                                    // :173
+      JCK_TRY(d_head(e, B, 0.1f, 0, 1, 4, st));                                                   // :174,176
+      JCK_TRY(d_backward(e, e->fake, B, true, false, in->drop_mask[1], st));                      // :175
       return JCK_OK;
     }
     case JCK_PHASE_D_GP: {                                                                        // :110-127, 178
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
       JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
-      JCK_TRY(d_forward(e, e->xhat, B, st));
-      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.f, 1, e->prob, e->ds, e->acc, -1, -1, st));
-      JCK_TRY(d_backward(e, e->xhat, B, false, true, st));
+      JCK_TRY(d_forward(e, e->xhat, B, in->drop_mask[2], st));
+      JCK_TRY(d_head(e, B, 0.f, 1, -1, -1, st));
+      JCK_TRY(d_backward(e, e->xhat, B, false, true, in->drop_mask[2], st));
       JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, HW, e->acc, 6, e->norms, st));
+      if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
+        JCK_TRY(gp_double_backward(e, e->xhat, B, 10.0f, in->drop_mask[2], st));
+        JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
+      }
       return JCK_OK;
     }
     case JCK_PHASE_D_STEP: {                                                                      // :180
@@ -365,10 +515,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
-      JCK_TRY(d_forward(e, e->fake, B, st));
-      JCK_TRY(jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, B, 8192, 0.9f, 0, e->prob, e->ds, e->acc, 2, 5, st));
+      JCK_TRY(d_forward(e, e->fake, B, in->drop_mask[3], st));
+      JCK_TRY(d_head(e, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
-      JCK_TRY(d_backward(e, e->fake, B, false, true, st));
+      JCK_TRY(d_backward(e, e->fake, B, false, true, in->drop_mask[3], st));
       JCK_TRY(g_backward(e, e->d_gx, B, st));
       return JCK_OK;
     }
@@ -385,11 +535,11 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
 
 extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }
 
-extern "C" int jck_engine_sample(jck_engine* e, const float* z, int n, float* out_nchw, void* stream) {
+extern "C" int jck_engine_sample(jck_engine* e, const float* z, const int64_t* labels, int n, float* out_nchw, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (n < 1 || n > e->B) JCK_FAIL(JCK_E_ARG, "sample: n must be in [1, batch]");
   hipStream_t st = (hipStream_t)stream;
-  JCK_TRY(g_forward(e, z, n, true, st));
+  JCK_TRY(g_forward(e, z, labels, n, st));
   return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, 64 * 64, st);
 }
 

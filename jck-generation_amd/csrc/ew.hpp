@@ -281,9 +281,9 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restric
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4, const float* __restrict__ w, int K,
-                                                       float target, int mode, float invB, float* __restrict__ prob,
-                                                       float* __restrict__ ds, float* __restrict__ scal, int slot_loss,
-                                                       int slot_p) {
+                                                       const float* __restrict__ bias, float target, int mode, float invB,
+                                                       float* __restrict__ prob, float* __restrict__ ds,
+                                                       float* __restrict__ scal, int slot_loss, int slot_p) {
   __shared__ float sm[4];
   const T* x = a4 + (long long)blockIdx.x * K;
   float s = 0.f;
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4,
   }
   s = block_sum256(s, sm);
   if (threadIdx.x == 0) {
+    if (bias) s += bias[0];
     const float p = 1.f / (1.f + expf(-s));
     prob[blockIdx.x] = p;
     const float pq = p * (1.f - p);
@@ -482,5 +483,323 @@ static __global__ void scalars_finalize_kernel(const float* __restrict__ acc, fl
     out[5] = gp;
     out[6] = lr;
     out[7] = lf;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// CGAN pieces (model/CGAN.py:79-162): Linear layers as GEMM operands, label embedding, concat, dropout, GP gradient
+// ------------------------------------------------------------------------------------------------------
+// nn.Linear weight [N][K] fp32 -> wp[row][col] of type W:
+//   transpose = 0: wp[n][k'] (forward operand, rows padded to NPad, K padded to KPad)
+//   transpose = 1: wp[k'][n] (dgrad operand, rows padded to KRows, columns padded to NPadK)
+// k' is the position in OUR activation order: the first hw*C columns of the reference are (c, hw) (NCHW flatten,
+// model/CGAN.py:119-120), ours are (hw, c) (NHWC); columns >= hw*C (the label embedding) keep their place.
+template <typename W>
+__global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, int rows, int cols, int transpose, int permC,
+                                   int permHW, W* __restrict__ wp) {
+  const long long total = (long long)rows * cols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const int n = transpose ? c : r, kp = transpose ? r : c;
+    float v = 0.f;
+    if (n < N && kp < K) {
+      int k = kp;
+      if (permC > 0 && kp < permC * permHW) { const int hw = kp / permC, ch = kp % permC; k = ch * permHW + hw; }
+      v = w[(long long)n * K + k];
+    }
+    stf(wp + i, v);
+  }
+}
+
+// grad[n][k] (+)= gp[n][k'] with the same column permutation (k' -> k) as pack_linear_kernel
+static __global__ void unperm_linear_grad_kernel(const float* __restrict__ gp, int N, int K, int ldp, int permC, int permHW,
+                                                 float* __restrict__ grad, int accumulate) {
+  const long long total = (long long)N * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K), k = (int)(i % K);
+    int kp = k;
+    if (permC > 0 && k < permC * permHW) { const int ch = k / permHW, hw = k % permHW; kp = hw * permC + ch; }
+    const float v = gp[(long long)n * ldp + kp];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+// label embedding: e[b][j] = lrelu(sum_i W[j][i] * onehot[b][i] + bias[j])   (model/CGAN.py:83-84,111)
+// labels: int64 one-hot [B][100] as the reference feeds them (preprocess/cgan_data_preprocessor.py:11-16)
+template <typename T>
+__global__ void label_embed_fwd_kernel(const long long* __restrict__ labels, const float* __restrict__ W,
+                                       const float* __restrict__ bias, float slope, int B, int NI, int NO, T* __restrict__ cbuf,
+                                       int ld, int col0, float* __restrict__ pre) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * NO) return;
+  const int b = i / NO, j = i % NO;
+  float s = bias[j];
+  for (int k = 0; k < NI; ++k) s += W[j * NI + k] * (float)labels[(long long)b * NI + k];
+  if (pre) pre[i] = s;
+  stf(cbuf + (long long)b * ld + col0 + j, s > 0.f ? s : slope * s);
+}
+// dW[j][i] += sum_b ue[b][j]*act'(pre) * onehot[b][i];  db[j] += sum_b ...      ue taken from gc[b][col0 + j] (type T)
+template <typename T>
+__global__ void label_embed_bwd_kernel(const T* __restrict__ gc, int ld, int col0, const float* __restrict__ pre,
+                                       const long long* __restrict__ labels, float slope, int B, int NI, int NO,
+                                       float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (j, k) plus NO threads for the bias
+  if (i < NO * NI) {
+    const int j = i / NI, k = i % NI;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
+      s += g * (float)labels[(long long)b * NI + k];
+    }
+    dW[i] += s;
+  } else if (i < NO * NI + NO) {
+    const int j = i - NO * NI;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
+    db[j] += s;
+  }
+}
+
+// cbuf[b][0..K0) = a4[b][0..K0)  (columns [K0, ld) are written by the label embedding / stay zero)
+template <typename T>
+__global__ void concat_rows_kernel(const T* __restrict__ a4, int K0, T* __restrict__ cbuf, int ld, long long total8) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;
+    const long long b = e / K0;
+    const int k = (int)(e % K0);
+    *reinterpret_cast<Raw8<T>*>(cbuf + b * ld + k) = *reinterpret_cast<const Raw8<T>*>(a4 + e);
+  }
+}
+// the reverse: a4-shaped gradient out of the first K0 columns
+template <typename T>
+__global__ void split_rows_kernel(const T* __restrict__ gc, int ld, int K0, T* __restrict__ ga4, long long total8) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;
+    const long long b = e / K0;
+    const int k = (int)(e % K0);
+    *reinterpret_cast<Raw8<T>*>(ga4 + e) = *reinterpret_cast<const Raw8<T>*>(gc + b * ld + k);
+  }
+}
+
+// y = x * mask * scale   (nn.Dropout(0.25) forward and backward: model/CGAN.py:105,122; mask in {0,1}, scale = 1/(1-p))
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, const float* __restrict__ mask, float scale, T* __restrict__ y,
+                               long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    stf(y + i, ldf(x + i) * mask[i] * scale);
+}
+
+// column sums of a [B][N] matrix of T into fp32 (bias gradients): db[j] += sum_b g[b][j]
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ g, int B, int N, int ld, float* __restrict__ db) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += ldf(g + (long long)b * ld + j);
+  db[j] += s;
+}
+
+// u = coef * (norm - 1) / norm * g      gradient of  lambda * mean_n (||g_n|| - 1)^2  w.r.t. g  (coef = 2*lambda/B)
+template <typename T>
+__global__ void gp_grad_kernel(const T* __restrict__ g, const float* __restrict__ norms, float coef, int per_image,
+                               T* __restrict__ u, long long total4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const float nr = norms[(i * 4) / per_image];
+    const float f = nr > 0.f ? coef * (nr - 1.f) / nr : 0.f;
+    float v[4];
+    ld4(g + i * 4, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= f;
+    st4(u + i * 4, v);
+  }
+}
+
+// second-order head terms of the penalty (see tests/test_gp_double_backward_math.py):
+//   uds[n] = <ughd[n,:], w2>;  rs[n] = uds * (1-2p) * p(1-p);  dw2[j] += sum_n ds[n] * ughd[n][j]     (ds = p(1-p))
+template <typename T>
+__global__ __launch_bounds__(256) void gp_head2_kernel(const T* __restrict__ ughd, const float* __restrict__ w2,
+                                                       const float* __restrict__ prob, int B, int K, float* __restrict__ rs,
+                                                       float* __restrict__ dw2) {
+  __shared__ float sm[4];
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < K; j += 256) {
+    const float v = ldf(ughd + (long long)n * K + j);
+    s += v * w2[j];
+    const float p = prob[n];
+    atomicAdd(dw2 + j, p * (1.f - p) * v);
+  }
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) {
+    const float p = prob[n], pq = p * (1.f - p);
+    rs[n] = s * (1.f - 2.f * p) * pq;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Second-order BatchNorm terms of the back-propagated gradient penalty (CGAN, train/cgan_trainer.py:200-203).
+// Notation (tests/test_gp_double_backward_math.py): first backward gy = (gamma/sigma) (gz - m1 - xhat*m2),
+// gz = g_a*act'(z), m1 = mean gz, m2 = mean gz*xhat.  The adjoint sweep carries v = adj(gy) forward through D
+// ("v-chain") and then the usual reverse sweep with two extra inputs per layer (xdir, sigexp).
+// Generic per-channel reduction: NA accumulators per channel, per-workgroup partials [blk][NA][C] (no atomics).
+// ------------------------------------------------------------------------------------------------------
+struct BnAux { const float* aux; int C; };       // aux = scale | shift | mean | invstd
+
+// MODE 1 (v-chain):  acc = { v, v*xhat, v*gy }             inputs a = v, b = y, c = gy
+// MODE 2 (reverse):  acc = { uz, uz*xhat, xdir, xdir*xhat } inputs a = ua, b = y, c = xdir;  uz = ua*act'(z)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn2_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                         const float* __restrict__ aux, float slope, float* __restrict__ partial,
+                                                         long long rows, int C) {
+  constexpr int NA = MODE == 1 ? 3 : 4;
+  extern __shared__ float lsum[];                         // [rstep][NA][C]
+  const int upr = C >> 3;
+  const int u = threadIdx.x % upr, r0 = threadIdx.x / upr, rstep = 256 / upr;
+  const int ch = u * 8;
+  float sc[8], sh[8], mu[8], is[8], acc[NA][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = aux[ch + k]; sh[k] = aux[C + ch + k]; mu[k] = aux[2 * C + ch + k]; is[k] = aux[3 * C + ch + k];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) acc[q][k] = 0.f;
+  }
+  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
+    float va[8], vb[8], vc[8];
+    ld8(a + r * C + ch, va);
+    ld8(b + r * C + ch, vb);
+    ld8(c + r * C + ch, vc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (vb[k] - mu[k]) * is[k];
+      if (MODE == 1) {
+        acc[0][k] += va[k]; acc[1][k] += va[k] * xh; acc[2][k] += va[k] * vc[k];
+      } else {
+        const float z = vb[k] * sc[k] + sh[k];
+        const float uz = z > 0.f ? va[k] : slope * va[k];
+        acc[0][k] += uz; acc[1][k] += uz * xh; acc[2][k] += vc[k]; acc[NA - 1][k] += vc[k] * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lsum[(r0 * NA + q) * C + ch + k] = acc[q][k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < NA * C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rstep; ++r) t += lsum[r * NA * C + i];
+    partial[(long long)blockIdx.x * NA * C + i] = t;
+  }
+}
+
+// sums[q*C + c] = sum over workgroups of partial[blk][q][c]      (NA * C outputs, one thread each: nblk <= 256)
+static __global__ void bn2_sums_kernel(const float* __restrict__ partial, int nblk, int NA, int C, float* __restrict__ sums) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NA * C) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += partial[(long long)k * NA * C + i];
+  sums[i] = s;
+}
+
+// v-chain apply:  u = act'(z) * (gamma/sigma) (v - mean v - xhat * mean(v xhat))                 (may overwrite v)
+//                 xdir = -(gamma/sigma) (v*m2 + gz * mean(v xhat)),  gz = gy*sigma/gamma + m1 + xhat*m2
+// s1 = sums of the FIRST backward (sum gz, sum gz*xhat), s3 = {sum v, sum v*xhat, sum v*gy}
+template <typename T>
+__global__ void bn2_vchain_apply_kernel(const T* __restrict__ v, const T* __restrict__ y, const T* __restrict__ gy,
+                                        const float* __restrict__ aux, const float* __restrict__ s1, const float* __restrict__ s3,
+                                        float slope, float inv_count, T* __restrict__ u, T* __restrict__ xdir, long long total8, int C) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 8) & (C - 1));
+    float vv[8], vy[8], vg[8], ou[8], ox[8];
+    ld8(v + i * 8, vv);
+    ld8(y + i * 8, vy);
+    ld8(gy + i * 8, vg);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sc = aux[c + k];                           // gamma / sigma
+      const float z = vy[k] * sc + aux[C + c + k];
+      const float xh = (vy[k] - aux[2 * C + c + k]) * aux[3 * C + c + k];
+      const float m1 = s1[c + k] * inv_count, m2 = s1[C + c + k] * inv_count;
+      const float mv = s3[c + k] * inv_count, mvx = s3[C + c + k] * inv_count;
+      const float gz = vg[k] / sc + m1 + xh * m2;
+      ox[k] = -sc * (vv[k] * m2 + gz * mvx);
+      const float ugz = sc * (vv[k] - mv - xh * mvx);
+      ou[k] = z > 0.f ? ugz : slope * ugz;
+    }
+    st8(u + i * 8, ou);
+    st8(xdir + i * 8, ox);
+  }
+}
+// direct parameter gradient of the v-chain: dgamma[c] += sum(v*gy) / gamma[c]
+static __global__ void bn2_vchain_dgamma_kernel(const float* __restrict__ s3, const float* __restrict__ gamma, float* __restrict__ dgamma, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) dgamma[c] += s3[2 * C + c] / gamma[c];
+}
+
+// reverse-sweep apply with the penalty's extra inputs:
+//   q = gamma*uz + xdir;  uy = (q - mean q - xhat*mean(q xhat)) / sigma  -  (sum(v*gy)/sigma) * xhat / n
+// s4 = {sum uz, sum uz*xhat, sum xdir, sum xdir*xhat};  vgy = sum v*gy (from the v-chain).  dgamma += sum uz*xhat, dbeta += sum uz
+template <typename T>
+__global__ void bn2_reverse_apply_kernel(const T* __restrict__ ua, const T* __restrict__ y, const T* __restrict__ xdir,
+                                         const float* __restrict__ aux, const float* __restrict__ gamma, const float* __restrict__ s4,
+                                         const float* __restrict__ vgy, float slope, float inv_count, T* __restrict__ uy,
+                                         long long total8, int C) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 8) & (C - 1));
+    float va[8], vy[8], vx[8], o[8];
+    ld8(ua + i * 8, va);
+    ld8(y + i * 8, vy);
+    ld8(xdir + i * 8, vx);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float g = gamma[c + k], is = aux[3 * C + c + k];
+      const float z = vy[k] * aux[c + k] + aux[C + c + k];
+      const float xh = (vy[k] - aux[2 * C + c + k]) * is;
+      const float uz = z > 0.f ? va[k] : slope * va[k];
+      const float q = g * uz + vx[k];
+      const float mq = (g * s4[c + k] + s4[2 * C + c + k]) * inv_count;
+      const float mqx = (g * s4[C + c + k] + s4[3 * C + c + k]) * inv_count;
+      o[k] = (q - mq - xh * mqx) * is - vgy[c + k] * is * xh * inv_count;
+    }
+    st8(uy + i * 8, o);
+  }
+}
+static __global__ void bn2_reverse_dparam_kernel(const float* __restrict__ s4, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { dgamma[c] += s4[C + c]; dbeta[c] += s4[c]; }
+}
+
+// h[b][j] = sum_z slab[z][b][j] + bias[j];  hd = h * mask * scale     (Linear(8392,256) finish + Dropout, model/CGAN.py:104-105,122)
+template <typename T>
+__global__ void linear_finish_kernel(const float* __restrict__ slab, int Z, long long zstride, const float* __restrict__ bias,
+                                     const float* __restrict__ mask, float scale, T* __restrict__ h, T* __restrict__ hd, int B, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  float s = bias ? bias[i % N] : 0.f;
+  for (int z = 0; z < Z; ++z) s += slab[(long long)z * zstride + i];
+  if (h) stf(h + i, s);
+  if (hd) stf(hd + i, mask ? s * mask[i] * scale : s);
+}
+
+// out[0] += sum_i x[i]   (bias gradient of a 1-output Linear)
+static __global__ __launch_bounds__(256) void sum_vec_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) out[0] += s;
+}
+// G input of the conditional GAN: [z | one-hot label] -> [B][CiPad] T   (model/CGAN.py:154-155: cat([x, labels], 1), int64 -> float)
+template <typename T>
+__global__ void cgan_z_kernel(const float* __restrict__ z, const long long* __restrict__ labels, int B, int NZ, int NL, int CiPad,
+                              T* __restrict__ out) {
+  const long long total = (long long)B * CiPad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CiPad);
+    const long long b = i / CiPad;
+    float v = 0.f;
+    if (c < NZ) v = z[b * NZ + c];
+    else if (c < NZ + NL) v = (float)labels[b * NL + (c - NZ)];
+    stf(out + i, v);
   }
 }

@@ -43,6 +43,12 @@ struct IgemmParams {
   int rows_are_phases;    // 1: MFMA row r = phase*4 + channel (4-channel outputs, all four parities in one tile)
   int gx, gy, gz;         // logical grid: pixel tiles, channel tiles, phases (launched as a 1-D grid of gx*gy*gz)
   unsigned act_bytes, w_bytes;   // sizes of the gathered tensor and of the packed weights (buffer descriptors)
+  int act_row_elems;      // > 0: plain row-major GEMM operand [M][act_row_elems] (Linear layers); taps unused
+  const float* bias;      // optional per-channel bias added in the epilogue (Linear layers)
+  int ksplit;             // > 1: split-K over gz = ksplit workgroup layers of `ksteps` k-steps each (plain GEMMs only);
+  int ksteps;             //      layer z writes its partial tile at out + z*out_split_stride
+  long long out_split_stride;
+  int out_f32;            // store fp32 regardless of T (split-K slabs)
   long long w_phase_stride;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
@@ -90,7 +96,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int bidy = wgid % p.gy;
-  const int z = (wgid / p.gy) % p.gz;
+  const int zraw = (wgid / p.gy) % p.gz;
+  const int z = p.ksplit > 1 ? 0 : zraw;                            // parity phase (tables, weights, output base)
+  const int kc0 = p.ksplit > 1 ? zraw * p.ksteps : 0;               // first k-step of this split
   const int bidx = wgid / (p.gy * p.gz);
   const int m0 = bidx * BPIX;
   const int ch0 = bidy * BCH;
@@ -113,7 +121,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int n = m >> p.logOHW;
     const int rem = m & ((1 << p.logOHW) - 1);
     const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
-    rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC) + (NSUB == 1 ? unit * 8 : 0)) * ESZ;
+    rowoff[ps] = p.act_row_elems ? ((unsigned)m * (unsigned)p.act_row_elems + unit * 8) * ESZ
+                                 : ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC) + (NSUB == 1 ? unit * 8 : 0)) * ESZ;
     riy[ps] = m < p.M ? iy0 : 0x40000000;
     rix[ps] = ix0;
   }
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   Stage st[NST];
 
   auto load_tiles = [&](int kc, Stage& sg) {
-    const int kbase = kc * IG_BK;                                  // wave-uniform
+    const int kbase = (kc + kc0) * IG_BK;                          // wave-uniform
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const int r = ps * 32 + lrow;
@@ -139,9 +148,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     if constexpr (NSUB == 1) {
       // C >= 64: the whole 64-wide k-step lies in ONE tap -> tap index, its (dy, dx) and its offset are scalars
-      const int t = kbase >> p.logC;
+      const int t = p.act_row_elems ? 0 : (kbase >> p.logC);
       const int dyv = p.dy[z][t], dxv = p.dx[z][t];
-      const int toffb = (((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * (int)ESZ;
+      const int toffb = p.act_row_elems ? kbase * (int)ESZ : (((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * (int)ESZ;
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / IG_BK;
+  const int nk = p.ksplit > 1 ? p.ksteps : p.K / IG_BK;
   const int sw = ((lane & 15) >> 1) & 7;                           // read-side swizzle of this lane's rows
   auto compute = [&](int buf) {
     const W* wt0 = reinterpret_cast<const W*>(lds + buf * C::BUF_BYTES);
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   if (p.stats) {
     // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
-    const long long slot = (((long long)z * p.gx + bidx) * nyrep + yrep) * C::WPIX + wpix;
+    const long long slot = (((long long)zraw * p.gx + bidx) * nyrep + yrep) * C::WPIX + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -280,14 +289,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int i = 0; i < FM; ++i) {
       int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
       if (ch >= p.NchStore) continue;
-      long long off = off0 + p.obase[z];
+      long long off = off0 + p.obase[z] + (long long)zraw * p.out_split_stride;
       if (p.rows_are_phases) { off = off0 + p.obase[ch >> 2]; ch = 0; }
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
+      }
       if (p.epi == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
       }
-      st4(outp + off + ch, v);
+      if (p.out_f32) st4(reinterpret_cast<float*>(p.out) + off + ch, v);
+      else st4(outp + off + ch, v);
     }
   }
 }

@@ -125,12 +125,12 @@ static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, in
 int launch_igemm(int prec, const IgemmParams& p0, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   IgemmParams p = p0;
   const long long esz = prec == JCK_PREC_F32 ? 4 : 2;
-  if (nsub == 1 && p.logC < 6) JCK_FAIL(JCK_E_ARG, "igemm: the gathered tensor needs >= 64 channels (or exactly 4)");
+  if (nsub == 1 && p.logC < 6 && !p.act_row_elems) JCK_FAIL(JCK_E_ARG, "igemm: the gathered tensor needs >= 64 channels (or exactly 4)");
   {
     // extent of the gathered tensor: rows (n, oy, ox) span N = M / (OH*OW) images of H x W x C
     const long long nimg = ((long long)p.M + (1ll << p.logOHW) - 1) >> p.logOHW;
-    const long long ab = nimg * p.H * p.W * (1ll << p.logC) * esz;
-    const long long wb = (long long)phases * (p.w_phase_stride ? p.w_phase_stride : (long long)nch_pad * p.K) * esz;
+    const long long ab = p.act_row_elems ? (long long)p.M * p.act_row_elems * esz : nimg * p.H * p.W * (1ll << p.logC) * esz;
+    const long long wb = (long long)(p.ksplit > 1 ? 1 : phases) * (p.w_phase_stride ? p.w_phase_stride : (long long)nch_pad * p.K) * esz;
     if (ab >= (1ll << 31) || wb >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "igemm: operand exceeds 2 GiB (32-bit buffer offsets)");
     p.act_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb;
   }
@@ -467,10 +467,10 @@ extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale,
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
-extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, int B, int K, float target, int mode, float* prob,
-                            float* ds, float* scal, int slot_loss, int slot_p, void* stream) {
+extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias, int B, int K, float target, int mode,
+                            float* prob, float* ds, float* scal, int slot_loss, int slot_p, void* stream) {
   if (K % 8) JCK_FAIL(JCK_E_ARG, "head_fwd: K % 8 != 0");
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K,
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K, bias,
                                       target, mode, 1.0f / (float)B, prob, ds, scal, slot_loss, slot_p));
   HIPCHK(hipGetLastError());
   return JCK_OK;
@@ -525,6 +525,192 @@ __global__ void debug_tr_kernel(const bf16_t* __restrict__ in, int ld, bf16_t* _
 extern "C" int jck_debug_tr_read(const void* in, int ld, void* out, void* stream) {
   if (ld % 4 || ld < 16) JCK_FAIL(JCK_E_ARG, "ld must be a multiple of 4 and >= 16");
   hipLaunchKernelGGL(debug_tr_kernel, dim3(1), dim3(64), 32 * ld * 2, (hipStream_t)stream, (const bf16_t*)in, ld, (bf16_t*)out);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// CGAN: Linear layers, label embedding, concat, dropout, second-order terms of the gradient penalty
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_pack_linear(int prec, const float* w, int N, int K, int rows, int cols, int transpose, int permC, int permHW,
+                               void* wp, void* stream) {
+  const long long total = (long long)rows * cols;
+  DISPATCH_T(prec, hipLaunchKernelGGL(pack_linear_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, N, K, rows,
+                                      cols, transpose, permC, permHW, (T*)wp));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// out[B][NStore] (T, or fp32 slabs [ksplit][B][NStore] when ksplit > 1) = x[B][Kpad] * wp[rows][Kpad]^T (+ bias)
+extern "C" int jck_linear_fwd(int prec, const void* x, const void* wp, const float* bias, void* out, int B, int Kpad, int N,
+                              int NStore, int ksplit, void* stream) {
+  if (Kpad % 64 || NStore % 4) JCK_FAIL(JCK_E_ARG, "linear_fwd: Kpad % 64 or NStore % 4");
+  const int rows = jck_pad_rows(N);
+  if (rows % 128) JCK_FAIL(JCK_E_ARG, "linear_fwd: N must be >= 65");
+  IgemmParams p = {};
+  p.act = x; p.w = wp; p.out = out; p.stats = nullptr;
+  p.M = B; p.NchStore = std::min(NStore, rows); p.K = Kpad; p.logC = 30; p.H = 1; p.W = 1; p.logOW = 0; p.logOHW = 0;
+  p.sy = p.sx = 1; p.ntaps = 1; p.act_row_elems = Kpad; p.bias = ksplit > 1 ? nullptr : bias;
+  p.osN = NStore; p.cstat = 4; p.ytiles_per_cset = 1;
+  int phases = 1;
+  if (ksplit > 1) {
+    const int nk = Kpad / 64;
+    if (nk % ksplit) JCK_FAIL(JCK_E_ARG, "linear_fwd: k-steps not divisible by ksplit");
+    p.ksplit = ksplit; p.ksteps = nk / ksplit; p.out_split_stride = (long long)B * NStore; p.out_f32 = 1;
+    phases = ksplit;
+  }
+  p.flops = 2.0 * B * N * (double)Kpad;
+  return launch_igemm(prec, p, rows, phases, 1, (hipStream_t)stream, nullptr);
+}
+
+extern "C" size_t jck_linear_wgrad_ws_bytes(int B, int Kpad, int N) { return plan_wgrad(B, Kpad, N).ws; }
+// gradp[N][Kpad] fp32 (+)= gy[B][N]^T * x[B][Kpad]     (our column order; see jck_unperm_linear_grad)
+extern "C" int jck_linear_wgrad(int prec, const void* gy, int ldgy, const void* x, int Kpad, float* ws, size_t ws_bytes,
+                                float* gradp, int accumulate, int B, int N, void* stream) {
+  if (Kpad % 64 || ldgy % 8) JCK_FAIL(JCK_E_ARG, "linear_wgrad: bad leading dimensions");
+  WgradParams p = {};
+  p.sside = gy; p.big = x; p.Mtot = B; p.CsStride = ldgy; p.logCb = 30; p.H = 1; p.W = 1; p.logOW = 0; p.logOHW = 0;
+  p.sy = p.sx = 1; p.ntaps = 1; p.dy[0] = 0; p.dx[0] = 0; p.big_row_elems = Kpad;
+  const WgradPlan pl = plan_wgrad(B, Kpad, N);
+  p.flops = 2.0 * B * N * (double)Kpad;
+  int rc = run_wgrad(prec, p, pl, 1, ws, ws_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long total = (long long)N * Kpad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, ws, pl.Z, pl.CsRows, pl.ncols, N, Kpad, 0, 1, gradp, accumulate);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_unperm_linear_grad(const float* gp, int N, int K, int ldp, int permC, int permHW, float* grad, int accumulate,
+                                      void* stream) {
+  const long long total = (long long)N * K;
+  hipLaunchKernelGGL(unperm_linear_grad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, gp, N, K, ldp, permC,
+                     permHW, grad, accumulate);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_linear_finish(int prec, const float* slab, int Z, const float* bias, const float* mask, float scale, void* h,
+                                 void* hd, int B, int N, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(linear_finish_kernel<T>, dim3(cdiv(B * N, 256)), dim3(256), 0, (hipStream_t)stream, slab, Z,
+                                      (long long)B * N, bias, mask, scale, (T*)h, (T*)hd, B, N));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI,
+                                   int NO, void* cbuf, int ld, int col0, float* pre, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_fwd_kernel<T>, dim3(cdiv(B * NO, 256)), dim3(256), 0, (hipStream_t)stream,
+                                      (const long long*)labels, W, b, slope, B, NI, NO, (T*)cbuf, ld, col0, pre));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
+                                   int B, int NI, int NO, float* dW, float* db, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(cdiv(NO * NI + NO, 256)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_concat_rows(int prec, const void* a4, int K0, void* cbuf, int ld, int B, void* stream) {
+  if (K0 % 8 || ld % 8) JCK_FAIL(JCK_E_ARG, "concat_rows: K0 % 8 or ld % 8");
+  const long long total8 = (long long)B * K0 / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(concat_rows_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const T*)a4,
+                                      K0, (T*)cbuf, ld, total8));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_split_rows(int prec, const void* gc, int ld, int K0, void* ga4, int B, void* stream) {
+  if (K0 % 8 || ld % 8) JCK_FAIL(JCK_E_ARG, "split_rows: K0 % 8 or ld % 8");
+  const long long total8 = (long long)B * K0 / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(split_rows_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const T*)gc, ld,
+                                      K0, (T*)ga4, total8));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_dropout(int prec, const void* x, const float* mask, float scale, void* y, long long n, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(dropout_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, mask, scale,
+                                      (T*)y, n));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_colsum(int prec, const void* g, int B, int N, int ld, float* db, void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, (const T*)g, B, N, ld, db));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_gp_grad(int prec, const void* g, const float* norms, float coef, int N, int HW, void* u, void* stream) {
+  const long long total4 = (long long)N * HW;
+  DISPATCH_T(prec, hipLaunchKernelGGL(gp_grad_kernel<T>, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, (const T*)g, norms,
+                                      coef, HW * 4, (T*)u, total4));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2,
+                            void* stream) {
+  DISPATCH_T(prec, hipLaunchKernelGGL(gp_head2_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)ughd, w2, prob, B, K,
+                                      rs, dw2));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// v-chain step of the penalty's double backward at one BatchNorm layer.  ws: jck_bn2_ws_floats(C) floats; on return
+// ws[0..3C) = {sum v, sum v*xhat, sum v*gy} (keep it for jck_bn2_reverse).  u may alias v.
+extern "C" size_t jck_bn2_ws_floats(int C) { return (size_t)(4 + 4 * BN_BWD_MAX_BLOCKS) * C; }
+extern "C" int jck_bn2_vchain(int prec, const void* v, const void* y, const void* gy, const float* aux, const float* s1,
+                              const float* gamma, float slope, float* ws, void* u, void* xdir, float* dgamma, long long rows, int C,
+                              void* stream) {
+  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn2_vchain: C must be a power of two in [8, 2048]");
+  const int rstep = 256 / (C / 8);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  float* partial = ws + 4 * C;
+  DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 3 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)v, (const T*)y, (const T*)gy, aux, slope, partial, rows, C));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws);
+  HIPCHK(hipGetLastError());
+  const long long total8 = rows * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn2_vchain_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const T*)v,
+                                      (const T*)y, (const T*)gy, aux, s1, ws, slope, 1.0f / (float)rows, (T*)u, (T*)xdir, total8, C));
+  HIPCHK(hipGetLastError());
+  if (dgamma) {
+    hipLaunchKernelGGL(bn2_vchain_dgamma_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, gamma, dgamma, C);
+    HIPCHK(hipGetLastError());
+  }
+  return JCK_OK;
+}
+// reverse-sweep BatchNorm backward with the penalty's extra inputs (xdir, sum v*gy from the v-chain at vsums[2C..3C)).
+extern "C" int jck_bn2_reverse(int prec, const void* ua, const void* y, const void* xdir, const float* aux, const float* gamma,
+                               const float* vsums, float slope, float* ws, void* uy, float* dgamma, float* dbeta, long long rows,
+                               int C, void* stream) {
+  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn2_reverse: C must be a power of two in [8, 2048]");
+  const int rstep = 256 / (C / 8);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  float* partial = ws + 4 * C;
+  DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 4 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)ua, (const T*)y, (const T*)xdir, aux, slope, partial, rows, C));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(cdiv(4 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws);
+  HIPCHK(hipGetLastError());
+  const long long total8 = rows * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn2_reverse_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)ua, (const T*)y, (const T*)xdir, aux, gamma, ws, vsums + 2 * C, slope,
+                                      1.0f / (float)rows, (T*)uy, total8, C));
+  HIPCHK(hipGetLastError());
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(bn2_reverse_dparam_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, dgamma, dbeta, C);
+    HIPCHK(hipGetLastError());
+  }
+  return JCK_OK;
+}
+
+extern "C" int jck_sum_vec(const float* x, int n, float* out, void* stream) {
+  hipLaunchKernelGGL(sum_vec_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_cgan_z(int prec, const float* z, const int64_t* labels, int B, int NZ, int NL, int CiPad, void* out, void* stream) {
+  const long long total = (long long)B * CiPad;
+  DISPATCH_T(prec, hipLaunchKernelGGL(cgan_z_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z,
+                                      (const long long*)labels, B, NZ, NL, CiPad, (T*)out));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

@@ -34,6 +34,7 @@ struct WgradParams {
   int ntaps;
   signed char dy[16], dx[16];
   int mchunk;             // pixel rows per blockIdx.z (multiple of WG_BKP)
+  int big_row_elems;      // > 0: the gathered side is a plain [Mtot][big_row_elems] matrix (Linear layers), 1 tap
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       zero_raw(greg[ps]);
       if constexpr (NSUB == 1) {
         const int iy = iy0 + dy0, ix = ix0 + dx0;
-        if (rok && tv0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        if (p.big_row_elems) {
+          if (rok && gcol < p.big_row_elems) ldraw(bigp + (long long)m * p.big_row_elems + gcol, greg[ps]);
+        } else if (rok && tv0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
           ldraw(bigp + ((((long long)n * p.H + iy) * p.W + ix) << p.logCb) + cb0, greg[ps]);
       } else {
         const int iya = iy0 + dy0, ixa = ix0 + dx0, iyb = iy0 + dy1, ixb = ix0 + dx1;

@@ -13,7 +13,7 @@ vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_d
 
 class StepInputs(C.Structure):
     _fields_ = [("real_nchw", vp), ("noise_real", vp), ("z", vp), ("noise_fake", vp), ("alpha", vp),
-                ("lr", f32), ("grad_scale", f32), ("step", i32)]
+                ("lr", f32), ("grad_scale", f32), ("step", i32), ("labels", vp), ("drop_mask", vp * 4)]
 
 
 # name -> (restype, argtypes)      (keep in sync with include/jckgan.h; tests/test_abi.py checks the symbol list)
@@ -45,7 +45,26 @@ PROTOS = {
     "jck_interp": (i32, [i32, vp, vp, vp, vp, i32, i32, vp]),
     "jck_gp_norm": (i32, [i32, vp, i32, i32, vp, i32, vp, vp]),
     "jck_tanh_bwd": (i32, [i32, vp, vp, f32, vp, i64, vp]),
-    "jck_head_fwd": (i32, [i32, vp, vp, i32, i32, f32, i32, vp, vp, vp, i32, i32, vp]),
+    "jck_head_fwd": (i32, [i32, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, i32, i32, vp]),
+    "jck_pack_linear": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "jck_linear_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "jck_linear_finish": (i32, [i32, vp, i32, vp, vp, f32, vp, vp, i32, i32, vp]),
+    "jck_linear_wgrad_ws_bytes": (sz, [i32, i32, i32]),
+    "jck_linear_wgrad": (i32, [i32, vp, i32, vp, i32, vp, sz, vp, i32, i32, i32, vp]),
+    "jck_unperm_linear_grad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "jck_label_embed_fwd": (i32, [i32, vp, vp, vp, f32, i32, i32, i32, vp, i32, i32, vp, vp]),
+    "jck_label_embed_bwd": (i32, [i32, vp, i32, i32, vp, vp, f32, i32, i32, i32, vp, vp, vp]),
+    "jck_concat_rows": (i32, [i32, vp, i32, vp, i32, i32, vp]),
+    "jck_split_rows": (i32, [i32, vp, i32, i32, vp, i32, vp]),
+    "jck_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),
+    "jck_colsum": (i32, [i32, vp, i32, i32, i32, vp, vp]),
+    "jck_sum_vec": (i32, [vp, i32, vp, vp]),
+    "jck_cgan_z": (i32, [i32, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "jck_gp_grad": (i32, [i32, vp, vp, f32, i32, i32, vp, vp]),
+    "jck_gp_head2": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "jck_bn2_ws_floats": (sz, [i32]),
+    "jck_bn2_vchain": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
+    "jck_bn2_reverse": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_head_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "jck_head_unpack_grad": (i32, [vp, i32, vp, i32, vp]),
     "jck_adam": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, i32, f32, vp]),
@@ -60,7 +79,7 @@ PROTOS = {
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
     "jck_engine_scalars": (vp, [vp]),
-    "jck_engine_sample": (i32, [vp, vp, i32, vp, vp]),
+    "jck_engine_sample": (i32, [vp, vp, vp, i32, vp, vp]),
     "jck_engine_tensor": (vp, [vp, C.c_char_p, C.POINTER(i64)]),
     "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),
     "jck_prof_enable": (i32, [i32]),

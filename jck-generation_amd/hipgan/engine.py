@@ -27,8 +27,11 @@ def _layout(family, net):
         if rc != 0:
             raise JckError(dll.jck_last_error().decode())
         shp = list(shape)
-        if kind.value == 0 and name.value.decode().startswith("conv"):
+        nm = name.value.decode()
+        if kind.value == 0 and nm.startswith("conv"):
             shp = shp
+        elif kind.value == 0 and nm.endswith(".weight") and (nm.startswith("linear") or nm.startswith("label_embedding")):
+            shp = shp[:2]
         else:
             shp = shp[:1]
         out.append((name.value.decode(), kind.value, off.value, numel.value, shp))
@@ -130,12 +133,14 @@ class DcganEngine:
     def _ordered(self, tag):
         """reference state_dict order: per layer weight, [bias, running_mean, running_var, num_batches_tracked]."""
         v = self.named_views(tag)
-        keys = []
+        keys = [k for k in ("label_embedding.weight", "label_embedding.bias") if k in v]
         for i in range(1, 6):
-            keys.append(f"conv{i}.weight")
+            if f"conv{i}.weight" in v:
+                keys.append(f"conv{i}.weight")
             if f"norm{i}.weight" in v:
                 keys += [f"norm{i}.weight", f"norm{i}.bias", f"norm{i}.running_mean", f"norm{i}.running_var",
                          f"norm{i}.num_batches_tracked"]
+        keys += [k for k in ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias") if k in v]
         return [(k, v[k]) for k in keys]
 
     def repack(self):
@@ -189,15 +194,32 @@ class DcganEngine:
         si.noise_fake = ptr(noise.get("n2"), B * 3 * 64 * 64)
         si.alpha = ptr(noise.get("alpha"), B)
         si.lr, si.grad_scale, si.step = lr, grad_scale, self.t + 1
+        if self.family == 1:
+            labels = noise.get("labels")
+            if labels is None or labels.shape != (B, 100) or labels.dtype != torch.int64:
+                raise JckError("CGAN step needs labels: int64 one-hot [B,100]")
+            lab = labels.to(self.device).contiguous()
+            keep.append(lab)
+            si.labels = lab.data_ptr()
+            for i in range(4):
+                m = noise.get(f"m{i + 1}")
+                if m is None:
+                    raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
+                si.drop_mask[i] = ptr(m, B * 256)
         return si, keep
 
-    def draw_noise(self, generator=None):
+    def draw_noise(self, generator=None, labels=None):
         """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111)."""
         B, dev = self.batch, self.device
-        return {"n1": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
-                "z": torch.randn(B, 100, 1, 1, device=dev, generator=generator),
-                "n2": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
-                "alpha": torch.rand(B, 1, 1, 1, device=dev, generator=generator)}
+        nz = {"n1": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
+              "z": torch.randn(B, 100, 1, 1, device=dev, generator=generator),
+              "n2": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
+              "alpha": torch.rand(B, 1, 1, 1, device=dev, generator=generator)}
+        if self.family == 1:
+            nz["labels"] = labels
+            for i in range(4):          # nn.Dropout(0.25) keep masks of the four D passes (model/CGAN.py:105)
+                nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
+        return nz
 
     def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0):
         """Enqueues one full step on the current stream; no host sync.  `reduce_d/reduce_g(flat_grads)` are
@@ -209,8 +231,12 @@ class DcganEngine:
         st = cur_stream()
         h = self._h
         lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
-        handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
-        lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)       # overlaps the D all-reduce (no gradients in DCGAN)
+        if self.family == 0:
+            handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
+            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # overlaps the D all-reduce (no gradients in DCGAN)
+        else:                                                      # CGAN back-propagates the penalty: reduce after it
+            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
+            handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
         if handle is not None:
             handle()
         lib.jck_engine_phase(h, PHASE_D_STEP, C.byref(si), st)
@@ -245,7 +271,7 @@ class DcganEngine:
         self.step_async(real, noise, lr, **kw)
         return self.scalars()
 
-    def sample(self, z):
+    def sample(self, z, labels=None):
         """G(z) with train-mode BatchNorm (train/dcgan_trainer.py:199-200) -> NCHW fp32 on the device.  The whole z is ONE
         BatchNorm batch (statistics and running-stat update over all n samples, as in the reference), so n <= batch."""
         n = z.shape[0]
@@ -256,8 +282,13 @@ class DcganEngine:
             self.repack()
         out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
         zc = z.to(self.device, torch.float32).contiguous().view(-1, 100)
-        lib.jck_engine_sample(self._h, zc, n, out, cur_stream())
-        self._keep_z = zc
+        lab = None
+        if self.family == 1:
+            if labels is None or labels.shape != (n, 100):
+                raise JckError("CGAN sample needs one-hot int64 labels [n,100]")
+            lab = labels.to(self.device, torch.int64).contiguous()
+        lib.jck_engine_sample(self._h, zc, lab, n, out, cur_stream())
+        self._keep_z = (zc, lab)
         return out
 
     def tensor(self, name):
@@ -266,6 +297,13 @@ class DcganEngine:
         p = load_library().jck_engine_tensor(self._h, name.encode(), C.byref(n))
         if not p:
             raise KeyError(name)
-        f32 = name in ("prob", "ds", "norms", "acc")
+        f32 = name in ("prob", "ds", "norms", "acc", "rs", "prob_gp")
         dt = torch.float32 if (f32 or self.prec == PREC_F32) else torch.bfloat16
         return self._ws_view(p, n.value, dt).clone()
+
+
+class CganEngine(DcganEngine):
+    """Conditional GAN (model/CGAN.py, train/cgan_trainer.py:173-213): labels + dropout masks ride in the noise dict
+    (`labels` int64 one-hot [B,100], `m1..m4` float keep-masks [B,256]); the gradient penalty is back-propagated."""
+
+    family = 1

@@ -227,7 +227,7 @@ class _HeadSigmoid(Function):
         lib.jck_pack_head(_f32(w), c, wp, cur_stream())
         prob = torch.empty(n, dtype=torch.float32, device=dev)
         dsig = torch.empty(n, dtype=torch.float32, device=dev)          # p(1-p)
-        lib.jck_head_fwd(prec, a4, wp, n, 16 * c, 0.0, 1, prob, dsig, None, -1, -1, cur_stream())
+        lib.jck_head_fwd(prec, a4, wp, None, n, 16 * c, 0.0, 1, prob, dsig, None, -1, -1, cur_stream())
         ctx.save_for_backward(a4, wp, dsig)
         ctx.meta = (prec, c)
         return prob.view(n, 1, 1, 1)

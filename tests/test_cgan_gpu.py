@@ -1,0 +1,72 @@
+"""CGAN step on the GPU (engine family 1) against the CPU oracle with identical weights, batch, labels, noise and dropout
+masks: label-embedding concat, Linear head, Dropout, and the BACK-PROPAGATED gradient penalty (double backward through conv,
+train-mode BatchNorm, LeakyReLU, Linear, Dropout, Sigmoid - train/cgan_trainer.py:200-203).  Tolerances as in
+tests/test_step_gpu.py (losses 1e-3 per step from identical state on the exact-fp32 path)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(B, seed, labels):
+    g = torch.Generator().manual_seed(seed)
+    nz = {"n1": torch.randn(B, 3, 64, 64, generator=g), "z": torch.randn(B, 100, 1, 1, generator=g),
+          "n2": torch.randn(B, 3, 64, 64, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g), "labels": labels}
+    for i in range(4):
+        nz[f"m{i + 1}"] = (torch.rand(B, 256, generator=g) >= 0.25).float()
+    return nz
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-12)
+
+
+def _cmp(views, refs, tol_l2, what):
+    bad = []
+    for k, r in refs.items():
+        g = views[k].detach().float().cpu().view(r.shape)
+        l2 = ((g - r).norm() / (r.norm() + 1e-30)).item()
+        mx = ((g - r).abs().max() / (r.abs().max() + 1e-30)).item()
+        if l2 > tol_l2:
+            bad.append(f"{what}:{k}: rel-l2 {l2:.3e} max/max {mx:.3e}")
+    assert not bad, "\\n".join(bad)
+
+
+@pytest.mark.parametrize("prec,B,tol,gtol", [("f32", 8, 1e-3, 2e-2), ("f32", 32, 1e-3, 5e-3), ("bf16", 32, 5e-2, 3e-1)])
+def test_cgan_step_parity(prec, B, tol, gtol):
+    from hipgan.engine import CganEngine
+    from oracle.gan_oracle import GanOracle
+    from util import synth_images, synth_onehot
+    orc = GanOracle("cgan", lr=2e-4, seed=12345)
+    eng = CganEngine(batch=B, prec=prec)
+    eng.load_state(orc.g, orc.d)
+    imgs = synth_images(B * 2)
+    onehot, _ = synth_onehot(B * 2)
+    for s in range(2):
+        real, lab = imgs[s * B:(s + 1) * B], onehot[s * B:(s + 1) * B]
+        nz = _noise(B, 300 + s, lab)
+        if s > 0:       # teacher forcing: restart from the oracle's state
+            eng.load_state(orc.g, orc.d)
+            for tag, opt in (("g", orc.opt_g), ("d", orc.opt_d)):
+                for what, src in (("m", opt.m), ("v", opt.v)):
+                    v = eng.named_views(tag, what)
+                    for k, t in src.items():
+                        v[k].copy_(t.view(v[k].shape))
+            eng.t = orc.opt_d.t
+        ref = orc.step(real, lab, nz)
+        got = eng.step(real.cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4)
+        for k in ("loss_real", "loss_fake", "gp", "loss_d", "loss_g", "d_x", "d_gz1", "d_gz2"):
+            assert _rel(got[k], ref[k]) < tol, (s, k, got[k], ref[k])
+        _cmp(eng.named_views("d", "grads"), orc.d_grads, gtol, f"s{s}.d_grads")
+        _cmp(eng.named_views("g", "grads"), orc.g_grads, gtol, f"s{s}.g_grads")
+
+
+def test_cgan_state_layout_matches_reference_keys():
+    from hipgan.engine import CganEngine
+    from util import load_golden
+    gold = load_golden("cgan_steps")["B8"]
+    eng = CganEngine(batch=4, prec="f32")
+    gs, ds = eng.state_dicts()
+    assert list(gs.keys()) == gold["ckpt_g_keys"] and list(ds.keys()) == gold["ckpt_d_keys"]
+    assert ds["linear1.weight"].shape == (256, 8392) and ds["label_embedding.weight"].shape == (200, 100)
+    assert gs["conv1.weight"].shape == (200, 512, 4, 4)

@@ -198,7 +198,7 @@ def test_head(G, prec):
     a4d = G.to_nhwc(a4.detach(), prec)
     prob, ds = torch.empty(b, device="cuda"), torch.empty(b, device="cuda")
     scal = torch.zeros(16, device="cuda")
-    G.lib.jck_head_fwd(prec, a4d, wp, b, 16 * c, 0.9, 0, prob, ds, scal, 0, 3, G.cur_stream())
+    G.lib.jck_head_fwd(prec, a4d, wp, None, b, 16 * c, 0.9, 0, prob, ds, scal, 0, 3, G.cur_stream())
     ga = torch.empty_like(a4d)
     dwp = torch.zeros(16 * c, device="cuda")
     G.lib.jck_head_bwd(prec, ds, wp, a4d, b, 16 * c, ga, dwp, 0, G.cur_stream())
@@ -211,7 +211,7 @@ def test_head(G, prec):
     G.check(G.from_nhwc(ga), a4.grad, 1e-5 if prec == 1 else 1e-2, "head dgrad")
     G.check(gw.cpu(), w.grad, 1e-5, "head wgrad")
     # gradient-penalty mode: d sum(sigmoid) / d logit
-    G.lib.jck_head_fwd(prec, a4d, wp, b, 16 * c, 0.0, 1, prob, ds, scal, -1, -1, G.cur_stream())
+    G.lib.jck_head_fwd(prec, a4d, wp, None, b, 16 * c, 0.0, 1, prob, ds, scal, -1, -1, G.cur_stream())
     torch.cuda.synchronize()
     G.check(ds.cpu(), (p * (1 - p)).detach(), 1e-5, "gp ds")
 
@@ -227,7 +227,7 @@ def test_head_clamp(G):
     wp = torch.empty(16 * c, device="cuda")
     G.lib.jck_pack_head(w.cuda(), c, wp, G.cur_stream())
     prob, ds, scal = torch.empty(b, device="cuda"), torch.empty(b, device="cuda"), torch.zeros(16, device="cuda")
-    G.lib.jck_head_fwd(1, G.to_nhwc(a4, 1), wp, b, 16 * c, 0.1, 0, prob, ds, scal, 0, 3, G.cur_stream())
+    G.lib.jck_head_fwd(1, G.to_nhwc(a4, 1), wp, None, b, 16 * c, 0.1, 0, prob, ds, scal, 0, 3, G.cur_stream())
     torch.cuda.synchronize()
     assert scal[0].item() / b == pytest.approx(ref.item(), rel=1e-6) == pytest.approx(90.0)
     assert float(ds.abs().max()) == 0.0
