@@ -282,3 +282,90 @@ def dcgan_generator(mod, z, prec="bf16"):
         h = _stage(mod, i, h, "up", 0.0, p)
     img = _UpTanh.apply(h, mod.conv5.weight, p)
     return _ToNCHW.apply(img, p)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CGAN head (model/CGAN.py:109-123): label MLP, concat, Linear(8392,256), Dropout(0.25), Linear(256,1), sigmoid
+# --------------------------------------------------------------------------------------------------------------------
+L1_K, L1_KPAD, L1_OUT, FEAT, EMB, L1_KSPLIT = 8392, 8448, 256, 8192, 200, 12
+
+
+class _CganHead(Function):
+    """a4 [B,4,4,512] (NHWC), one-hot labels -> probability [B,1].  First-order backward to a4 and to the five parameter
+    tensors.  `mask` is the dropout keep mask [B,256] (float 0/1)."""
+
+    @staticmethod
+    def forward(ctx, a4, labels, mask, we, be, w1, b1, w2, b2, prec):
+        dev, st = a4.device, cur_stream()
+        B = a4.shape[0]
+        dt = _DT[prec]
+        a4 = a4.contiguous()
+        cbuf = torch.zeros(B, L1_KPAD, dtype=dt, device=dev)
+        lib.jck_concat_rows(prec, a4, FEAT, cbuf, L1_KPAD, B, st)
+        pre_e = torch.empty(B * EMB, dtype=torch.float32, device=dev)
+        lab = labels.to(torch.int64).contiguous()
+        lib.jck_label_embed_fwd(prec, lab, _f32(we), _f32(be), 0.2, B, 100, EMB, cbuf, L1_KPAD, FEAT, pre_e, st)
+        w1p = torch.empty(L1_OUT * L1_KPAD, dtype=dt, device=dev)
+        lib.jck_pack_linear(prec, _f32(w1), L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, w1p, st)
+        slab = torch.empty(L1_KSPLIT * B * L1_OUT, dtype=torch.float32, device=dev)
+        lib.jck_linear_fwd(prec, cbuf, w1p, None, slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st)
+        hd = torch.empty(B, L1_OUT, dtype=dt, device=dev)
+        mask = mask.to(torch.float32).contiguous()
+        lib.jck_linear_finish(prec, slab, L1_KSPLIT, _f32(b1), mask, 1.0 / 0.75, None, hd, B, L1_OUT, st)
+        prob = torch.empty(B, dtype=torch.float32, device=dev)
+        dsig = torch.empty(B, dtype=torch.float32, device=dev)
+        w2f, b2f = _f32(w2).view(-1), _f32(b2)
+        lib.jck_head_fwd(prec, hd, w2f, b2f, B, L1_OUT, 0.0, 1, prob, dsig, None, -1, -1, st)
+        ctx.save_for_backward(a4, lab, mask, cbuf, pre_e, hd, dsig, w1, w2f)
+        ctx.prec = prec
+        return prob.view(B, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gp):
+        a4, lab, mask, cbuf, pre_e, hd, dsig, w1, w2f = ctx.saved_tensors
+        prec, st = ctx.prec, cur_stream()
+        dev, dt = a4.device, _DT[prec]
+        B = a4.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ds = (gp.reshape(B).to(torch.float32) * dsig).contiguous()
+        ghd = torch.empty(B, L1_OUT, dtype=dt, device=dev)
+        gw2 = torch.zeros(L1_OUT, **f32)
+        lib.jck_head_bwd(prec, ds, w2f, hd, B, L1_OUT, ghd, gw2, 1, st)
+        gb2 = torch.zeros(1, **f32)
+        lib.jck_sum_vec(ds, B, gb2, st)
+        gh = torch.empty_like(ghd)
+        lib.jck_dropout(prec, ghd, mask, 1.0 / 0.75, gh, B * L1_OUT, st)
+        nb = lib.jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT)
+        ws = torch.empty(nb // 4, **f32)
+        gw1p = torch.empty(L1_OUT * L1_KPAD, **f32)
+        lib.jck_linear_wgrad(prec, gh, L1_OUT, cbuf, L1_KPAD, ws, nb, gw1p, 0, B, L1_OUT, st)
+        gw1 = torch.empty(L1_OUT, L1_K, **f32)
+        lib.jck_unperm_linear_grad(gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, gw1, 0, st)
+        gb1 = torch.zeros(L1_OUT, **f32)
+        lib.jck_colsum(prec, gh, B, L1_OUT, L1_OUT, gb1, st)
+        w1t = torch.empty(L1_KPAD * L1_OUT, dtype=dt, device=dev)
+        lib.jck_pack_linear(prec, _f32(w1), L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, w1t, st)
+        gc = torch.empty(B, L1_KPAD, dtype=dt, device=dev)
+        lib.jck_linear_fwd(prec, gh, w1t, None, gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st)
+        ga4 = torch.empty_like(a4)
+        lib.jck_split_rows(prec, gc, L1_KPAD, FEAT, ga4, B, st)
+        gwe, gbe = torch.zeros(EMB, 100, **f32), torch.zeros(EMB, **f32)
+        lib.jck_label_embed_bwd(prec, gc, L1_KPAD, FEAT, pre_e, lab, 0.2, B, 100, EMB, gwe, gbe, st)
+        return ga4, None, None, gwe, gbe, gw1, gb1, gw2.view(1, L1_OUT), gb2, None
+
+
+def cgan_discriminator(mod, x, labels, prec="bf16", mask=None):
+    """model/CGAN.py:109-123 on the HIP path.  x NCHW fp32 [B,3,64,64] + one-hot int64 [B,100] -> [B,1] fp32."""
+    _need_cuda(x, "Discriminator.forward")
+    if x.dim() != 4 or x.shape[1:] != (3, 64, 64) or labels.shape != (x.shape[0], 100):
+        raise JckError(f"Discriminator expects [B,3,64,64] and one-hot [B,100], got {tuple(x.shape)}, {tuple(labels.shape)}")
+    p = _PREC[prec]
+    h = _ToNHWC.apply(x, p)
+    for i in (1, 2, 3, 4):
+        h = _stage(mod, i, h, "down", 0.2, p)
+    if mask is None:        # nn.Dropout(0.25) in training mode (the reference never switches D to eval)
+        mask = (torch.rand(x.shape[0], L1_OUT, device=x.device) >= 0.25).float() if mod.training else \
+            torch.full((x.shape[0], L1_OUT), 0.75, device=x.device)
+    return _CganHead.apply(h, labels.to(x.device), mask, mod.label_embedding.weight, mod.label_embedding.bias,
+                           mod.linear1.weight, mod.linear1.bias, mod.linear2.weight, mod.linear2.bias, p)

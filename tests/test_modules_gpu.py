@@ -60,3 +60,35 @@ def test_modules_reject_cpu_tensors():
         DCGAN.Generator()(torch.randn(2, 100, 1, 1))
     with pytest.raises(JckError):
         DCGAN.Discriminator()(torch.randn(2, 3, 64, 64))
+
+
+@pytest.mark.parametrize("prec,rtol", [("f32", 2e-4), ("bf16", 1.5e-1)])
+def test_cgan_modules_vs_golden(prec, rtol):
+    """CGAN nn.Modules (label concat in G, label MLP + Linear head in D) against the reference's classes; the golden pins
+    the p=0 dropout function, i.e. a keep 'mask' of 0.75 under the 1/0.75 scale."""
+    from hipgan import functional as HF
+    from model import CGAN
+    from util import check_digest, check_digest_dict, load_golden, synth_onehot
+    gold = load_golden("modules")["cgan"]
+    torch.manual_seed(12345)
+    g, d = CGAN.Generator(), CGAN.Discriminator()
+    g.apply(CGAN.weights_init)
+    d.apply(CGAN.weights_init)
+    check_digest_dict(dict(g.state_dict()), gold["init_g"], 0, 0, "init_g")
+    check_digest_dict(dict(d.state_dict()), gold["init_d"], 0, 0, "init_d")
+    g, d = g.cuda(), d.cuda()
+    g.prec = d.prec = prec
+    z, x, rg, rd = _inputs(4)
+    oh, _ = synth_onehot(4, seed=5)
+    xg = x.cuda().requires_grad_(True)
+    fake = g(z.cuda(), oh.cuda())
+    dout = HF.cgan_discriminator(d, xg, oh.cuda(), prec, mask=torch.full((4, 256), 0.75, device="cuda")).view(-1)
+    (fake * rg.cuda()).sum().backward()
+    (dout * rd.cuda()).sum().backward()
+    check_digest(fake, gold["g_out"], rtol, 1e-6, "g_out")
+    assert (dout.detach().cpu().double() - torch.tensor(gold["d_out"]["vals"])).abs().max() < rtol
+    check_digest_dict({k: p.grad for k, p in g.named_parameters()}, gold["g_grads"], rtol * 5, 1e-6, "g_grads")
+    check_digest_dict({k: p.grad for k, p in d.named_parameters()}, gold["d_grads"], rtol * 5, 1e-6, "d_grads")
+    check_digest(xg.grad, gold["d_xgrad"], rtol * 5, 1e-7, "d_xgrad")
+    out = d(x.cuda(), oh.cuda())                 # training-mode dropout with a device mask: shape / range only
+    assert out.shape == (4, 1) and float(out.min()) > 0 and float(out.max()) < 1

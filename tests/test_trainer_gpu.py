@@ -92,3 +92,43 @@ def test_main_wiring_with_ragged_last_batch(tmp_path, monkeypatch):
     assert out.shape == (5, 3, 64, 64) and float(out.abs().max()) <= 1.0
     assert any(f.endswith(".log") for f in os.listdir(args.save_path))
     _fresh_logger()
+
+
+class SynthPreC(SynthPre):
+    idx_to_labels = {i: str(i) for i in range(100)}
+
+
+@pytest.mark.parametrize("key", ["B8", "B32"])
+def test_cgan_trainer_reproduces_reference_run(key, tmp_path, monkeypatch):
+    """CGANTrainer on the exact-fp32 path with CPU-generator noise and dropout masks against the fixture recorded from the
+    reference's own CGANTrainer.train() (tests/golden/cgan_steps.json): includes the back-propagated gradient penalty."""
+    from model import CGAN
+    from train.cgan_trainer import CGANTrainer
+    from util import load_golden, rel, synth_images, synth_onehot
+    gold = load_golden("cgan_steps")[key]
+    B, steps = gold["B"], gold["steps"]
+    monkeypatch.chdir(tmp_path)
+    _fresh_logger()
+    imgs = synth_images(B * steps)
+    oh, _ = synth_onehot(B * steps)
+    batches = [(imgs[i * B:(i + 1) * B], oh[i * B:(i + 1) * B]) for i in range(steps)]
+    args = argparse.Namespace(epoch=1, max_learning_rate=gold["lr"], model_path="golden", log_file=0,
+                              save_path=str(tmp_path / "save" / "cgan" / "golden"), batch_size=B, num_worker=0)
+    torch.manual_seed(12345)
+    g, d = CGAN.Generator(), CGAN.Discriminator()
+    tr = CGANTrainer(args, g, d, SynthPreC(batches), prec="f32", host_rng=True)
+    losses_d, losses_g = tr.train()
+    for s in range(steps):
+        tol = 1e-3 if s == 0 else 1e-2
+        assert rel(losses_d[s], gold["losses_d"][s]) < tol, (s, losses_d, gold["losses_d"])
+        assert rel(losses_g[s], gold["losses_g"][s]) < tol * 5, (s, losses_g, gold["losses_g"])
+    saved = sorted(os.path.relpath(os.path.join(r, f), tmp_path) for r, _, fs in os.walk(tmp_path) for f in fs)
+    pts = [p for p in saved if p.endswith(".pt")]
+    ck = torch.load(tmp_path / pts[0], weights_only=False)
+    assert sorted(ck.keys()) == gold["ckpt_keys"]
+    assert list(ck["model_g"].keys()) == gold["ckpt_g_keys"] and list(ck["model_d"].keys()) == gold["ckpt_d_keys"]
+    g2, d2 = CGAN.Generator(), CGAN.Discriminator()
+    g2.load_state_dict(ck["model_g"])
+    d2.load_state_dict(ck["model_d"])
+    torch.optim.Adam(d2.parameters(), lr=0.1, betas=[0.5, 0.999]).load_state_dict(ck["optimizer_d"])
+    _fresh_logger()
