@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="dcgan", choices=["dcgan", "cgan"],
+                    help="dcgan = the headline config (BASELINE.json configs[1]); cgan = configs[3] (label-concat path, 10 classes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -111,25 +113,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    from hipgan.engine import DcganEngine
+    from hipgan.engine import CganEngine, DcganEngine
     from hipgan.dist import GradReducer
     from hipgan import lib
-    from model import DCGAN
+    from model import CGAN, DCGAN
 
     B = a.batch
     dev = torch.device("cuda", local)
-    eng = DcganEngine(batch=B, prec=a.prec, device=dev)
+    cgan = a.model == "cgan"
+    M = CGAN if cgan else DCGAN
+    eng = (CganEngine if cgan else DcganEngine)(batch=B, prec=a.prec, device=dev)
     torch.manual_seed(12345)                            # change_randomseed.py:1 - identical weights on every rank
-    net_g, net_d = DCGAN.Generator(), DCGAN.Discriminator()
-    net_g.apply(DCGAN.weights_init)
-    net_d.apply(DCGAN.weights_init)
+    net_g, net_d = M.Generator(), M.Discriminator()
+    net_g.apply(M.weights_init)
+    net_d.apply(M.weights_init)
     eng.load_state(net_g.state_dict(), net_d.state_dict())
     gen = torch.Generator(device=dev).manual_seed(2024 + rank)
     batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    # CGAN: 10-class synthetic labels as one-hot int64 [B,100] (classes 0-9 of the reference's 100-wide encoding)
+    labels = [torch.nn.functional.one_hot(torch.randint(0, 10, (B,), device=dev, generator=gen), 100).to(torch.int64)
+              for _ in range(4)] if cgan else None
     red = GradReducer(world) if world > 1 else None
 
     def one_step(i):
-        noise = eng.draw_noise(gen)                     # device-side RNG, inside the step like the reference
+        # device-side RNG, inside the step like the reference
+        noise = eng.draw_noise(gen, labels=labels[i % 4]) if cgan else eng.draw_noise(gen)
         if red:
             eng.step_async(batches[i % 4], noise, 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
         else:
@@ -157,16 +165,20 @@ def main():
     ms = dt / a.steps * 1e3
     value = world * B * a.steps / dt
 
-    out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
+    out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256" if not cgan else "images/sec (G+D step) CGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": a.prec if a.prec == "bf16" else "f32(split-bf16x3)",
            "data": "synthetic",
-           "config": {"workload": f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
-                                  f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})",
+           "config": {"workload": (f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
+                                   f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})") if not cgan else
+                                  (f"CGAN 64x64x3, 10-class synthetic one-hot labels, batch {B} per GPU, full step incl. the "
+                                   f"back-propagated gradient penalty (BASELINE.json configs[3])"),
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                       "dead_D_wgrad_in_G_phase": "skipped (never observable: zeroed at train/dcgan_trainer.py:155)"},
            "losses_last_step": {k: round(v, 5) for k, v in scal.items() if k in ("loss_d", "loss_g", "gp")}}
     fl = step_flops_per_image() * B
+    if cgan:   # + v-chain (D forward-like + direct wgrads) and the reverse sweep (wgrad + dgrad) of the penalty, + linear1
+        fl += 2 * B * (D_FWD + D_FWD + D_FWD + (D_FWD - D_CONV1))
     out["step_mfma"] = {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                         "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
