@@ -1,6 +1,7 @@
 // Whole-step engine: the reference's training iteration (train/dcgan_trainer.py:155-189) as one native
 // schedule of kernel launches on a HIP stream.  The host makes one call per phase; nothing in here
 // allocates, synchronises or reads back - scalars stay on the device until the trainer logs them.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -109,15 +110,24 @@ struct jck_engine {
   void *d_down[4], *d_up[4];
   float *d_head_wp, *d_head_dwp;
   void *g1_w, *g_up[4], *g_down[4];
-  // activations
-  void *d_y[4], *d_a[4], *d_g[4], *d_gx;
+  // activations: two complete D sets (set 1 lets the gradient-penalty pass run on a side stream beside the D(fake) pass)
+  struct DSet { void *y[4], *a[4], *g[4], *gx; BnBuf bn[4]; float *prob, *ds, *norms; } dset[2];
+  void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
+  void*& d_gx = dset[0].gx;
+  BnBuf* d_bn = dset[0].bn;
+  float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
+  float* d_rs[4];                       // deferred BatchNorm running-stat records of D: [pass 0..3][2*C] per layer
+  // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
+  hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
+  hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  bool overlap = true, gp_inflight = false;
   void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
   unsigned char* zero_d; size_t zero_d_bytes;      // stats + sums of D's 4 layers
   unsigned char* zero_g; size_t zero_g_bytes;
-  BnBuf d_bn[4], g_bn[4];
-  float *acc, *scal_out, *prob, *ds, *norms;
+  BnBuf g_bn[4];
+  float *acc, *scal_out;
   float* wg_ws; size_t wg_ws_bytes;
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
@@ -143,11 +153,19 @@ struct jck_engine {
       g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i])));
     }
     const size_t img = (size_t)B * 64 * 64 * 4;
-    for (int i = 0; i < 4; ++i) {
-      const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
-      d_y[i] = c.take<unsigned char>(bytes(n)); d_a[i] = c.take<unsigned char>(bytes(n)); d_g[i] = c.take<unsigned char>(bytes(n));
+    for (int sI = 0; sI < 2; ++sI) {
+      DSet& D = dset[sI];
+      for (int i = 0; i < 4; ++i) {
+        const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+        D.y[i] = c.take<unsigned char>(bytes(n)); D.a[i] = c.take<unsigned char>(bytes(n)); D.g[i] = c.take<unsigned char>(bytes(n));
+        D.bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(D_CS[i]));
+        D.bn[i].aux = c.take<float>(4 * D_CS[i]);
+        D.bn[i].stats = c.take<float>(jck_stats_floats((long long)B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
+      }
+      D.gx = c.take<unsigned char>(bytes(img));
+      D.prob = c.take<float>(B); D.ds = c.take<float>(B); D.norms = c.take<float>(B);
     }
-    d_gx = c.take<unsigned char>(bytes(img));
+    for (int i = 0; i < 4; ++i) d_rs[i] = c.take<float>(4 * 2 * D_CS[i]);
     g_z = c.take<unsigned char>(bytes((size_t)B * z_pad(family)));
     // G layer i (0..3): output of conv(i+1) = [B, h, h, C] with (h, C) = (4,512), (8,256), (16,128), (32,64)
     for (int i = 0; i < 4; ++i) {
@@ -160,13 +178,7 @@ struct jck_engine {
     // zeroed-per-pass regions
     {
       size_t start = c.off;
-      zero_d = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) d_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(D_CS[i]));
-      zero_d_bytes = c.off - start;
-      for (int i = 0; i < 4; ++i) {
-        d_bn[i].aux = c.take<float>(4 * D_CS[i]);
-        d_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
-      }
+      zero_d = nullptr; zero_d_bytes = 0;
       start = c.off;
       zero_g = base ? base + start : nullptr;
       for (int i = 0; i < 4; ++i) g_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(512 >> i));
@@ -178,7 +190,6 @@ struct jck_engine {
       }
     }
     acc = c.take<float>(16); scal_out = c.take<float>(8);
-    prob = c.take<float>(B); ds = c.take<float>(B); norms = c.take<float>(B);
     size_t w = 0;
     for (int i = 0; i < 4; ++i) {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
@@ -226,10 +237,26 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   e->family = family; e->prec = prec; e->B = batch; e->esz = prec == JCK_PREC_BF16 ? 2 : 4;
   e->LG = make_layout(family, 0); e->LD = make_layout(family, 1);
   e->carve(nullptr);
+  e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
+  if (e->overlap) {
+    hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
+    for (auto p : ss) HIPCHK(hipStreamCreateWithFlags(p, hipStreamNonBlocking));
+    hipEvent_t* ev[9] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
+  }
   *out = e;
   return JCK_OK;
 }
-extern "C" void jck_engine_destroy(jck_engine* e) { delete e; }
+extern "C" void jck_engine_destroy(jck_engine* e) {
+  if (!e) return;
+  if (e->overlap) {
+    hipStream_t ss[3] = {e->sA, e->sB, e->sC};
+    for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
+    hipEvent_t ev[9] = {e->evW[0], e->evW[1], e->evW[2], e->evW[3], e->evWdone, e->ev0, e->evF, e->evReal, e->evGP};
+    for (auto p : ev) if (p) (void)hipEventDestroy(p);
+  }
+  delete e;
+}
 extern "C" int jck_engine_num_tensors(int family, int net) { return (int)make_layout(family, net).t.size(); }
 extern "C" int jck_engine_tensor_info(int family, int net, int idx, char* name, int name_cap, int* kind, long long* offset,
                                       long long* numel, int* shape4) {
@@ -293,24 +320,41 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
 // ---------------------------------------------------------------------------------------------------------
 static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
-static int d_convs_forward(jck_engine* e, const void* x_in, int B, hipStream_t st) {
+typedef jck_engine::DSet DSet;
+
+// conv stack of D on activation set `D`; BatchNorm running statistics are NOT touched here: (mean, unbiased var) go to the
+// deferred record of `pass` (0 real, 1 fake, 2 penalty, 3 G phase) and are applied in that order at the end of the step,
+// which keeps the result bitwise independent of how the passes overlap on streams.
+static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st) {
   const void* in = x_in;
   for (int i = 0; i < 4; ++i) {
     const int hb = D_HB[i], cs = D_CS[i];
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], e->d_y[i], e->d_bn[i].stats, &e->d_bn[i].slots, B, hb, hb, D_CB[i], cs, st));
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, D_CB[i], cs, st));
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn_finalize(e->d_bn[i].stats, e->d_bn[i].slots, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
-                            e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
-                            e->dnbt + i, BN_MOM, BN_EPS, e->d_bn[i].aux, cs, st));
-    JCK_TRY(jck_bn_act_fwd(e->prec, e->d_y[i], e->d_bn[i].aux, LRELU, e->d_a[i], rows, cs, st));
-    in = e->d_a[i];
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
+                       e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]), (float*)nullptr, (float*)nullptr,
+                       (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + (size_t)pass * 2 * cs);
+    HIPCHK(hipGetLastError());
+    JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
+    in = D.a[i];
+  }
+  return JCK_OK;
+}
+
+static int d_apply_running_stats(jck_engine* e, int npass, hipStream_t st) {
+  for (int i = 0; i < 4; ++i) {
+    const int cs = D_CS[i];
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(cs, 256)), dim3(256), 0, st, e->d_rs[i], npass, (long long)2 * cs, BN_MOM,
+                       e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
+                       (long long*)(e->dnbt + i), cs);
+    HIPCHK(hipGetLastError());
   }
   return JCK_OK;
 }
 
 // D forward up to (not including) the sigmoid head.  family 1: concat + Linear(8392,256) + Dropout (model/CGAN.py:117-122)
-static int d_forward(jck_engine* e, const void* x_in, int B, const float* drop_mask, hipStream_t st) {
-  JCK_TRY(d_convs_forward(e, x_in, B, st));
+static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
+  JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st));
   if (e->family == 1) {
     if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
     JCK_TRY(jck_concat_rows(e->prec, e->d_a[3], FEAT, e->cbuf, L1_KPAD, B, st));
@@ -324,17 +368,17 @@ static int d_forward(jck_engine* e, const void* x_in, int B, const float* drop_m
 }
 
 // sigmoid head + loss (mode 0) or + d(sum p)/dlogit (mode 1); fills e->prob / e->ds
-static int d_head(jck_engine* e, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
+static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
   if (e->family == 0)
-    return jck_head_fwd(e->prec, e->d_a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, e->prob, e->ds, e->acc, slot_loss, slot_p, st);
+    return jck_head_fwd(e->prec, D.a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, st);
   return jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, target,
-                      mode, e->prob, e->ds, e->acc, slot_loss, slot_p, st);
+                      mode, D.prob, D.ds, e->acc, slot_loss, slot_p, st);
 }
 
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
-static int d_head_backward(jck_engine* e, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
+static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
   if (e->family == 0) {
-    JCK_TRY(jck_head_bwd(e->prec, ds, e->d_head_wp, e->d_a[3], B, FEAT, ga4_out, want_wgrad ? e->d_head_dwp : nullptr, 0, st));
+    JCK_TRY(jck_head_bwd(e->prec, ds, e->d_head_wp, D.a[3], B, FEAT, ga4_out, want_wgrad ? e->d_head_dwp : nullptr, 0, st));
     if (want_wgrad) JCK_TRY(jck_head_unpack_grad(e->d_head_dwp, 512, e->P(e->LD, e->dg, NAMES_CW[4]), 1, st));
     return JCK_OK;
   }
@@ -355,22 +399,30 @@ static int d_head_backward(jck_engine* e, const float* ds, int B, bool want_wgra
   return JCK_OK;
 }
 
-static int d_backward(jck_engine* e, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask, hipStream_t st) {
-  JCK_TRY(d_head_backward(e, e->ds, B, want_wgrad, drop_mask, e->d_g[3], st));
+// D backward on set `D`.  With `side` != nullptr the weight-gradient products run on that stream beside the dgrad chain
+// (both only READ gy_i and the saved activations); the main stream waits for them before returning.
+static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
+                      hipStream_t st, hipStream_t side) {
+  JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[3], st));
+  const bool par = want_wgrad && side != nullptr;
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn_act_bwd(e->prec, e->d_g[i], e->d_y[i], e->d_bn[i].aux, LRELU, e->d_bn[i].sums, e->d_g[i],
+    JCK_TRY(jck_bn_act_bwd(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i],
                            want_wgrad ? e->P(e->LD, e->dg, NAMES_NW[i]) : nullptr,
                            want_wgrad ? e->P(e->LD, e->dg, NAMES_NB[i]) : nullptr, rows, cs, st));
-    const void* big = i == 0 ? x_in : e->d_a[i - 1];
-    if (want_wgrad)
-      JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    const void* big = i == 0 ? x_in : D.a[i - 1];
+    if (want_wgrad) {
+      hipStream_t ws = st;
+      if (par) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+      JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, ws));
+    }
     if (i > 0)
-      JCK_TRY(jck_conv_up(e->prec, e->d_g[i], e->d_up[i], e->d_g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+      JCK_TRY(jck_conv_up(e->prec, D.g[i], e->d_up[i], D.g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
     else if (want_xgrad)
-      JCK_TRY(jck_conv_up(e->prec, e->d_g[0], e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+      JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
+  if (par) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
 
@@ -403,7 +455,7 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
   JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), e->prob_gp, B, L1_OUT, e->rs,
                        e->P(e->LD, e->dg, "linear2.weight"), st));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
-  JCK_TRY(d_head_backward(e, e->rs, B, true, drop_mask, e->d_v[3], st));
+  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[3], st));
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
@@ -449,19 +501,22 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
 }
 
 // g_fake = gradient w.r.t. the noisy fake image (NHWC4); fills G's grads arena (accumulating)
-static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st) {
+static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side) {
   JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * 64 * 64 * 4, st));
   const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
   for (int i = 3; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = G_CS[i]), big side has G_CB[i] channels
     const int hs = G_HS[i], cs = G_CS[i], cb = G_CB[i];
+    hipStream_t ws = st;
+    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[i + 1]), 1, B,
-                           2 * hs, 2 * hs, cb, cs, st));
+                           2 * hs, 2 * hs, cb, cs, ws));
     JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
     const long long rows = (long long)B * hs * hs;
     JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
                            e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
     gbig = e->g_gr[i];
   }
+  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, z_dim(e->family),
                        z_pad(e->family), G_C1, st));
   return JCK_OK;
@@ -479,30 +534,58 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     if (!in->labels) JCK_FAIL(JCK_E_ARG, "CGAN phases need labels");
     e->cur_labels = in->labels;
   }
+  DSet& D0 = e->dset[0];
+  DSet& D1 = e->dset[1];
+  // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
+  // on the main stream (it produces gradients and shares the head buffers).
+  hipStream_t sA = e->overlap ? e->sA : nullptr;
+  const bool ov_g = e->overlap, ov_gp = e->overlap && !cg;
+  auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
+    JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
+    JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
+    JCK_TRY(d_head(e, D, B, 0.f, 1, -1, -1, s));
+    JCK_TRY(d_backward(e, D, e->xhat, B, false, true, in->drop_mask[2], s, nullptr));
+    JCK_TRY(jck_gp_norm(e->prec, D.gx, B, HW, e->acc, 6, D.norms, s));
+    return JCK_OK;
+  };
   switch (phase) {
     case JCK_PHASE_D_LOSS: {
       if (!in->real_nchw || !in->z) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw and z");
+      if (ov_gp && !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs alpha (the penalty pass starts inside this phase)");
       HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
       HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
       if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+      hipStream_t sG = st;
+      if (ov_g) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0)); sG = e->sB; }
+      JCK_TRY(g_forward(e, in->z, in->labels, B, sG));                                            // :168-169
+      JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, sG));     // :171
+      if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
       JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
-      JCK_TRY(d_forward(e, e->real_noisy, B, in->drop_mask[0], st));                               // :162
-      JCK_TRY(d_head(e, B, 0.9f, 0, 0, 3, st));                                                   // :163,165
-      JCK_TRY(d_backward(e, e->real_noisy, B, true, false, in->drop_mask[0], st));                 // :164 (cgan :203)
-      JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                            // :168-169
-      JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));     // :171
-      JCK_TRY(d_forward(e, e->fake, B, in->drop_mask[1], st));                                    // :173
-      JCK_TRY(d_head(e, B, 0.1f, 0, 1, 4, st));                                                   // :174,176
-      JCK_TRY(d_backward(e, e->fake, B, true, false, in->drop_mask[1], st));                      // :175
+      if (ov_gp) HIPCHK(hipEventRecord(e->evReal, st));
+      JCK_TRY(d_forward(e, D0, e->real_noisy, B, 0, in->drop_mask[0], st));                        // :162
+      JCK_TRY(d_head(e, D0, B, 0.9f, 0, 0, 3, st));                                               // :163,165
+      JCK_TRY(d_backward(e, D0, e->real_noisy, B, true, false, in->drop_mask[0], st, sA));         // :164 (cgan :203)
+      if (ov_g) HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
+      if (ov_gp) {                                   // penalty pass on its own stream and activation set
+        HIPCHK(hipStreamWaitEvent(e->sC, e->evF, 0));
+        HIPCHK(hipStreamWaitEvent(e->sC, e->evReal, 0));
+        JCK_TRY(penalty_pass(D1, e->sC));
+        HIPCHK(hipEventRecord(e->evGP, e->sC));
+        e->gp_inflight = true;
+      }
+      JCK_TRY(d_forward(e, D0, e->fake, B, 1, in->drop_mask[1], st));                             // :173
+      JCK_TRY(d_head(e, D0, B, 0.1f, 0, 1, 4, st));                                               // :174,176
+      JCK_TRY(d_backward(e, D0, e->fake, B, true, false, in->drop_mask[1], st, sA));              // :175
       return JCK_OK;
     }
-    case JCK_PHASE_D_GP: {                                                                        // :110-127, 178
+    case JCK_PHASE_D_GP: {
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
-      JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
-      JCK_TRY(d_forward(e, e->xhat, B, in->drop_mask[2], st));
-      JCK_TRY(d_head(e, B, 0.f, 1, -1, -1, st));
-      JCK_TRY(d_backward(e, e->xhat, B, false, true, in->drop_mask[2], st));
-      JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, HW, e->acc, 6, e->norms, st));
+      if (e->gp_inflight) {                           // started in PHASE_D_LOSS: just join
+        HIPCHK(hipStreamWaitEvent(st, e->evGP, 0));
+        e->gp_inflight = false;
+        return JCK_OK;
+      }
+      JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
         JCK_TRY(gp_double_backward(e, e->xhat, B, 10.0f, in->drop_mask[2], st));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
@@ -510,21 +593,23 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       return JCK_OK;
     }
     case JCK_PHASE_D_STEP: {                                                                      // :180
+      if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
       JCK_TRY(jck_adam(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
-      JCK_TRY(d_forward(e, e->fake, B, in->drop_mask[3], st));
-      JCK_TRY(d_head(e, B, 0.9f, 0, 2, 5, st));
+      JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st));
+      JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
-      JCK_TRY(d_backward(e, e->fake, B, false, true, in->drop_mask[3], st));
-      JCK_TRY(g_backward(e, e->d_gx, B, st));
+      JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr));
+      JCK_TRY(g_backward(e, D0.gx, B, st, sA));
       return JCK_OK;
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
       JCK_TRY(jck_adam(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
+      JCK_TRY(d_apply_running_stats(e, 4, st));     // the four D passes' BatchNorm records, in the reference's order
       hipLaunchKernelGGL(scalars_finalize_kernel, dim3(1), dim3(64), 0, st, e->acc, 1.0f / (float)B, 10.0f, e->scal_out);
       HIPCHK(hipGetLastError());
       return JCK_OK;

@@ -130,7 +130,7 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                  long long* __restrict__ nbt, float momentum, float eps,
-                                                                 float* __restrict__ aux, int C) {
+                                                                 float* __restrict__ aux, int C, float* __restrict__ stat_out = nullptr) {
   __shared__ double sh[4][8];
   const int c0 = blockIdx.x * 4;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
@@ -161,11 +161,31 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
   aux[C + c] = beta[c] - mean * sc;
   aux[2 * C + c] = mean;
   aux[3 * C + c] = invstd;
+  const float unbiased = var * (count / fmaxf(count - 1.f, 1.f));
+  if (stat_out) {             // deferred running-stat update (passes that run concurrently on different streams)
+    stat_out[c] = mean;
+    stat_out[C + c] = unbiased;
+  }
   if (running_mean) {
-    const float unbiased = var * (count / fmaxf(count - 1.f, 1.f));
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
+}
+
+// applies `npass` deferred (mean, unbiased var) records in order - bitwise the same recurrence as npass sequential updates
+static __global__ void bn_running_update_kernel(const float* __restrict__ slots, int npass, long long pass_stride, float momentum,
+                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                long long* __restrict__ nbt, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += npass;
+  if (c >= C) return;
+  float rm = running_mean[c], rv = running_var[c];
+  for (int p = 0; p < npass; ++p) {
+    rm = (1.f - momentum) * rm + momentum * slots[p * pass_stride + c];
+    rv = (1.f - momentum) * rv + momentum * slots[p * pass_stride + C + c];
+  }
+  running_mean[c] = rm;
+  running_var[c] = rv;
 }
 
 // a = act(scale[c]*y + shift[c]), act = x>0 ? x : slope*x
