@@ -187,6 +187,11 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
 #define JCK_PHASE_D_STEP 2
 #define JCK_PHASE_G_LOSS 3
 #define JCK_PHASE_G_STEP 4
+/* PHASE_D_LOSS = PHASE_D_REAL (:155-165, needs no G) followed by PHASE_D_FAKE (:168-176 + start of the penalty pass).
+ * Issued separately, D_REAL of step k+1 may run on another stream beside the G phase of step k: it uses its own
+ * activation set, and scalar accumulators / BatchNorm records are double-buffered on the parity of `step`. */
+#define JCK_PHASE_D_REAL 5
+#define JCK_PHASE_D_FAKE 6
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1) */
@@ -203,6 +208,7 @@ typedef struct jck_step_inputs {
 int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
 const float* jck_engine_scalars(const jck_engine*);
+const float* jck_engine_scalars_at(const jck_engine*, int step);   /* buffer of the given (1-based) step's parity */
 /* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */
 int jck_engine_sample(jck_engine*, const float* z, const int64_t* labels /* family 1 */, int n, float* out_nchw, void* stream);
 /* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */

@@ -111,12 +111,13 @@ struct jck_engine {
   float *d_head_wp, *d_head_dwp;
   void *g1_w, *g_up[4], *g_down[4];
   // activations: two complete D sets (set 1 lets the gradient-penalty pass run on a side stream beside the D(fake) pass)
-  struct DSet { void *y[4], *a[4], *g[4], *gx; BnBuf bn[4]; float *prob, *ds, *norms; } dset[2];
+  struct DSet { void *y[4], *a[4], *g[4], *gx; BnBuf bn[4]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
   void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
   void*& d_gx = dset[0].gx;
   BnBuf* d_bn = dset[0].bn;
   float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
-  float* d_rs[4];                       // deferred BatchNorm running-stat records of D: [pass 0..3][2*C] per layer
+  float* d_rs[4];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
+  int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
   hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
@@ -127,7 +128,8 @@ struct jck_engine {
   unsigned char* zero_d; size_t zero_d_bytes;      // stats + sums of D's 4 layers
   unsigned char* zero_g; size_t zero_g_bytes;
   BnBuf g_bn[4];
-  float *acc, *scal_out;
+  float *acc, *scal_out;                // current-parity views into acc2 / scal2
+  float *acc2, *scal2;
   float* wg_ws; size_t wg_ws_bytes;
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
@@ -153,7 +155,7 @@ struct jck_engine {
       g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i])));
     }
     const size_t img = (size_t)B * 64 * 64 * 4;
-    for (int sI = 0; sI < 2; ++sI) {
+    for (int sI = 0; sI < 3; ++sI) {
       DSet& D = dset[sI];
       for (int i = 0; i < 4; ++i) {
         const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
@@ -165,7 +167,7 @@ struct jck_engine {
       D.gx = c.take<unsigned char>(bytes(img));
       D.prob = c.take<float>(B); D.ds = c.take<float>(B); D.norms = c.take<float>(B);
     }
-    for (int i = 0; i < 4; ++i) d_rs[i] = c.take<float>(4 * 2 * D_CS[i]);
+    for (int i = 0; i < 4; ++i) d_rs[i] = c.take<float>(2 * 4 * 2 * D_CS[i]);
     g_z = c.take<unsigned char>(bytes((size_t)B * z_pad(family)));
     // G layer i (0..3): output of conv(i+1) = [B, h, h, C] with (h, C) = (4,512), (8,256), (16,128), (32,64)
     for (int i = 0; i < 4; ++i) {
@@ -189,7 +191,8 @@ struct jck_engine {
         g_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * h * h, C, i == 0 ? 16 : 1));
       }
     }
-    acc = c.take<float>(16); scal_out = c.take<float>(8);
+    acc2 = c.take<float>(32); scal2 = c.take<float>(16);
+    acc = acc2; scal_out = scal2;
     size_t w = 0;
     for (int i = 0; i < 4; ++i) {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
@@ -333,7 +336,7 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]), (float*)nullptr, (float*)nullptr,
-                       (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + (size_t)pass * 2 * cs);
+                       (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
     JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
     in = D.a[i];
@@ -344,7 +347,7 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 static int d_apply_running_stats(jck_engine* e, int npass, hipStream_t st) {
   for (int i = 0; i < 4; ++i) {
     const int cs = D_CS[i];
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(cs, 256)), dim3(256), 0, st, e->d_rs[i], npass, (long long)2 * cs, BN_MOM,
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(cs, 256)), dim3(256), 0, st, e->d_rs[i] + (size_t)e->parity * 4 * 2 * cs, npass, (long long)2 * cs, BN_MOM,
                        e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
                        (long long*)(e->dnbt + i), cs);
     HIPCHK(hipGetLastError());
@@ -516,9 +519,12 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
                            e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
     gbig = e->g_gr[i];
   }
-  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+  // the split-K workspace belongs to the side stream: G.conv1's weight gradient goes there too
+  hipStream_t ws1 = st;
+  if (side) { HIPCHK(hipEventRecord(e->evW[0], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[0], 0)); ws1 = side; }
   JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, z_dim(e->family),
-                       z_pad(e->family), G_C1, st));
+                       z_pad(e->family), G_C1, ws1));
+  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
 
@@ -536,6 +542,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   }
   DSet& D0 = e->dset[0];
   DSet& D1 = e->dset[1];
+  DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
+  e->parity = in->step & 1;
+  e->acc = e->acc2 + 16 * e->parity;
+  e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
   hipStream_t sA = e->overlap ? e->sA : nullptr;
@@ -549,24 +559,36 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     return JCK_OK;
   };
   switch (phase) {
-    case JCK_PHASE_D_LOSS: {
-      if (!in->real_nchw || !in->z) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw and z");
-      if (ov_gp && !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs alpha (the penalty pass starts inside this phase)");
-      HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
-      HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
-      if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+    case JCK_PHASE_D_LOSS:
+    case JCK_PHASE_D_REAL:
+    case JCK_PHASE_D_FAKE: {
+      if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
+        if (!in->real_nchw) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw");
+        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                   // D.zero_grad()  :155
+        if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+      }
       hipStream_t sG = st;
-      if (ov_g) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0)); sG = e->sB; }
-      JCK_TRY(g_forward(e, in->z, in->labels, B, sG));                                            // :168-169
-      JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, sG));     // :171
-      if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
-      JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
-      if (ov_gp) HIPCHK(hipEventRecord(e->evReal, st));
-      JCK_TRY(d_forward(e, D0, e->real_noisy, B, 0, in->drop_mask[0], st));                        // :162
-      JCK_TRY(d_head(e, D0, B, 0.9f, 0, 0, 3, st));                                               // :163,165
-      JCK_TRY(d_backward(e, D0, e->real_noisy, B, true, false, in->drop_mask[0], st, sA));         // :164 (cgan :203)
+      if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_FAKE) {   // G forward: beside D(real) when both are in this call
+        if (!in->z) JCK_FAIL(JCK_E_ARG, "G forward needs z");
+        if (ov_gp && !in->alpha) JCK_FAIL(JCK_E_ARG, "alpha is needed here (the penalty pass starts inside this phase)");
+        if (ov_g) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0)); sG = e->sB; }
+        JCK_TRY(g_forward(e, in->z, in->labels, B, sG));                                          // :168-169
+        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, sG));   // :171
+        if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
+      }
+      if (phase != JCK_PHASE_D_FAKE) {
+        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        if (ov_gp && phase == JCK_PHASE_D_LOSS) HIPCHK(hipEventRecord(e->evReal, st));           // penalty pass needs only this
+        JCK_TRY(d_forward(e, DR, e->real_noisy, B, 0, in->drop_mask[0], st));                      // :162
+        JCK_TRY(d_head(e, DR, B, 0.9f, 0, 0, 3, st));                                             // :163,165
+        JCK_TRY(d_backward(e, DR, e->real_noisy, B, true, false, in->drop_mask[0], st, sA));       // :164 (cgan :203)
+        if (phase == JCK_PHASE_D_REAL) return JCK_OK;
+      }
+      // ---- D on the fake batch (:170-176) with the penalty pass (:178) beside it
       if (ov_g) HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
       if (ov_gp) {                                   // penalty pass on its own stream and activation set
+        if (phase == JCK_PHASE_D_FAKE) HIPCHK(hipEventRecord(e->evReal, st));    // real_noisy came from an earlier call on st
         HIPCHK(hipStreamWaitEvent(e->sC, e->evF, 0));
         HIPCHK(hipStreamWaitEvent(e->sC, e->evReal, 0));
         JCK_TRY(penalty_pass(D1, e->sC));
@@ -619,6 +641,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
 }
 
 extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }
+extern "C" const float* jck_engine_scalars_at(const jck_engine* e, int step) { return e ? e->scal2 + 8 * (step & 1) : nullptr; }
 
 extern "C" int jck_engine_sample(jck_engine* e, const float* z, const int64_t* labels, int n, float* out_nchw, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");

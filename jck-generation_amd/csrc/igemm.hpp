@@ -34,6 +34,7 @@ struct IgemmParams {
   int sy, sx;
   int ntaps;
   signed char dy[4][16], dx[4][16];
+  int tap[4][16];         // (dy << 16) | (dx & 0xffff), filled by the launcher: dword table -> scalar loads in the kernel
   long long osN;          // output offset = n*osN + oy*osY + ox*osX + obase[z]   (elements)
   int osY, osX;
   int obase[4];
@@ -71,6 +72,67 @@ template <class P, int BCH, int BPIX> struct IgemmCfg {
   static constexpr int LDS_BYTES = 2 * BUF_BYTES + 128;
   // slots of partial statistics written by one launch = gridDim.x * gridDim.z * (gridDim.y / ytiles_per_cset) * WPIX
 };
+
+
+// Shared epilogue: optional BatchNorm partial statistics, bias, tanh, NHWC store of 4 consecutive channels per lane.
+template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z, int zraw,
+                                               int bidx, int bidy, int m0, int ch0) {
+  typedef typename P::T T;
+  // ---- epilogue --------------------------------------------------------------------------------------
+  if (p.stats) {
+    // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
+    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
+    const long long slot = (((long long)zraw * p.gx + bidx) * nyrep + yrep) * WPIXN + wpix;
+    float* sp = p.stats + slot * 2 * p.cstat;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
+      if ((lane & 15) == 0) {
+        const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
+        if (ch < p.NchStore) {
+          const int cc = ch & (p.cstat - 1);
+          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
+          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
+        }
+      }
+    }
+  }
+  T* outp = reinterpret_cast<T*>(p.out);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int m = m0 + wpix * FN * 16 + j * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    const int n = m >> p.logOHW;
+    const int rem = m & ((1 << p.logOHW) - 1);
+    const long long off0 = (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY +
+                           (long long)(rem & ((1 << p.logOW) - 1)) * p.osX;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
+      if (ch >= p.NchStore) continue;
+      long long off = off0 + p.obase[z] + (long long)zraw * p.out_split_stride;
+      if (p.rows_are_phases) { off = off0 + p.obase[ch >> 2]; ch = 0; }
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
+      }
+      if (p.epi == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+      }
+      if (p.out_f32) st4(reinterpret_cast<float*>(p.out) + off + ch, v);
+      else st4(outp + off + ch, v);
+    }
+  }
+}
 
 template <class P, int BCH, int BPIX, int NSUB, int NST = 2>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
@@ -251,57 +313,138 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  // ---- epilogue --------------------------------------------------------------------------------------
-  if (p.stats) {
-    // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
-    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
-    const long long slot = (((long long)zraw * p.gx + bidx) * nyrep + yrep) * C::WPIX + wpix;
-    float* sp = p.stats + slot * 2 * p.cstat;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
-      if ((lane & 15) == 0) {
-        const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
-        if (ch < p.NchStore) {
-          const int cc = ch & (p.cstat - 1);
-          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
-          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
-        }
-      }
-    }
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (bf16, C >= 64 gathers): operands go global -> LDS directly with global_load_lds_dwordx4 (no VGPR
+// staging, no ds_write), NSTG LDS stages, ONE raw s_barrier per k-step and counted s_waitcnt vmcnt so that the loads of
+// the next stages stay in flight across the barrier.  Each wave-instruction writes 1 KiB = 8 tile rows x 128 B lane-
+// linearly, so the bank swizzle (chunk ^= (row >> 1) & 7) is applied to the per-lane SOURCE address; out-of-image taps
+// and rows past M read a 16-byte zero page instead.  Same tile geometry, fragment reads and epilogue as igemm_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
+
+template <int BCH, int BPIX, int NSTG>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
+  typedef PrecBf16 P;
+  typedef IgemmCfg<P, BCH, BPIX> C;
+  constexpr int FM = C::FM, FN = C::FN, LD = IG_BK;                 // unpadded 128-byte rows
+  constexpr int STG_BYTES = (BCH + BPIX) * LD * 2;
+  constexpr int NLD = (BCH + BPIX) / 32;                            // DMA wave-instructions per stage and wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* lds = smem_raw;                                    // the ONLY shared object (hipcc wait-insertion trap)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x;
+  int wgid;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  T* outp = reinterpret_cast<T*>(p.out);
+  wgid = __builtin_amdgcn_readfirstlane(wgid);                      // provably wave-uniform: tap tables come by s_load
+  const int bidy = wgid % p.gy;
+  const int zraw = (wgid / p.gy) % p.gz;
+  const int z = zraw;
+  const int bidx = wgid / (p.gy * p.gz);
+  const int m0 = bidx * BPIX, ch0 = bidy * BCH;
+  const int Cc = 1 << p.logC;
+
+  const int lrow = tid >> 3, unit = tid & 7;
+  const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;      // swizzle on the source side
+  unsigned rowoff[C::APASS];
+  int riy[C::APASS], rix[C::APASS];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int m = m0 + wpix * FN * 16 + j * 16 + (lane & 15);
-    if (m >= p.M) continue;
+  for (int ps = 0; ps < C::APASS; ++ps) {
+    const int m = m0 + ps * 32 + lrow;
     const int n = m >> p.logOHW;
     const int rem = m & ((1 << p.logOHW) - 1);
-    const long long off0 = (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY +
-                           (long long)(rem & ((1 << p.logOW) - 1)) * p.osX;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
-      if (ch >= p.NchStore) continue;
-      long long off = off0 + p.obase[z] + (long long)zraw * p.out_split_stride;
-      if (p.rows_are_phases) { off = off0 + p.obase[ch >> 2]; ch = 0; }
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.bias[ch + r];
-      }
-      if (p.epi == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-      }
-      if (p.out_f32) st4(reinterpret_cast<float*>(p.out) + off + ch, v);
-      else st4(outp + off + ch, v);
-    }
+    const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
+    rowoff[ps] = p.act_row_elems ? (unsigned)m * (unsigned)p.act_row_elems * 2u
+                                 : ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC)) * 2u;
+    riy[ps] = m < p.M ? iy0 : 0x40000000;
+    rix[ps] = ix0;
   }
+  unsigned wrowoff[C::WPASS];
+#pragma unroll
+  for (int ps = 0; ps < C::WPASS; ++ps)
+    wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + lrow) * p.K) * 2);
+  const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
+  const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+  const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page);
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nk = p.K / IG_BK;
+  // k-steps past the end re-load the last tile into a stage nobody reads: no predicate, no branch, exact vmcnt arithmetic
+  auto issue = [&](int kc, int stage) {
+    const int kbase = min(kc, nk - 1) * IG_BK;
+    unsigned char* sb = lds + stage * STG_BYTES + wave * (8 * LD * 2);           // this wave's 8 rows of each 32-row pass
+#pragma unroll
+    for (int ps = 0; ps < C::WPASS; ++ps) {
+      const unsigned char* src = wb + (wrowoff[ps] + (unsigned)kbase * 2u + src_chunk);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
+    }
+    const int t = __builtin_amdgcn_readfirstlane(p.act_row_elems ? 0 : (kbase >> p.logC));
+    const int tp = p.tap[z][t];
+    const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
+    const unsigned toffb = p.act_row_elems ? (unsigned)kbase * 2u
+                                           : (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
+#pragma unroll
+    for (int ps = 0; ps < C::APASS; ++ps) {
+      const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
+      const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+    }
+  };
+
+  const int wch = (C::WCH == 2) ? (wave >> 1) : 0;
+  const int wpix = (C::WCH == 2) ? (wave & 1) : wave;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int sw = ((lane & 15) >> 1) & 7;
+  auto compute = [&](int stage) {
+    const bf16_t* wt0 = reinterpret_cast<const bf16_t*>(lds + stage * STG_BYTES);
+    const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD;
+    const bf16_t* at = wt0 + BCH * LD + (wpix * FN * 16 + (lane & 15)) * LD;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = (((lane >> 4) + ks * 4) ^ sw) * 8;
+      bf16x8 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + col);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + col);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    }
+  };
+
+  // prologue: NSTG-1 stages in flight
+#pragma unroll
+  for (int s = 0; s < NSTG - 1; ++s) issue(s, s);
+  int st_c = 0, st_i = NSTG - 1;                                    // stage to compute, stage to refill
+  for (int k = 0; k < nk; ++k) {
+    // all but the (NSTG-2) youngest stages have landed -> stage k is in LDS (this wave's part); the barrier then covers
+    // every wave's part and also guarantees that everybody finished reading the stage that is refilled next
+    if constexpr (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NLD * (NSTG - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (NLD * (NSTG - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (NLD * (NSTG - 2) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (NLD * (NSTG - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(NSTG == 2 || NLD * (NSTG - 2) == 6 || NLD * (NSTG - 2) == 8 || NLD * (NSTG - 2) == 12 || NLD * (NSTG - 2) == 16, "add the vmcnt literal");
+    __builtin_amdgcn_s_barrier();
+    issue(k + NSTG - 1, st_i);
+    compute(st_c);
+    st_c = (st_c + 1 == NSTG) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dead tail loads before the epilogue reuses nothing of LDS
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
 }

@@ -99,8 +99,45 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
   return JCK_OK;
 }
 
+template <int BCH, int BPIX, int NSTG>
+static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
+  constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
+  constexpr int variant = BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
+  ProfScope prof(variant, p.flops, st);
+  auto kern = igemm_dma_kernel<BCH, BPIX, NSTG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
+  IgemmParams q = p;
+  q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
+  if (q.stats) {
+    q.ytiles_per_cset = std::max(1, q.cstat / BCH);
+    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX>::WPIX);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), LDSB, st, q);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 template <class P>
 static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
+  // bf16 tiles with >= 128 channel rows run on the LDS-DMA kernel with 2 LDS stages (64 / 48 KB -> 2-3 workgroups per CU,
+  // which hide each other's load latency): 128x128 tiles while that still gives >= 512 workgroups, else 128x64.
+  // Measured on MI355X at B=256 (tests/_micro.py, us): down2 36.2 -> 29.7, down3 43.0 -> 30.3, down4 65.8 -> 40.3,
+  // up2 47.2 -> 30.8, up3 34.5 -> 28.8; 3-4 stages at one workgroup per CU are slower.  JCK_IGEMM_DMA=0 disables.
+  static const int use_dma = getenv("JCK_IGEMM_DMA") ? atoi(getenv("JCK_IGEMM_DMA")) : 1;
+  if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && p.ksplit <= 1 && !p.rows_are_phases) {
+    const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
+    static const int f_tile = getenv("JCK_DMA_TILE") ? atoi(getenv("JCK_DMA_TILE")) : 0;     // experiments: force a configuration
+    static const int f_stg = getenv("JCK_DMA_STG") ? atoi(getenv("JCK_DMA_STG")) : 0;
+    if (f_tile == 128 && f_stg == 3) return launch_igemm_dma<128, 128, 3>(p, nch_pad, phases, st, slots);
+    if (f_tile == 64 && f_stg == 3) return launch_igemm_dma<128, 64, 3>(p, nch_pad, phases, st, slots);
+    if (f_tile == 128 || (f_tile == 0 && wgs >= 512)) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
+    return launch_igemm_dma<128, 64, 2>(p, nch_pad, phases, st, slots);
+  }
   if (nch_pad % 128 == 0) {
     if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4-channel gather with >=128 output rows unsupported");
     // keep >= ~256 workgroups in flight: halve the pixel tile for small pixel counts
@@ -110,6 +147,8 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
+    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases)
+      return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
     if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st, slots);
   }
@@ -124,6 +163,8 @@ static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, in
                                int accumulate, hipStream_t st);
 int launch_igemm(int prec, const IgemmParams& p0, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   IgemmParams p = p0;
+  for (int zz = 0; zz < 4; ++zz)
+    for (int t = 0; t < 16; ++t) p.tap[zz][t] = ((int)p.dy[zz][t] << 16) | ((int)p.dx[zz][t] & 0xffff);
   const long long esz = prec == JCK_PREC_F32 ? 4 : 2;
   if (nsub == 1 && p.logC < 6 && !p.act_row_elems) JCK_FAIL(JCK_E_ARG, "igemm: the gathered tensor needs >= 64 channels (or exactly 4)");
   {
@@ -237,7 +278,8 @@ static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
   pl.gy = cdiv(Cs, pl.BS);
   pl.CsRows = pl.gy * pl.BS;
   const int tiles = pl.gx * pl.gy;
-  long long Z = std::max(1, (tiles >= 4 ? 1024 : 256) / tiles);
+  static const int target = getenv("JCK_WGRAD_WGS") ? atoi(getenv("JCK_WGRAD_WGS")) : 256;
+  long long Z = std::max(1, (tiles >= 4 ? target : 256) / tiles);
   const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
   Z = std::min(Z, maxZ);
   long long mchunk = (Mtot + Z - 1) / Z;

@@ -79,6 +79,7 @@ PROTOS = {
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
     "jck_engine_scalars": (vp, [vp]),
+    "jck_engine_scalars_at": (vp, [vp, i32]),
     "jck_engine_sample": (i32, [vp, vp, vp, i32, vp, vp]),
     "jck_engine_tensor": (vp, [vp, C.c_char_p, C.POINTER(i64)]),
     "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),

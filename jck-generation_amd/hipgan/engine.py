@@ -6,12 +6,13 @@ them.  `named_views()` exposes every tensor under the reference's state-dict key
 (model/DCGAN.py:10-27,42-59) as a zero-copy view, so nn.Module parameters can live in the arenas.
 """
 import ctypes as C
+import os
 
 import torch
 
 from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, load_library
 
-PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP = range(5)
+PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE = range(7)
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
@@ -54,7 +55,7 @@ class DcganEngine:
         torch.cuda.set_device(self.device)
         self.prec = _PREC[prec] if share is None else share.prec
         self.batch = batch
-        self._shared = share._shared if share is not None else {"t": 0, "version": 0}
+        self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
         self._packed_version = -1
         h = C.c_void_p()
         dll = load_library()
@@ -102,7 +103,8 @@ class DcganEngine:
 
     # ---- state ------------------------------------------------------------------------------------------
     def named_views(self, tag, what="params"):
-        """{state-dict key: view}. what: 'params' (incl. BN buffers), 'grads', 'm', 'v'."""
+        """{state-dict key: view}. what: 'params' (incl. BN buffers), 'grads', 'm', 'v'.  (Call join() first when a step
+        may still be in flight and the views are about to be read.)"""
         out = {}
         bn_i = 0
         for name, kind, off, numel, shp in self.layout[tag]:
@@ -117,6 +119,7 @@ class DcganEngine:
 
     def load_state(self, g_state, d_state):
         """Copies reference-keyed state dicts (CPU or device tensors) into the arenas and re-derives the bf16 operands."""
+        self.join()
         for tag, sd in (("g", g_state), ("d", d_state)):
             views = self.named_views(tag)
             for k, v in sd.items():
@@ -127,6 +130,7 @@ class DcganEngine:
         self.repack()
 
     def state_dicts(self):
+        self.join()
         order = lambda tag: {k: v.detach().cpu().clone() for k, v in self._ordered(tag)}
         return order("g"), order("d")
 
@@ -221,42 +225,93 @@ class DcganEngine:
                 nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
         return nz
 
-    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0):
-        """Enqueues one full step on the current stream; no host sync.  `reduce_d/reduce_g(flat_grads)` are
-        called between the loss and the optimiser phases (data-parallel gradient all-reduce)."""
+    # ---- cross-step pipeline -------------------------------------------------------------------------------
+    # The G phase of step k (D pass on the fake batch, backward into G, Adam(G), G's gradient all-reduce) runs on a second
+    # torch stream; the real-batch D pass of step k+1 does not depend on it and starts at once on the caller's stream.
+    def _g_stream(self):
+        if self._shared["g_stream"] is None:
+            self._shared["g_stream"] = torch.cuda.Stream(device=self.device)
+        return self._shared["g_stream"]
+
+    def join(self):
+        """Makes the current stream wait for a G phase still in flight (call before reading weights, scalars, ...)."""
+        gs = self._shared["g_stream"]
+        if gs is not None:
+            torch.cuda.current_stream().wait_stream(gs)
+
+    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None):
+        """Enqueues one full step; no host sync.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
+        optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
+        env JCK_PIPELINE=1 enables): run the G phase - with G's gradient all-reduce - on a second stream so that the next
+        step's D(real) pass overlaps it.  On one GPU the in-step overlap already saturates the memory system and the
+        pipeline measured 8 % slower; it exists for the multi-GPU case where it hides the G all-reduce."""
+        if pipeline is None:
+            pipeline = self.family == 0 and os.environ.get("JCK_PIPELINE", "0") == "1"
         noise = noise if noise is not None else self.draw_noise()
         if self._packed_version != self._shared["version"]:
+            self.join()
             self.repack()
         si, keep = self._inputs(real, noise, lr, grad_scale)
-        st = cur_stream()
+        main = torch.cuda.current_stream()
+        st = main.cuda_stream
         h = self._h
-        lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
+        if pipeline:
+            gs = self._g_stream()
+            lib.jck_engine_phase(h, PHASE_D_REAL, C.byref(si), st)     # beside the previous step's G phase
+            main.wait_stream(gs)                                       # G weights of the previous step are final
+            lib.jck_engine_phase(h, PHASE_D_FAKE, C.byref(si), st)
+        else:
+            self.join()
+            lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
         if self.family == 0:
             handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
-            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # overlaps the D all-reduce (no gradients in DCGAN)
+            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
         else:                                                      # CGAN back-propagates the penalty: reduce after it
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
             handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
         if handle is not None:
             handle()
         lib.jck_engine_phase(h, PHASE_D_STEP, C.byref(si), st)
-        lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
-        handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
-        if handle is not None:
-            handle()
-        lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
+        if pipeline:
+            gs.wait_stream(main)
+            with torch.cuda.stream(gs):
+                lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), gs.cuda_stream)
+                handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+                if handle is not None:
+                    handle()
+                lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), gs.cuda_stream)
+        else:
+            lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
+            handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+            if handle is not None:
+                handle()
+            lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1
+        self._shared["last_step"] = self.t
         self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
         self._packed_version = self._shared["version"]
         self._keep = keep
 
-    def scalars_view(self):
-        """Device view (float32[8]) of the step scalars - no sync."""
-        return self._ws_view(load_library().jck_engine_scalars(self._h), 8, torch.float32)
+    def record_scalars(self, dst_row):
+        """Copies the step scalars (device float[8]) into `dst_row` on the stream that produced them - no host sync and no
+        stall of the next step's D pass."""
+        gs = self._shared["g_stream"]
+        src = self.scalars_view(joined=False)
+        if gs is None:
+            dst_row.copy_(src, non_blocking=True)
+        else:
+            with torch.cuda.stream(gs):
+                dst_row.copy_(src, non_blocking=True)
+
+    def scalars_view(self, joined=True):
+        """Device view (float32[8]) of the last step's scalars - no host sync (the current stream joins the G phase)."""
+        if joined:
+            self.join()
+        return self._ws_view(load_library().jck_engine_scalars_at(self._h, self._shared["last_step"]), 8, torch.float32)
 
     def scalars(self):
         """Host copy of the eight step scalars (one device->host sync)."""
-        vals = self._ws_view(load_library().jck_engine_scalars(self._h), 8, torch.float32).cpu().tolist()
+        vals = self.scalars_view().cpu().tolist()
         return dict(zip(SCALAR_NAMES, vals))
 
     def _ws_view(self, ptr, numel, dtype):
@@ -278,6 +333,7 @@ class DcganEngine:
         if n > self.batch:
             raise JckError(f"sample: {n} latent vectors exceed this engine's batch {self.batch}; bind an engine with batch >= n "
                            f"(DcganEngine(batch=n, share=engine))")
+        self.join()
         if self._packed_version != self._shared["version"]:
             self.repack()
         out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
@@ -293,6 +349,7 @@ class DcganEngine:
 
     def tensor(self, name):
         """Debug/parity view of an internal NHWC tensor as a torch tensor (copy)."""
+        self.join()
         n = C.c_longlong()
         p = load_library().jck_engine_tensor(self._h, name.encode(), C.byref(n))
         if not p:

@@ -72,6 +72,7 @@ class CGANTrainer(DCGANTrainer):
     def save_model(self, typ, iters, inception_score, fid, intra_fid, images):
         if self.rank != 0:
             return
+        self.engine.join()                      # the G phase of the last step may still be in flight on its stream
         save_path = os.path.join(self.model_save_path, typ)
         os.makedirs(save_path, exist_ok=True)
         for filename in os.listdir(save_path):
@@ -179,7 +180,7 @@ class CGANTrainer(DCGANTrainer):
                 else:
                     noise = eng.draw_noise(labels=labels)
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
-                history[iters].copy_(eng.scalars_view(), non_blocking=True)
+                eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:
                     s = eng.scalars()
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"

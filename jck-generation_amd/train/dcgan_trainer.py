@@ -137,6 +137,7 @@ class DCGANTrainer(Trainer):
     def save_model(self, typ, iters, value, images):
         if self.rank != 0:
             return
+        self.engine.join()                      # the G phase of the last step may still be in flight on its stream
         save_path = os.path.join(self.model_save_path, typ)
         os.makedirs(save_path, exist_ok=True)
         for filename in os.listdir(save_path):
@@ -217,7 +218,7 @@ class DCGANTrainer(Trainer):
                     noise = {"n1": torch.randn(b, 3, 64, 64), "z": torch.randn(b, 100, 1, 1), "n2": torch.randn(b, 3, 64, 64),
                              "alpha": torch.rand(b, 1, 1, 1)}
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
-                history[iters].copy_(eng.scalars_view(), non_blocking=True)
+                eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:
                     s = eng.scalars()                                # the only host sync of the iteration
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
@@ -225,6 +226,7 @@ class DCGANTrainer(Trainer):
                 if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
                     self._evaluate(fixed_noise, iters, best)
                 iters += 1
+        self.engine.join()
         torch.cuda.synchronize()
         end = time.time()
         self.logger.debug(f"train finish\ttiem: {time_to_str(end - start)}")
