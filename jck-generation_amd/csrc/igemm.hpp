@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // linearly, so the bank swizzle (chunk ^= (row >> 1) & 7) is applied to the per-lane SOURCE address; out-of-image taps
 // and rows past M read a 16-byte zero page instead.  Same tile geometry, fragment reads and epilogue as igemm_kernel.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
+static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
 
 template <int BCH, int BPIX, int NSTG>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {

@@ -283,7 +283,7 @@ static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
   const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
   Z = std::min(Z, maxZ);
   long long mchunk = (Mtot + Z - 1) / Z;
-  mchunk = (mchunk + WG_BKP - 1) / WG_BKP * WG_BKP;
+  mchunk = (mchunk + 63) / 64 * 64;            // multiple of both k-step sizes (32 register-staged, 64 LDS-DMA)
   Z = (Mtot + mchunk - 1) / mchunk;
   pl.Z = (int)Z; pl.mchunk = (int)mchunk;
   pl.ws = (size_t)Z * pl.CsRows * ncols * sizeof(float);
@@ -306,8 +306,25 @@ static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t
   return JCK_OK;
 }
 
+static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  constexpr int LDSB = 2 * 2 * WGD_BKP * 256;
+  ProfScope prof(10, p.flops, st);
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(pl.gx, pl.gy, pl.Z), dim3(256), LDSB, st, p);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 template <class P>
 static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, hipStream_t st) {
+  static const int use_dma = getenv("JCK_WGRAD_DMA") ? atoi(getenv("JCK_WGRAD_DMA")) : 1;
+  if (use_dma && !P::IS_F32 && pl.BG == 128 && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
+      pl.mchunk % WGD_BKP == 0)
+    return launch_wgrad_dma(p, pl, st);
   if (pl.BG == 128 && pl.BS == 128 && nsub == 1) return launch_wgrad_t<P, 128, 128, 1>(p, pl, st);
   if (pl.BG == 128 && pl.BS == 64 && nsub == 1) return launch_wgrad_t<P, 128, 64, 1>(p, pl, st);
   if (pl.BG == 64 && pl.BS == 64 && nsub == 2) return launch_wgrad_t<P, 64, 64, 2>(p, pl, st);

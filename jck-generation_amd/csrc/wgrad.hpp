@@ -259,3 +259,135 @@ static __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float*
   if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
   *reinterpret_cast<f32x4*>(dst) = o;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128x128 bf16 weight-gradient tile: both operand tiles ([64 pixels][128 channels], 256-byte rows)
+// go global -> LDS with global_load_lds_dwordx4 (1 KiB = 4 pixel rows per wave-instruction), two LDS stages of 32 KB
+// (several workgroups per CU hide each other's latency), raw s_barrier + s_waitcnt vmcnt(0) per 64-pixel k-step.
+// Rows are unpadded; the 16-byte chunk index is XORed with ((row & 3) << 2) | ((row >> 2) & 3) on the SOURCE side and
+// in the ds_read_b64_tr_b16 address (the guide's 256-byte-row image that serves transposed reads without conflicts).
+// Out-of-image taps / pixels past the split read a zero page.  Requires Cb >= 64 (a 128-column tile spans <= 2 taps).
+// ------------------------------------------------------------------------------------------------------------------
+static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page_w[64];
+
+#define WGD_BKP 64
+static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
+  constexpr int BG = 128, BS = 128, FM = 4, FN = 4;
+  constexpr int ROWB = 256;                                          // bytes per tile row (128 bf16)
+  constexpr int TILE_BYTES = WGD_BKP * ROWB;                         // 16 KB per operand tile
+  constexpr int STG_BYTES = 2 * TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* lds = smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g0 = blockIdx.x * BG, s0 = blockIdx.y * BS;
+  const int mz0 = blockIdx.z * p.mchunk;
+  const int mz1 = min(mz0 + p.mchunk, p.Mtot);
+  const unsigned char* bigb = reinterpret_cast<const unsigned char*>(p.big);
+  const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(p.sside);
+  const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page_w);
+  const int Cb = 1 << p.logCb;
+
+  // this lane's place inside a wave-instruction: 4 rows x 16 chunks
+  const int r4 = lane >> 4, pc = lane & 15;
+  // the tile's first tap and (when Cb == 64) the next one
+  const int t_base = g0 >> p.logCb;
+  const int cb_base = g0 & (Cb - 1);
+  const int tA = min(t_base, p.ntaps - 1), tB = min(t_base + 1, p.ntaps - 1);
+  const int dyA = p.dy[tA], dxA = p.dx[tA], dyB = p.dy[tB], dxB = p.dx[tB];
+  const bool tvA = t_base < p.ntaps, tvB = t_base + 1 < p.ntaps;
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue = [&](int mbase, int stage) {
+    unsigned char* gt = lds + stage * STG_BYTES;
+    unsigned char* st = gt + TILE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 16 + wave * 4 + r4;                          // 0..63 inside the tile
+      const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));      // logical 16-byte chunk fetched by this lane
+      const int m = mbase + row;
+      const bool rok = m < mz1;
+      const int n = m >> p.logOHW;
+      const int rem = m & ((1 << p.logOHW) - 1);
+      const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
+      // gathered side: column g0 + lc*8 -> (tap, cb)
+      const int col = cb_base + lc * 8;
+      const bool second = col >= Cb;                                   // only when Cb == 64
+      const int dyv = second ? dyB : dyA, dxv = second ? dxB : dxA;
+      const bool tv = second ? tvB : tvA;
+      const int cb = second ? col - Cb : col;
+      const int iy = iy0 + dyv, ix = ix0 + dxv;
+      const bool ok = rok && tv && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const long long goff = ((((long long)n * p.H + iy) * p.W + ix) << p.logCb) + cb;
+      const unsigned char* gsrc = ok ? bigb + goff * 2 : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(gt + (q * 16 + wave * 4) * ROWB), 16, 0, 0);
+      const bool sok = rok && (s0 + lc * 8 < p.CsStride);
+      const unsigned char* ssrc = sok ? sb_ + ((long long)m * p.CsStride + s0 + lc * 8) * 2 : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)ssrc, (lptr_t)(st + (q * 16 + wave * 4) * ROWB), 16, 0, 0);
+    }
+  };
+
+  const int wg = wave >> 1, ws = wave & 1;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: group g = lane>>4 covers pixels 8g..8g+7 of a 32-pixel sub-step; lane il = lane&15 supplies
+  // &tile[row][col0 + 4*(il&3)] with row = 8g + (il>>2) (+4 for the second read) and receives column col0 + il.
+  const int il = lane & 15;
+  auto tr_addr = [&](const unsigned char* tile, int row, int col0) -> const bf16_t* {
+    const int chunk = (col0 >> 3) + ((il & 3) >> 1);
+    const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+    return reinterpret_cast<const bf16_t*>(tile + row * ROWB + ((chunk ^ f) << 4) + ((il & 1) << 3));
+  };
+  auto compute = [&](int stage) {
+    const unsigned char* gt = lds + stage * STG_BYTES;
+    const unsigned char* st = gt + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < WGD_BKP / 32; ++kk) {
+      const int row = kk * 32 + (lane >> 4) * 8 + (il >> 2);
+      bf16x8 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int c0 = wg * 64 + i * 16;
+        a[i] = join_tr(lds_tr4(tr_addr(gt, row, c0)), lds_tr4(tr_addr(gt, row + 4, c0)));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c0 = ws * 64 + j * 16;
+        b[j] = join_tr(lds_tr4(tr_addr(st, row, c0)), lds_tr4(tr_addr(st, row + 4, c0)));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    }
+  };
+
+  const int nk = (mz1 > mz0) ? (mz1 - mz0 + WGD_BKP - 1) / WGD_BKP : 0;
+  issue(mz0, 0);                                                      // rows past mz1 read the zero page
+  for (int k = 0; k < nk; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(mz0 + (k + 1) * WGD_BKP, (k + 1) & 1);                      // past the end: all zero page, never read
+    compute(k & 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* part = p.part + (long long)blockIdx.z * p.CsRows * p.ncols;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int cs = s0 + ws * 64 + j * 16 + (lane & 15);
+    if (cs >= p.CsRows) continue;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int col = g0 + wg * 64 + i * 16 + (lane >> 4) * 4;
+      if (col >= p.ncols) continue;
+      *reinterpret_cast<f32x4*>(part + (long long)cs * p.ncols + col) = acc[i][j];
+    }
+  }
+}
