@@ -54,11 +54,17 @@ def pmc_traffic(kernel):
     if not m:
         return None
     kind, prec, a, b, img = m.groups()
-    pat = f"{kind}_kernel<{'PrecBf16' if prec == 'bf16' else 'PrecF32'}, {a}, {b}, {2 if img else 1}"
-    for name, v in tr.items():
+    # the profiler's variant label -> the kernel symbol rocprofv3 reports: LDS-DMA variants first (bf16 only), then the
+    # register-staged templates
+    pats = []
+    if prec == "bf16" and not img and (kind == "igemm" or (a, b) == ("128", "128")):
+        pats.append(f"igemm_dma_kernel<{a}, {b}, " if kind == "igemm" else "wgrad_dma_kernel")
+    pats.append(f"{kind}_kernel<{'PrecBf16' if prec == 'bf16' else 'PrecF32'}, {a}, {b}, {2 if img else 1}")
+    for pat in pats:
+      for name, v in tr.items():
         if pat in name:
-            return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
-                    "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
+          return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
+                  "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
     return None
 
 
