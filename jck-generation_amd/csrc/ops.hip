@@ -1,5 +1,6 @@
 // C-ABI launchers for the per-op entry points of include/jckgan.h (host side; kernels in *.hpp).
 #include "ops_internal.hpp"
+#include "thin.hpp"
 
 #include <cstdlib>
 #include <string>
@@ -33,7 +34,7 @@ const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "
                                   "igemm<bf16,16,256>",  "igemm<f32,128,128>", "igemm<f32,128,64>",      "igemm<f32,64,128,img>",
                                   "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
                                   "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
-                                  "wgrad<f32,64,64,img>", "wgrad<f32,64,64>"};
+                                  "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>"};
 struct ProfScope {
   ProfRec r; bool on; hipStream_t st;
   ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
@@ -188,6 +189,42 @@ extern "C" size_t jck_stats_floats(long long pixels, int C, int nyrep) {
 }
 extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)elems * (prec == JCK_PREC_F32 ? 4 : 2); }
 
+// image-side layers on the streaming kernels of thin.hpp (bf16, 64 channels on the wide side, row length % 16 == 0)
+static const int g_use_thin = getenv("JCK_THIN") ? atoi(getenv("JCK_THIN")) : 1;
+#define IMG_GPW 8
+static int launch_img_down(const void* x, const void* w, void* out, float* stats, int* slots, int N, int Hb, int Wb, double flops,
+                           hipStream_t st) {
+  ImgDownParams q = {};
+  const int OH = Hb / 2, OW = Wb / 2;
+  q.x = x; q.w = w; q.out = out; q.stats = stats;
+  q.ngroups = N * OH * (OW / 16); q.H = Hb; q.W = Wb; q.logOH = ilog2(OH); q.logG = ilog2(OW / 16);
+  q.x_bytes = (unsigned)((long long)N * Hb * Wb * 4 * 2);
+  static const int gpw = getenv("JCK_IMG_GPW") ? atoi(getenv("JCK_IMG_GPW")) : IMG_GPW;
+  const int grid = cdiv(q.ngroups, 4 * gpw);
+  if (stats) {
+    if (!slots) JCK_FAIL(JCK_E_ARG, "conv_down: stats requested without a slot-count output");
+    *slots = grid;
+  }
+  ProfScope prof(18, flops, st);
+  if (gpw == 2) hipLaunchKernelGGL(img_down_kernel<2>, dim3(grid), dim3(256), 0, st, q);
+  else if (gpw == 4) hipLaunchKernelGGL(img_down_kernel<4>, dim3(grid), dim3(256), 0, st, q);
+  else if (gpw == 16) hipLaunchKernelGGL(img_down_kernel<16>, dim3(grid), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL(img_down_kernel<IMG_GPW>, dim3(grid), dim3(256), 0, st, q);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+#define IMG_UP_R 8
+static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, int N, int Hs, int Ws, double flops, hipStream_t st) {
+  ImgUpParams q = {};
+  q.a = a; q.w = w; q.out = out; q.epi_tanh = epi_tanh;
+  q.nunits = N * (Hs / IMG_UP_R) * (Ws / 16); q.Hs = Hs; q.Ws = Ws; q.logYB = ilog2(Hs / IMG_UP_R); q.logG = ilog2(Ws / 16);
+  q.a_bytes = (unsigned)((long long)N * Hs * Ws * 64 * 2);
+  ProfScope prof(19, flops, st);
+  hipLaunchKernelGGL(img_up_kernel<IMG_UP_R>, dim3(cdiv(q.nunits, 4)), dim3(256), 0, st, q);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                              int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
   const int cbp = jck_pad_chan(Cb);
@@ -204,6 +241,8 @@ extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* sma
   p.cstat = Cs; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
   if (stats && !is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
+  if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH))
+    return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream);
   return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream, stats_slots);
 }
 
@@ -229,6 +268,8 @@ extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* 
     p.osN = (long long)4 * Hs * Ws * cbp; p.osY = 2 * 2 * Ws * cbp; p.osX = 2 * cbp;
     p.cstat = 4; p.ytiles_per_cset = 1; p.epi = epi_tanh ? 1 : 0; p.w_phase_stride = 0;
     p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
+    if (g_use_thin && prec == JCK_PREC_BF16 && Cs == 64 && Ws % 16 == 0 && Hs % IMG_UP_R == 0)
+      return launch_img_up(small_in, w, big_out, epi_tanh ? 1 : 0, N, Hs, Ws, p.flops, (hipStream_t)stream);
     return launch_igemm(prec, p, 16, 1, 1, (hipStream_t)stream, nullptr);
   }
   static const int DI[2][2] = {{0, -1}, {1, 0}};          // input offset of tap th for output parity ph

@@ -219,19 +219,24 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int Z
   }
 }
 
-// image layers (CbPad = 4, ncols = 64): one workgroup per cs row; 64 columns x 4 slab lanes, LDS reduce over the lanes
+// image layers (CbPad = 4, ncols = 64): one workgroup per cs row; 16 float4 columns x 16 slab lanes (every thread keeps
+// Z/16 independent 16-byte loads in flight), LDS reduce over the slab lanes
 static __global__ __launch_bounds__(256) void wgrad_reduce_img_kernel(const float* __restrict__ part, int Z, int CsRows, int Cb,
                                                                       float* __restrict__ grad, int accumulate) {
-  __shared__ float red[4][64];
-  const int cs = blockIdx.x, col = threadIdx.x & 63, zl = threadIdx.x >> 6;
-  float s = 0.f;
-  for (int z = zl; z < Z; z += 4) s += part[((long long)z * CsRows + cs) * 64 + col];
-  red[zl][col] = s;
+  __shared__ float red[16][64];
+  const int cs = blockIdx.x, c4 = (threadIdx.x & 15) * 4, zl = threadIdx.x >> 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int z = zl; z < Z; z += 16) s += *reinterpret_cast<const f32x4*>(part + ((long long)z * CsRows + cs) * 64 + c4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[zl][c4 + k] = s[k];
   __syncthreads();
-  if (zl == 0) {
-    const int t = col >> 2, cb = col & 3;
+  if (threadIdx.x < 64) {
+    const int col = threadIdx.x, t = col >> 2, cb = col & 3;
     if (cb < Cb) {
-      const float v = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v += red[k][col];
       float* d = grad + ((long long)cs * Cb + cb) * 16 + t;
       *d = accumulate ? *d + v : v;
     }

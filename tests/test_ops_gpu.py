@@ -37,7 +37,7 @@ def test_tr_read_semantics(G):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shape", [(2, 8, 64, 128), (3, 64, 3, 64), (2, 16, 128, 256), (4, 8, 256, 512), (1, 4, 64, 128),
-                                   (5, 32, 64, 128)])
+                                   (5, 32, 64, 128), (3, 32, 3, 64), (2, 128, 3, 64)])
 def test_conv_down(G, prec, shape):
     n, hb, cb, cs = shape
     g = torch.Generator().manual_seed(1)
@@ -57,7 +57,8 @@ def test_conv_down(G, prec, shape):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("shape", [(2, 4, 512, 256), (2, 8, 256, 128), (3, 16, 128, 64), (2, 32, 64, 3), (5, 4, 128, 64)])
+@pytest.mark.parametrize("shape", [(2, 4, 512, 256), (2, 8, 256, 128), (3, 16, 128, 64), (2, 32, 64, 3), (5, 4, 128, 64),
+                                   (3, 16, 64, 3), (1, 64, 64, 3)])
 def test_conv_up(G, prec, shape):
     n, hs, cs, cb = shape
     g = torch.Generator().manual_seed(2)
