@@ -113,6 +113,12 @@ int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int
                  int accumulate, void* stream);
 /* grad[1][C][4][4] (+)= dwp (packed (h,w,c) order) */
 int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream);
+/* D.conv5 backward in one launch (DCGAN engine path): g_a4[n][k] = ds[n]*wp[k] (skipped when g_a4 is NULL) and
+ * grad[c][t] += sum_n ds[n]*a4[n][t*C+c] accumulated with float atomics straight into the PyTorch-layout gradient of
+ * conv5.weight [1][C][4][4] (skipped when grad is NULL).  Replaces aten::convolution_backward behind
+ * model/DCGAN.py:26 in train/dcgan_trainer.py:164,175,187. */
+int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4, float* grad,
+                      void* stream);
 
 /* ---- CGAN pieces (model/CGAN.py:79-162, train/cgan_trainer.py:173-213) ---------------------------------------------
  * Linear layers run on the gather-GEMM kernels as plain row-major products; our activation order is NHWC, so the

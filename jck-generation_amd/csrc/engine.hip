@@ -121,7 +121,7 @@ struct jck_engine {
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
   hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
-  bool overlap = true, gp_inflight = false;
+  bool overlap = true, gp_inflight = false, defer_join = true;
   void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
@@ -241,6 +241,7 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   e->LG = make_layout(family, 0); e->LD = make_layout(family, 1);
   e->carve(nullptr);
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
+  e->defer_join = !(getenv("JCK_DEFER_JOIN") && atoi(getenv("JCK_DEFER_JOIN")) == 0);
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto p : ss) HIPCHK(hipStreamCreateWithFlags(p, hipStreamNonBlocking));
@@ -292,28 +293,50 @@ extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, 
   return JCK_OK;
 }
 
+// all conv operands of one network in one launch (ew.hpp: pack_multi_kernel); the two Linear operands of CGAN's D follow
 extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  PackJobs jobs = {};
+  int n = 0, chunk = 0;
+  auto add = [&](int kind, const float* w, void* wp, long long total, int a, int b, int c) {
+    PackJob& J = jobs.j[n];
+    J.w = w; J.wp = wp; J.total = total; J.kind = kind; J.a = a; J.b = b; J.c = c;
+    jobs.first_chunk[n] = chunk;
+    chunk += (int)((total + PACK_CHUNK - 1) / PACK_CHUNK);
+    ++n;
+  };
+  auto add_down = [&](const float* w, int Cs, int Cb, void* wp) {
+    const int cbp = jck_pad_chan(Cb), rows = jck_pad_rows(Cs);
+    add(0, w, wp, (long long)rows * 16 * cbp, Cs, Cb, ilog2(cbp));
+  };
+  auto add_up = [&](const float* w, int Cs, int Cb, void* wp) {
+    if (Cb <= 4) add(2, w, wp, 16ll * 9 * Cs, Cs, Cb, 0);
+    else add(1, w, wp, 4ll * jck_pad_rows(Cb) * 4 * Cs, Cs, Cb, jck_pad_rows(Cb));
+  };
   if (net == 1) {
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LD, e->dp, NAMES_CW[i]);
-      JCK_TRY(jck_pack_down(e->prec, w, D_CS[i], D_CB[i], e->d_down[i], stream));
-      JCK_TRY(jck_pack_up(e->prec, w, D_CS[i], D_CB[i], e->d_up[i], stream));
+      add_down(w, D_CS[i], D_CB[i], e->d_down[i]);
+      add_up(w, D_CS[i], D_CB[i], e->d_up[i]);
     }
-    if (e->family == 0) {
-      JCK_TRY(jck_pack_head(e->P(e->LD, e->dp, NAMES_CW[4]), 512, e->d_head_wp, stream));
-    } else {
-      const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
-      JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
-      JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
-    }
+    if (e->family == 0) add(4, e->P(e->LD, e->dp, NAMES_CW[4]), e->d_head_wp, 16ll * 512, 512, 0, 0);
   } else {
-    JCK_TRY(jck_pack_g1(e->prec, e->P(e->LG, e->gp, NAMES_CW[0]), z_dim(e->family), G_C1, z_pad(e->family), e->g1_w, stream));
+    add(3, e->P(e->LG, e->gp, NAMES_CW[0]), e->g1_w, 16ll * G_C1 * z_pad(e->family), z_dim(e->family), G_C1, z_pad(e->family));
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
-      JCK_TRY(jck_pack_up(e->prec, w, G_CS[i], G_CB[i], e->g_up[i], stream));
-      JCK_TRY(jck_pack_down(e->prec, w, G_CS[i], G_CB[i], e->g_down[i], stream));
+      add_up(w, G_CS[i], G_CB[i], e->g_up[i]);
+      add_down(w, G_CS[i], G_CB[i], e->g_down[i]);
     }
+  }
+  jobs.first_chunk[n] = chunk;
+  jobs.n = n;
+  if (e->prec == JCK_PREC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
+  else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
+  HIPCHK(hipGetLastError());
+  if (net == 1 && e->family == 1) {
+    const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
+    JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
+    JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
   }
   return JCK_OK;
 }
@@ -344,17 +367,6 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
   return JCK_OK;
 }
 
-static int d_apply_running_stats(jck_engine* e, int npass, hipStream_t st) {
-  for (int i = 0; i < 4; ++i) {
-    const int cs = D_CS[i];
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(cs, 256)), dim3(256), 0, st, e->d_rs[i] + (size_t)e->parity * 4 * 2 * cs, npass, (long long)2 * cs, BN_MOM,
-                       e->dbn + find(e->LD, NAMES_RM[i])->offset, e->dbn + find(e->LD, NAMES_RV[i])->offset,
-                       (long long*)(e->dnbt + i), cs);
-    HIPCHK(hipGetLastError());
-  }
-  return JCK_OK;
-}
-
 // D forward up to (not including) the sigmoid head.  family 1: concat + Linear(8392,256) + Dropout (model/CGAN.py:117-122)
 static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
   JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st));
@@ -380,11 +392,8 @@ static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slo
 
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
 static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
-  if (e->family == 0) {
-    JCK_TRY(jck_head_bwd(e->prec, ds, e->d_head_wp, D.a[3], B, FEAT, ga4_out, want_wgrad ? e->d_head_dwp : nullptr, 0, st));
-    if (want_wgrad) JCK_TRY(jck_head_unpack_grad(e->d_head_dwp, 512, e->P(e->LD, e->dg, NAMES_CW[4]), 1, st));
-    return JCK_OK;
-  }
+  if (e->family == 0)
+    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[3], B, 512, ga4_out, want_wgrad ? e->P(e->LD, e->dg, NAMES_CW[4]) : nullptr, st);
   // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds
   JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), e->h_drop, B, L1_OUT, e->g_hd,
                        want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, st));
@@ -405,7 +414,7 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
 // D backward on set `D`.  With `side` != nullptr the weight-gradient products run on that stream beside the dgrad chain
 // (both only READ gy_i and the saved activations); the main stream waits for them before returning.
 static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
-                      hipStream_t st, hipStream_t side) {
+                      hipStream_t st, hipStream_t side, bool join = true) {
   JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[3], st));
   const bool par = want_wgrad && side != nullptr;
   for (int i = 3; i >= 0; --i) {
@@ -425,7 +434,9 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     else if (want_xgrad)
       JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
-  if (par) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+  // join = false: the caller's NEXT d_backward/g_backward with a side stream (or its own join) orders the main stream
+  // behind these weight gradients - nothing on the main stream reads them before the optimiser step
+  if (par && join) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
 
@@ -582,7 +593,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         if (ov_gp && phase == JCK_PHASE_D_LOSS) HIPCHK(hipEventRecord(e->evReal, st));           // penalty pass needs only this
         JCK_TRY(d_forward(e, DR, e->real_noisy, B, 0, in->drop_mask[0], st));                      // :162
         JCK_TRY(d_head(e, DR, B, 0.9f, 0, 0, 3, st));                                             // :163,165
-        JCK_TRY(d_backward(e, DR, e->real_noisy, B, true, false, in->drop_mask[0], st, sA));       // :164 (cgan :203)
+        // D(real)'s weight gradients stay in flight on sA while D(fake) starts (own activation set); D(fake)'s backward
+        // queues behind them on sA and joins.  PHASE_D_REAL alone (pipeline mode) and CGAN (shared set) join here.
+        JCK_TRY(d_backward(e, DR, e->real_noisy, B, true, false, in->drop_mask[0], st, sA,
+                           phase == JCK_PHASE_D_REAL || cg || !e->defer_join));                                     // :164 (cgan :203)
         if (phase == JCK_PHASE_D_REAL) return JCK_OK;
       }
       // ---- D on the fake batch (:170-176) with the penalty pass (:178) beside it
@@ -631,9 +645,20 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_G_STEP: {                                                                      // :189
       JCK_TRY(jck_adam(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
-      JCK_TRY(d_apply_running_stats(e, 4, st));     // the four D passes' BatchNorm records, in the reference's order
-      hipLaunchKernelGGL(scalars_finalize_kernel, dim3(1), dim3(64), 0, st, e->acc, 1.0f / (float)B, 10.0f, e->scal_out);
-      HIPCHK(hipGetLastError());
+      {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
+        TailJobs t = {};
+        for (int i = 0; i < 4; ++i) {
+          const int cs = D_CS[i];
+          t.l[i].rec = e->d_rs[i] + (size_t)e->parity * 4 * 2 * cs;
+          t.l[i].rm = e->dbn + find(e->LD, NAMES_RM[i])->offset;
+          t.l[i].rv = e->dbn + find(e->LD, NAMES_RV[i])->offset;
+          t.l[i].nbt = (long long*)(e->dnbt + i);
+          t.l[i].C = cs;
+        }
+        t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
+        hipLaunchKernelGGL(step_tail_kernel, dim3(2, 5), dim3(256), 0, st, t);
+        HIPCHK(hipGetLastError());
+      }
       return JCK_OK;
     }
   }

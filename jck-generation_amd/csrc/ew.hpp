@@ -374,6 +374,49 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
+// D.conv5 backward in one launch: g_a4[n][k] = ds[n] * w[k] and grad(conv5.weight)[c][t] += sum_n ds[n] * a4[n][t*C + c]
+// (k = t*C + c is the packed (h,w,c) order; the sum goes straight into the PyTorch-layout gradient with float atomics, so
+// there is no scratch vector to zero and no unpack pass).  grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __restrict__ ds, const float* __restrict__ w,
+                                                             const T* __restrict__ a4, int B, int K, int C,
+                                                             T* __restrict__ g, float* __restrict__ grad) {
+  __shared__ float red[4][64][9];
+  const int u = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int k = (blockIdx.x * 64 + u) * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (k < K) {
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = w[k + j];
+    for (int n = blockIdx.y * 4 + ln; n < B; n += gridDim.y * 4) {
+      const float d = ds[n];
+      if (grad) {
+        float v[8];
+        ld8(a4 + (long long)n * K + k, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += d * v[j];
+      }
+      if (g) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = d * wv[j];
+        st8(g + (long long)n * K + k, o);
+      }
+    }
+  }
+  if (!grad) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ln][u][j] = s[j];
+  __syncthreads();
+  if (ln == 0 && k < K) {
+    const int t = k / C, c = k % C;                      // 8 consecutive k share the tap (C % 8 == 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      atomicAdd(grad + (long long)(c + j) * 16 + t, red[0][u][j] + red[1][u][j] + red[2][u][j] + red[3][u][j]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor algorithm, amsgrad=False, weight_decay=0) over a flat arena
 // ------------------------------------------------------------------------------------------------------
@@ -396,76 +439,106 @@ static __global__ void adam_kernel(float* __restrict__ p, const float* __restric
 // weight packing (fp32 PyTorch layout [Cs][Cb][4][4] -> GEMM operand layouts in bf16 (fast) or fp32 (parity))
 // ------------------------------------------------------------------------------------------------------
 // down: wp[cs][ (kh*4+kw)*CbPad + cb ]   rows cs in [0, CsPad)
+__device__ __forceinline__ float pack_down_val(const float* __restrict__ w, int Cs, int Cb, int logCbPad, long long i) {
+  const long long K = 16ll << logCbPad;
+  const int cs = (int)(i / K);
+  const int k = (int)(i % K);
+  const int t = k >> logCbPad, cb = k & ((1 << logCbPad) - 1);
+  return (cs < Cs && cb < Cb) ? w[((long long)cs * Cb + cb) * 16 + t] : 0.f;
+}
 template <typename W>
 __global__ void pack_down_kernel(const float* __restrict__ w, int Cs, int Cb, int CsPad, int logCbPad, W* __restrict__ wp) {
   const long long K = 16ll << logCbPad, total = (long long)CsPad * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int cs = (int)(i / K);
-    const int k = (int)(i % K);
-    const int t = k >> logCbPad, cb = k & ((1 << logCbPad) - 1);
-    float v = 0.f;
-    if (cs < Cs && cb < Cb) v = w[((long long)cs * Cb + cb) * 16 + t];
-    stf(wp + i, v);
-  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    stf(wp + i, pack_down_val(w, Cs, Cb, logCbPad, i));
 }
 
 // up: wp[phase][cb][ (th*2+tw)*Cs + cs ], rows cb in [0, CbPad); phase = ph*2+pw;
 // output row 2q+ph takes input rows q + DY[ph][th] through kernel rows KH[ph][th]
 static __device__ __constant__ int c_up_k[2][2] = {{1, 3}, {0, 2}};
+__device__ __forceinline__ float pack_up_val(const float* __restrict__ w, int Cs, int Cb, int CbPad, long long i) {
+  const long long K = 4ll * Cs, per = (long long)CbPad * K;
+  const int phase = (int)(i / per);
+  const long long r = i % per;
+  const int cb = (int)(r / K);
+  const int k = (int)(r % K);
+  const int t = k / Cs, cs = k % Cs;
+  const int kh = c_up_k[phase >> 1][t >> 1], kw = c_up_k[phase & 1][t & 1];
+  return cb < Cb ? w[((long long)cs * Cb + cb) * 16 + kh * 4 + kw] : 0.f;
+}
 template <typename W>
 __global__ void pack_up_kernel(const float* __restrict__ w, int Cs, int Cb, int CbPad, W* __restrict__ wp) {
-  const long long K = 4ll * Cs, per = (long long)CbPad * K, total = 4 * per;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int phase = (int)(i / per);
-    const long long r = i % per;
-    const int cb = (int)(r / K);
-    const int k = (int)(r % K);
-    const int t = k / Cs, cs = k % Cs;
-    const int kh = c_up_k[phase >> 1][t >> 1], kw = c_up_k[phase & 1][t & 1];
-    float v = 0.f;
-    if (cb < Cb) v = w[((long long)cs * Cb + cb) * 16 + kh * 4 + kw];
-    stf(wp + i, v);
-  }
+  const long long total = 4ll * CbPad * 4 * Cs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    stf(wp + i, pack_up_val(w, Cs, Cb, CbPad, i));
 }
 
 // up, 3/4-channel output (G.conv5, dgrad of D.conv1): all four output parities in ONE 16-row operand,
 // wp[phase*4 + c][ (dyi*3+dxi)*Cs + cs ] over the 9 input offsets dy,dx in {-1,0,1}; unused (phase, offset) pairs are 0
+__device__ __forceinline__ float pack_up16_val(const float* __restrict__ w, int Cs, int Cb, long long i) {
+  const long long K = 9ll * Cs;
+  const int r = (int)(i / K), k = (int)(i % K);
+  const int phase = r >> 2, c = r & 3, t9 = k / Cs, cs = k % Cs;
+  const int dy = t9 / 3 - 1, dx = t9 % 3 - 1, ph = phase >> 1, pw = phase & 1;
+  // output row 2q+ph reads input row q+dy through kernel row kh:  ph=0: (0 -> 1), (-1 -> 3);  ph=1: (+1 -> 0), (0 -> 2)
+  const int kh = ph == 0 ? (dy == 0 ? 1 : (dy == -1 ? 3 : -1)) : (dy == 1 ? 0 : (dy == 0 ? 2 : -1));
+  const int kw = pw == 0 ? (dx == 0 ? 1 : (dx == -1 ? 3 : -1)) : (dx == 1 ? 0 : (dx == 0 ? 2 : -1));
+  return (c < Cb && kh >= 0 && kw >= 0) ? w[((long long)cs * Cb + c) * 16 + kh * 4 + kw] : 0.f;
+}
 template <typename W>
 __global__ void pack_up16_kernel(const float* __restrict__ w, int Cs, int Cb, W* __restrict__ wp) {
-  const long long K = 9ll * Cs, total = 16 * K;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(i / K), k = (int)(i % K);
-    const int phase = r >> 2, c = r & 3, t9 = k / Cs, cs = k % Cs;
-    const int dy = t9 / 3 - 1, dx = t9 % 3 - 1, ph = phase >> 1, pw = phase & 1;
-    // output row 2q+ph reads input row q+dy through kernel row kh:  ph=0: (0 -> 1), (-1 -> 3);  ph=1: (+1 -> 0), (0 -> 2)
-    const int kh = ph == 0 ? (dy == 0 ? 1 : (dy == -1 ? 3 : -1)) : (dy == 1 ? 0 : (dy == 0 ? 2 : -1));
-    const int kw = pw == 0 ? (dx == 0 ? 1 : (dx == -1 ? 3 : -1)) : (dx == 1 ? 0 : (dx == 0 ? 2 : -1));
-    float v = 0.f;
-    if (c < Cb && kh >= 0 && kw >= 0) v = w[((long long)cs * Cb + c) * 16 + kh * 4 + kw];
-    stf(wp + i, v);
-  }
+  const long long total = 16 * 9ll * Cs;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    stf(wp + i, pack_up16_val(w, Cs, Cb, i));
 }
 
 // G.conv1 (ConvTranspose on a 1x1 input): wp[(kh*4+kw)*Co + co][ci], ci in [0, CiPad)
+__device__ __forceinline__ float pack_g1_val(const float* __restrict__ w, int Ci, int Co, int CiPad, long long i) {
+  const int ci = (int)(i % CiPad);
+  const long long r = i / CiPad;
+  const int co = (int)(r % Co), t = (int)(r / Co);
+  return ci < Ci ? w[((long long)ci * Co + co) * 16 + t] : 0.f;
+}
 template <typename W>
 __global__ void pack_g1_kernel(const float* __restrict__ w, int Ci, int Co, int CiPad, W* __restrict__ wp) {
   const long long total = 16ll * Co * CiPad;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % CiPad);
-    const long long r = i / CiPad;
-    const int co = (int)(r % Co), t = (int)(r / Co);
-    float v = 0.f;
-    if (ci < Ci) v = w[((long long)ci * Co + co) * 16 + t];
-    stf(wp + i, v);
-  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    stf(wp + i, pack_g1_val(w, Ci, Co, CiPad, i));
 }
 
-// D.conv5 weight [1][512][4][4] -> f32 vector in (h, w, c) order
+// D.conv5 (a dot product per image): wp[(kh*4+kw)*C + c] fp32
 static __global__ void pack_head_kernel(const float* __restrict__ w, int C, float* __restrict__ wp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 16 * C) return;
   const int t = i / C, c = i % C;
   wp[i] = w[c * 16 + t];
+}
+
+// Every packed operand of one network in ONE launch (the optimiser step is followed by 9-10 repacks; as separate launches
+// their ~4.5 us floor each left the GPU idle for ~45 us twice per step).  Jobs are cut into 2048-element chunks; a
+// workgroup finds its job from the chunk prefix table.
+#define PACK_MAX_JOBS 12
+#define PACK_CHUNK 2048
+struct PackJob { const float* w; void* wp; long long total; int kind, a, b, c; };   // kind: 0 down 1 up 2 up16 3 g1 4 head
+struct PackJobs { PackJob j[PACK_MAX_JOBS]; int first_chunk[PACK_MAX_JOBS + 1]; int n; };
+template <typename W>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_chunk[ji + 1]) ++ji;
+  const PackJob& J = jobs.j[ji];
+  const long long base = (long long)(blockIdx.x - jobs.first_chunk[ji]) * PACK_CHUNK;
+#pragma unroll
+  for (int u = 0; u < PACK_CHUNK / 256; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i >= J.total) break;
+    switch (J.kind) {
+      case 0: stf(reinterpret_cast<W*>(J.wp) + i, pack_down_val(J.w, J.a, J.b, J.c, i)); break;
+      case 1: stf(reinterpret_cast<W*>(J.wp) + i, pack_up_val(J.w, J.a, J.b, J.c, i)); break;
+      case 2: stf(reinterpret_cast<W*>(J.wp) + i, pack_up16_val(J.w, J.a, J.b, i)); break;
+      case 3: stf(reinterpret_cast<W*>(J.wp) + i, pack_g1_val(J.w, J.a, J.b, J.c, i)); break;
+      default: { const int t = (int)(i / J.a), c = (int)(i % J.a); reinterpret_cast<float*>(J.wp)[i] = J.w[c * 16 + t]; } break;
+    }
+  }
 }
 
 template <typename T>
@@ -504,6 +577,38 @@ static __global__ void scalars_finalize_kernel(const float* __restrict__ acc, fl
     out[6] = lr;
     out[7] = lf;
   }
+}
+
+// End of a step in ONE launch: the deferred BatchNorm running-stat records of D's four layers (blockIdx.y = layer, same
+// recurrence as bn_running_update_kernel) and the logged scalars (blockIdx.y = 4).
+struct TailLayer { const float* rec; float* rm; float* rv; long long* nbt; int C; };
+struct TailJobs { TailLayer l[4]; int npass; float momentum; const float* acc; float invB, lambda_gp; float* out; };
+static __global__ void step_tail_kernel(const TailJobs t) {
+  if (blockIdx.y == 4) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      const float lr = t.acc[0] * t.invB, lf = t.acc[1] * t.invB, gp = t.acc[6] * t.invB;
+      t.out[0] = (lr + lf) + t.lambda_gp * gp;
+      t.out[1] = t.acc[2] * t.invB;
+      t.out[2] = t.acc[3] * t.invB;
+      t.out[3] = t.acc[4] * t.invB;
+      t.out[4] = t.acc[5] * t.invB;
+      t.out[5] = gp;
+      t.out[6] = lr;
+      t.out[7] = lf;
+    }
+    return;
+  }
+  const TailLayer& L = t.l[blockIdx.y];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && L.nbt) *L.nbt += t.npass;
+  if (c >= L.C) return;
+  float rm = L.rm[c], rv = L.rv[c];
+  for (int p = 0; p < t.npass; ++p) {
+    rm = (1.f - t.momentum) * rm + t.momentum * L.rec[(long long)p * 2 * L.C + c];
+    rv = (1.f - t.momentum) * rv + t.momentum * L.rec[(long long)p * 2 * L.C + L.C + c];
+  }
+  L.rm[c] = rm;
+  L.rv[c] = rv;
 }
 
 // ------------------------------------------------------------------------------------------------------

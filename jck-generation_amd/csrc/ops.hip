@@ -320,7 +320,8 @@ static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
   pl.CsRows = pl.gy * pl.BS;
   const int tiles = pl.gx * pl.gy;
   static const int target = getenv("JCK_WGRAD_WGS") ? atoi(getenv("JCK_WGRAD_WGS")) : 256;
-  long long Z = std::max(1, (tiles >= 4 ? target : 256) / tiles);
+  static const int target_small = getenv("JCK_WGRAD_SMALL_WGS") ? atoi(getenv("JCK_WGRAD_SMALL_WGS")) : 512;
+  long long Z = std::max(1, (tiles >= 4 ? target : target_small) / tiles);
   const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
   Z = std::min(Z, maxZ);
   long long mchunk = (Mtot + Z - 1) / Z;
@@ -355,7 +356,9 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(pl.gx, pl.gy, pl.Z), dim3(256), LDSB, st, p);
+  WgradParams q = p;
+  q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
+  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(pl.gx * pl.gy * pl.Z), dim3(256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -590,6 +593,16 @@ extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const vo
                                         (const T*)a4, B, K, dwp));
     HIPCHK(hipGetLastError());
   }
+  return JCK_OK;
+}
+extern "C" int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4,
+                                 float* grad, void* stream) {
+  if (C % 8) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: C % 8 != 0");
+  if (!g_a4 && !grad) return JCK_OK;
+  const int K = 16 * C;
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), 16), dim3(256), 0, (hipStream_t)stream, ds, wp,
+                                      (const T*)a4, B, K, C, (T*)g_a4, grad));
+  HIPCHK(hipGetLastError());
   return JCK_OK;
 }
 extern "C" int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream) {

@@ -35,6 +35,7 @@ struct WgradParams {
   signed char dy[16], dx[16];
   int mchunk;             // pixel rows per blockIdx.z (multiple of WG_BKP)
   int big_row_elems;      // > 0: the gathered side is a plain [Mtot][big_row_elems] matrix (Linear layers), 1 tap
+  int gx, gy, gz;         // logical grid of the LDS-DMA kernel (launched 1-D): column tiles, row tiles, pixel chunks
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -286,8 +287,17 @@ static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g0 = blockIdx.x * BG, s0 = blockIdx.y * BS;
-  const int mz0 = blockIdx.z * p.mchunk;
+  // XCD-aware order (workgroup id % 8 = XCD, each with its own 4 MB L2): every XCD takes a contiguous run of logical tiles,
+  // column tile fastest, then row tile, then pixel chunk - the tiles of one pixel chunk read the same rows of both operands
+  // (other taps / channel chunks), so a chunk's 1.5-4.5 MB working set is fetched into ONE L2 instead of all eight
+  int wgid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    wgid = __builtin_amdgcn_readfirstlane((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx);
+  }
+  const int bx = wgid % p.gx, by = (wgid / p.gx) % p.gy, bz = wgid / (p.gx * p.gy);
+  const int g0 = bx * BG, s0 = by * BS;
+  const int mz0 = bz * p.mchunk;
   const int mz1 = min(mz0 + p.mchunk, p.Mtot);
   const unsigned char* bigb = reinterpret_cast<const unsigned char*>(p.big);
   const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(p.sside);
@@ -383,7 +393,7 @@ static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  float* part = p.part + (long long)blockIdx.z * p.CsRows * p.ncols;
+  float* part = p.part + (long long)bz * p.CsRows * p.ncols;
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int cs = s0 + ws * 64 + j * 16 + (lane & 15);

@@ -67,6 +67,7 @@ PROTOS = {
     "jck_bn2_reverse": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_head_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "jck_head_unpack_grad": (i32, [vp, i32, vp, i32, vp]),
+    "jck_head_bwd_conv": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, vp]),
     "jck_adam": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, i32, f32, vp]),
     "jck_engine_create": (i32, [C.POINTER(vp), i32, i32, i32]),
     "jck_engine_destroy": (None, [vp]),

@@ -211,6 +211,13 @@ def test_head(G, prec):
     assert abs(scal[3].item() / b - p.mean().item()) < 1e-5
     G.check(G.from_nhwc(ga), a4.grad, 1e-5 if prec == 1 else 1e-2, "head dgrad")
     G.check(gw.cpu(), w.grad, 1e-5, "head wgrad")
+    # the one-launch form the engine uses: dgrad + weight gradient accumulated straight into the PyTorch layout
+    ga2 = torch.empty_like(a4d)
+    gw2 = torch.full((1, c, 4, 4), 0.5, device="cuda")
+    G.lib.jck_head_bwd_conv(prec, ds, wp, a4d, b, c, ga2, gw2, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ga2, ga)
+    G.check(gw2.cpu() - 0.5, w.grad, 2e-5, "fused head wgrad")
     # gradient-penalty mode: d sum(sigmoid) / d logit
     G.lib.jck_head_fwd(prec, a4d, wp, None, b, 16 * c, 0.0, 1, prob, ds, scal, -1, -1, G.cur_stream())
     torch.cuda.synchronize()
