@@ -89,6 +89,17 @@ int jck_bn_act_fwd(int prec, const void* y, const float* aux, float slope, void*
 size_t jck_bn_bwd_ws_floats(int C);
 int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                    float* dgamma, float* dbeta, long long rows, int C, void* stream);
+/* Grouped forms: `groups` independent BatchNorm batches stored back to back - [groups][rows][C] tensors, [groups][slots]
+ * statistic slots, [groups][4C] aux, [groups][2C] (mean, unbiased var) records, [groups][jck_bn_bwd_ws_floats(C)] backward
+ * workspace.  For the D passes that share weights and run as ONE conv launch (train/dcgan_trainer.py:162,173,118); every
+ * group is normalised with its own batch statistics, exactly as in the separate passes.  Only groups < grad_groups add to
+ * dgamma / dbeta. */
+int jck_bn_finalize_grouped(const float* stats, int slots_per_group, float count, const float* gamma, const float* beta, float eps,
+                            float* aux, float* stat_out, int C, int groups, void* stream);
+int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group, int C,
+                           int groups, void* stream);
+int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                           float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* stream);
 
 /* ---- images, noise, heads, loss ----------------------------------------------------------------------------- */
 /* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "ops_internal.hpp"
+#define JCK_BATCHED_DEFAULT 3
 
 namespace {
 
@@ -116,6 +117,10 @@ struct jck_engine {
   void*& d_gx = dset[0].gx;
   BnBuf* d_bn = dset[0].bn;
   float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
+  // batched D passes (DCGAN): up to 3 batches that share D's weights go through ONE launch per layer, BatchNorm grouped
+  struct BSet { void *y[4], *a[4], *g[4]; float *stats[4], *aux[4], *sums[4]; float *prob, *ds; } bset;
+  int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
+  bool gp_done = false;
   float* d_rs[4];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
@@ -175,8 +180,19 @@ struct jck_engine {
       const size_t n = (size_t)B * h * h * C;
       g_y[i] = c.take<unsigned char>(bytes(n)); g_a[i] = c.take<unsigned char>(bytes(n)); g_gr[i] = c.take<unsigned char>(bytes(n));
     }
-    fake_raw = c.take<unsigned char>(bytes(img)); fake = c.take<unsigned char>(bytes(img)); g_raw = c.take<unsigned char>(bytes(img));
-    real_noisy = c.take<unsigned char>(bytes(img)); xhat = c.take<unsigned char>(bytes(img));
+    fake_raw = c.take<unsigned char>(bytes(img)); g_raw = c.take<unsigned char>(bytes(img));
+    // real_noisy | fake | xhat are consecutive (img bytes % 256 == 0): the batched D pass reads them as one 3B-image tensor
+    real_noisy = c.take<unsigned char>(bytes(img)); fake = c.take<unsigned char>(bytes(img)); xhat = c.take<unsigned char>(bytes(img));
+    if (batched) {
+      for (int i = 0; i < 4; ++i) {
+        const size_t n = (size_t)3 * B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+        bset.y[i] = c.take<unsigned char>(bytes(n)); bset.a[i] = c.take<unsigned char>(bytes(n)); bset.g[i] = c.take<unsigned char>(bytes(n));
+        bset.sums[i] = c.take<float>(3 * jck_bn_bwd_ws_floats(D_CS[i]));
+        bset.aux[i] = c.take<float>(3 * 4 * D_CS[i]);
+        bset.stats[i] = c.take<float>(jck_stats_floats((long long)3 * B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
+      }
+      bset.prob = c.take<float>(3 * B); bset.ds = c.take<float>(3 * B);
+    }
     // zeroed-per-pass regions
     {
       size_t start = c.off;
@@ -196,6 +212,7 @@ struct jck_engine {
     size_t w = 0;
     for (int i = 0; i < 4; ++i) {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
+      w = std::max(w, jck_conv_wgrad_ws_bytes(2 * B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, G_HS[i] * 2, G_HS[i] * 2, G_CB[i], G_CS[i]));
     }
     w = std::max(w, jck_g1_wgrad_ws_bytes(B, z_pad(family), G_C1));
@@ -239,12 +256,21 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   jck_engine* e = new jck_engine();
   e->family = family; e->prec = prec; e->B = batch; e->esz = prec == JCK_PREC_BF16 ? 2 : 4;
   e->LG = make_layout(family, 0); e->LD = make_layout(family, 1);
-  e->carve(nullptr);
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
+  // batched D passes need whole tiles per group: 16*B rows at the last layer, tiles of up to 128 rows
+  e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
+  if (family != 0 || !e->overlap || batch % 8 != 0 || (e->batched != 2 && e->batched != 3)) e->batched = 0;
+  e->carve(nullptr);
   e->defer_join = !(getenv("JCK_DEFER_JOIN") && atoi(getenv("JCK_DEFER_JOIN")) == 0);
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
-    for (auto p : ss) HIPCHK(hipStreamCreateWithFlags(p, hipStreamNonBlocking));
+    // queue priorities (JCK_PRIO=1): the weight-gradient and penalty streams are off the critical path -> low; G's forward
+    // gates D(fake) -> high
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // lo = numerically largest = lowest priority
+    const bool prio = getenv("JCK_PRIO") && atoi(getenv("JCK_PRIO")) != 0;
+    const int pr[3] = {prio ? lo : 0, prio ? hi : 0, prio ? lo : 0};
+    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, pr[i]));
     hipEvent_t* ev[9] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
   }
@@ -346,6 +372,7 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
 // ---------------------------------------------------------------------------------------------------------
 static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
+
 typedef jck_engine::DSet DSet;
 
 // conv stack of D on activation set `D`; BatchNorm running statistics are NOT touched here: (mean, unbiased var) go to the
@@ -437,6 +464,56 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
   // join = false: the caller's NEXT d_backward/g_backward with a side stream (or its own join) orders the main stream
   // behind these weight gradients - nothing on the main stream reads them before the optimiser step
   if (par && join) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+  return JCK_OK;
+}
+
+// D forward + backward on G batches stored back to back from `x_in` (real_noisy | fake | xhat are consecutive): ONE launch
+// per layer and direction instead of G, BatchNorm statistics per group (= per batch, as in the separate passes,
+// train/dcgan_trainer.py:162,173,118).  Groups [0, G-1) are loss passes (targets / accumulator slots given per group) and
+// contribute weight gradients; the LAST group is the penalty pass (head mode 1, gradient w.r.t. its input image -> dset[0].gx,
+// norms -> dset[0].norms).  Group g writes BatchNorm record pass0 + g.  Weight gradients run on `side`.
+static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pass0, const float* targets, const int* slot_loss,
+                          const int* slot_p, hipStream_t st, hipStream_t side) {
+  auto& S = e->bset;
+  const size_t esz = e->esz;
+  const int gw = G - 1;
+  auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
+  const void* in = x_in;
+  for (int i = 0; i < 4; ++i) {
+    const int hb = D_HB[i], cs = D_CS[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    int slots = 0;
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], S.y[i], S.stats[i], &slots, G * B, hb, hb, D_CB[i], cs, st));
+    if (slots % G) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
+    JCK_TRY(jck_bn_finalize_grouped(S.stats[i], slots / G, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
+                                    BN_EPS, S.aux[i], e->d_rs[i] + ((size_t)e->parity * 4 + pass0) * 2 * cs, cs, G, st));
+    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, S.y[i], S.aux[i], LRELU, S.a[i], rows, cs, G, st));
+    in = S.a[i];
+  }
+  for (int g = 0; g < G; ++g) {
+    const bool pen = g == G - 1;
+    JCK_TRY(jck_head_fwd(e->prec, at(S.a[3], (size_t)g * B * FEAT), e->d_head_wp, nullptr, B, FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
+                         S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], st));
+  }
+  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), st));
+  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
+                            at(S.g[3], (size_t)gw * B * FEAT), nullptr, st));
+  for (int i = 3; i >= 0; --i) {
+    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
+                                   e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+    const void* big = i == 0 ? x_in : S.a[i - 1];
+    hipStream_t ws = st;
+    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
+    if (i > 0)
+      JCK_TRY(jck_conv_up(e->prec, S.g[i], e->d_up[i], S.g[i - 1], nullptr, nullptr, 0, G * B, hb / 2, hb / 2, cs, cb, st));
+    else
+      JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)gw * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+  }
+  JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->norms, st));
+  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
 
@@ -560,7 +637,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
   hipStream_t sA = e->overlap ? e->sA : nullptr;
-  const bool ov_g = e->overlap, ov_gp = e->overlap && !cg;
+  const bool ov_g = e->overlap, ov_gp = e->overlap && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
     JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
@@ -571,6 +648,21 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   };
   switch (phase) {
     case JCK_PHASE_D_LOSS:
+      if (e->batched == 3) {                          // [real | fake | penalty] as one 3B pass after G's forward
+        if (!in->real_nchw || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw, z and alpha");
+        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
+        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
+        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));   // :171
+        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
+        const float tg[2] = {0.9f, 0.1f};
+        const int sl[2] = {0, 1}, sp[2] = {3, 4};
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA));                   // :162-176, 178
+        e->gp_done = true;
+        return JCK_OK;
+      }
+      [[fallthrough]];
     case JCK_PHASE_D_REAL:
     case JCK_PHASE_D_FAKE: {
       if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
@@ -601,6 +693,14 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       // ---- D on the fake batch (:170-176) with the penalty pass (:178) beside it
       if (ov_g) HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
+      if (e->batched == 2 && phase == JCK_PHASE_D_LOSS) {       // [fake | penalty] as one 2B pass
+        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
+        const float tg[1] = {0.1f};
+        const int sl[1] = {1}, sp[1] = {4};
+        JCK_TRY(d_batched_pass(e, e->fake, B, 2, 1, tg, sl, sp, st, sA));
+        e->gp_done = true;
+        return JCK_OK;
+      }
       if (ov_gp) {                                   // penalty pass on its own stream and activation set
         if (phase == JCK_PHASE_D_FAKE) HIPCHK(hipEventRecord(e->evReal, st));    // real_noisy came from an earlier call on st
         HIPCHK(hipStreamWaitEvent(e->sC, e->evF, 0));
@@ -616,6 +716,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_D_GP: {
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
+      if (e->gp_done) { e->gp_done = false; return JCK_OK; }    // computed inside the batched pass of PHASE_D_LOSS
       if (e->gp_inflight) {                           // started in PHASE_D_LOSS: just join
         HIPCHK(hipStreamWaitEvent(st, e->evGP, 0));
         e->gp_inflight = false;

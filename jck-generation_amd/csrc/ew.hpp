@@ -133,6 +133,11 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
                                                                  float* __restrict__ aux, int C, float* __restrict__ stat_out = nullptr) {
   __shared__ double sh[4][8];
   const int c0 = blockIdx.x * 4;
+  // grouped launch (gridDim.y > 1): group g owns slots [g*slots, (g+1)*slots), aux block g and record g (independent
+  // BatchNorm batches that went through ONE conv launch - the D passes that share weights)
+  stats += (long long)blockIdx.y * slots * 2 * C;
+  aux += (long long)blockIdx.y * 4 * C;
+  if (stat_out) stat_out += (long long)blockIdx.y * 2 * C;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   for (int k = threadIdx.x; k < slots; k += 256) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + c0);
@@ -192,6 +197,7 @@ static __global__ void bn_running_update_kernel(const float* __restrict__ slots,
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ aux, float slope,
                                   T* __restrict__ a, long long total8, int C) {
+  y += (long long)blockIdx.y * total8 * 8; a += (long long)blockIdx.y * total8 * 8; aux += (long long)blockIdx.y * 4 * C;   // group
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i * 8) & (C - 1));
     float v[8];
@@ -211,8 +217,11 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
-                                                            float* __restrict__ partial, long long rows, int C) {
+                                                            float* __restrict__ partial, long long rows, int C,
+                                                            long long group_stride = 0) {
   extern __shared__ float lsum[];                         // [rstep][2][C]
+  ga += (long long)blockIdx.y * rows * C; y += (long long)blockIdx.y * rows * C;                    // group
+  aux += (long long)blockIdx.y * 4 * C; partial += (long long)blockIdx.y * group_stride;
   const int upr = C >> 3;                                 // 8-channel units per row
   const int u = threadIdx.x % upr, r0 = threadIdx.x / upr, rstep = 256 / upr;
   const int c = u * 8;
@@ -246,9 +255,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // stage 2: sums[0..2C) = sum over workgroups; dgamma += s2, dbeta += s1 (when given).  One workgroup per 4 channels.
 static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
+                                                                 long long group_stride = 0, int grad_groups = 1) {
   __shared__ float sh[4][8];
   const int c0 = blockIdx.x * 4;
+  // grouped: blockIdx.y = group; only groups < grad_groups contribute to dgamma / dbeta (float atomics: with <= 2 adders
+  // on a zeroed gradient the sum does not depend on their order)
+  partial += (long long)blockIdx.y * group_stride; sums += (long long)blockIdx.y * group_stride;
+  const bool atomic = gridDim.y > 1;
+  if ((int)blockIdx.y >= grad_groups) { dgamma = nullptr; dbeta = nullptr; }
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   for (int k = threadIdx.x; k < nblk; k += 256) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (long long)k * 2 * C + c0);
@@ -268,15 +283,22 @@ static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __
   const float s1 = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], s2 = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
   sums[c] = s1;
   sums[C + c] = s2;
-  if (dgamma) dgamma[c] += s2;
-  if (dbeta) dbeta[c] += s1;
+  if (atomic) {
+    if (dgamma) atomicAdd(dgamma + c, s2);
+    if (dbeta) atomicAdd(dbeta + c, s1);
+  } else {
+    if (dgamma) dgamma[c] += s2;
+    if (dbeta) dbeta[c] += s1;
+  }
 }
 
 // g_y = scale * (g_z - s1/n - xhat * s2/n)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restrict__ y, const float* __restrict__ aux,
                                     const float* __restrict__ sums, float slope, float inv_count,
-                                    T* __restrict__ gy, long long total8, int C) {
+                                    T* __restrict__ gy, long long total8, int C, long long group_stride = 0) {
+  ga += (long long)blockIdx.y * total8 * 8; y += (long long)blockIdx.y * total8 * 8; gy += (long long)blockIdx.y * total8 * 8;   // group
+  aux += (long long)blockIdx.y * 4 * C; sums += (long long)blockIdx.y * group_stride;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i * 8) & (C - 1));
     float vg[8], vy[8];

@@ -528,6 +528,51 @@ extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const fl
   return JCK_OK;
 }
 
+// Grouped forms: `groups` independent BatchNorm batches stored back to back ([groups][rows][C] tensors, [groups][slots]
+// statistics slots, [groups][4C] aux, [groups][jck_bn_bwd_ws_floats(C)] backward workspace).  They serve D passes that
+// share weights and went through ONE conv launch (train/dcgan_trainer.py:162,173,118 run D on three batches with the
+// same weights); each group is normalised with its own batch statistics exactly as the separate passes are.
+extern "C" int jck_bn_finalize_grouped(const float* stats, int slots_per_group, float count, const float* gamma, const float* beta,
+                                       float eps, float* aux, float* stat_out, int C, int groups, void* stream) {
+  if (slots_per_group < 1 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_finalize_grouped: slots and groups must be >= 1");
+  if (C % 4) JCK_FAIL(JCK_E_ARG, "bn_finalize_grouped: C % 4 != 0");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, stats, slots_per_group, count, gamma,
+                     beta, (float*)nullptr, (float*)nullptr, (long long*)nullptr, 0.f, eps, aux, C, stat_out);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group,
+                                      int C, int groups, void* stream) {
+  if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_act_fwd_grouped: C must be a power of two >= 8");
+  const long long total8 = rows_per_group * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)y, aux, slope, (T*)a, total8, C));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
+                                      void* g_y, float* dgamma, float* dbeta, long long rows_per_group, int C, int groups,
+                                      int grad_groups, void* stream) {
+  if (!is_pow2(C) || C < 8 || C > 2048 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd_grouped: C must be a power of two in [8, 2048]");
+  const long long rows = rows_per_group;
+  const int rstep = 256 / (C / 8);
+  if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd_grouped: C too large");
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
+  float* partial = sums + 2 * C;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C,
+                     gstride, grad_groups);
+  HIPCHK(hipGetLastError());
+  const long long total8 = rows * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // images, heads
 // ---------------------------------------------------------------------------------------------------------

@@ -39,6 +39,9 @@ PROTOS = {
     "jck_bn_act_fwd": (i32, [i32, vp, vp, f32, vp, i64, i32, vp]),
     "jck_bn_bwd_ws_floats": (sz, [i32]),
     "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
+    "jck_bn_finalize_grouped": (i32, [vp, i32, f32, vp, vp, f32, vp, vp, i32, i32, vp]),
+    "jck_bn_act_fwd_grouped": (i32, [i32, vp, vp, f32, vp, i64, i32, i32, vp]),
+    "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),
     "jck_axpy_noise": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),

@@ -215,9 +215,12 @@ class DcganEngine:
     def draw_noise(self, generator=None, labels=None):
         """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111)."""
         B, dev = self.batch, self.device
-        nz = {"n1": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
-              "z": torch.randn(B, 100, 1, 1, device=dev, generator=generator),
-              "n2": torch.randn(B, 3, 64, 64, device=dev, generator=generator),
+        # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
+        ni, nzz = B * 3 * 64 * 64, B * 100
+        buf = torch.randn(2 * ni + nzz, device=dev, generator=generator)
+        nz = {"n1": buf[:ni].view(B, 3, 64, 64),
+              "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
+              "n2": buf[ni + nzz:].view(B, 3, 64, 64),
               "alpha": torch.rand(B, 1, 1, 1, device=dev, generator=generator)}
         if self.family == 1:
             nz["labels"] = labels
