@@ -100,6 +100,21 @@ int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slop
                            int groups, void* stream);
 int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                            float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* stream);
+/* BatchNorm backward fused with the dgrad that produces its input: jck_conv_up_bnbwd / jck_conv_down_bnbwd are
+ * jck_conv_up / jck_conv_down whose statistic slots receive sum(g_z) and sum(g_z*xhat) of the layer whose input gradient
+ * they produce (g_z = g_a*act'(z); bn_y = that layer's saved conv output, same layout as the output; bn_aux = its
+ * [groups][4C] table from jck_bn_finalize*; group_images = images per BatchNorm group, 0 = one group).  jck_bn_bwd_finish
+ * then reduces the [groups][slots_per_group] slots, adds dgamma/dbeta and applies
+ * g_y = scale*(g_z - s1/n - xhat*s2/n).  Together they replace aten::native_batch_norm_backward +
+ * aten::leaky_relu_backward / threshold_backward (model/DCGAN.py:11-24,43-56 under train/dcgan_trainer.py:164,175,187)
+ * without the separate reduction pass over g_a. */
+int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
+                      int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
+int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb,
+                        int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
+int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,
+                      int slots_per_group, float* sums, void* g_y, float* dgamma, float* dbeta, long long rows_per_group, int C,
+                      int groups, int grad_groups, void* stream);
 
 /* ---- images, noise, heads, loss ----------------------------------------------------------------------------- */
 /* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */

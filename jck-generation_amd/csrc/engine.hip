@@ -126,7 +126,7 @@ struct jck_engine {
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
   hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
-  bool overlap = true, gp_inflight = false, defer_join = true;
+  bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
   void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
@@ -259,9 +259,12 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
   // batched D passes need whole tiles per group: 16*B rows at the last layer, tiles of up to 128 rows
   e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
-  if (family != 0 || !e->overlap || batch % 8 != 0 || (e->batched != 2 && e->batched != 3)) e->batched = 0;
+  if (family != 0 || !e->overlap || batch % 8 != 0 || (e->batched < 2 || e->batched > 4)) e->batched = 0;
   e->carve(nullptr);
   e->defer_join = !(getenv("JCK_DEFER_JOIN") && atoi(getenv("JCK_DEFER_JOIN")) == 0);
+  // BatchNorm-backward statistics in the dgrad epilogue (jck_conv_*_bnbwd): correct and tested, but measured 4 % SLOWER than
+  // the separate reduction pass at B=256 (the extra epilogue work lengthens every workgroup's tail) - opt-in
+  e->fuse_bnbwd = getenv("JCK_FUSE_BNBWD") && atoi(getenv("JCK_FUSE_BNBWD")) != 0;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     // queue priorities (JCK_PRIO=1): the weight-gradient and penalty streams are off the critical path -> low; G's forward
@@ -447,16 +450,23 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn_act_bwd(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i],
-                           want_wgrad ? e->P(e->LD, e->dg, NAMES_NW[i]) : nullptr,
-                           want_wgrad ? e->P(e->LD, e->dg, NAMES_NB[i]) : nullptr, rows, cs, st));
+    float* dgam = want_wgrad ? e->P(e->LD, e->dg, NAMES_NW[i]) : nullptr;
+    float* dbet = want_wgrad ? e->P(e->LD, e->dg, NAMES_NB[i]) : nullptr;
+    if (i < 3 && e->fuse_bnbwd)      // the dgrad launch below (previous iteration) already left sum g_z, sum g_z*xhat in the slots
+      JCK_TRY(jck_bn_bwd_finish(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].stats, D.bn[i].slots, D.bn[i].sums, D.g[i], dgam,
+                                dbet, rows, cs, 1, 1, st));
+    else
+      JCK_TRY(jck_bn_act_bwd(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, st));
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
       if (par) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
       JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, ws));
     }
-    if (i > 0)
+    if (i > 0 && e->fuse_bnbwd)
+      JCK_TRY(jck_conv_up_bnbwd(e->prec, D.g[i], e->d_up[i], D.g[i - 1], D.bn[i - 1].stats, &D.bn[i - 1].slots, B, hb / 2, hb / 2, cs, cb,
+                                D.y[i - 1], D.bn[i - 1].aux, LRELU, 0, st));
+    else if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, D.g[i], e->d_up[i], D.g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
     else if (want_xgrad)
       JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
@@ -472,42 +482,68 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
 // train/dcgan_trainer.py:162,173,118).  Groups [0, G-1) are loss passes (targets / accumulator slots given per group) and
 // contribute weight gradients; the LAST group is the penalty pass (head mode 1, gradient w.r.t. its input image -> dset[0].gx,
 // norms -> dset[0].norms).  Group g writes BatchNorm record pass0 + g.  Weight gradients run on `side`.
-static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pass0, const float* targets, const int* slot_loss,
-                          const int* slot_p, hipStream_t st, hipStream_t side) {
+// forward of the conv stack for groups [g0, g0 + n) of the batched set (x_in = first image of group g0); own slot range
+static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int n, int pass0, hipStream_t st) {
   auto& S = e->bset;
   const size_t esz = e->esz;
-  const int gw = G - 1;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   const void* in = x_in;
   for (int i = 0; i < 4; ++i) {
     const int hb = D_HB[i], cs = D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    // statistic slots of group g0 start at the g0/3 point of the buffer (sized for 3B pixels at one slot per 32 pixels)
+    float* stats = S.stats[i] + (size_t)g0 * (jck_stats_floats((long long)3 * B * (hb / 2) * (hb / 2), cs, 1) / 3 / (2 * cs)) * (2 * cs);
     int slots = 0;
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], S.y[i], S.stats[i], &slots, G * B, hb, hb, D_CB[i], cs, st));
-    if (slots % G) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
-    JCK_TRY(jck_bn_finalize_grouped(S.stats[i], slots / G, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
-                                    BN_EPS, S.aux[i], e->d_rs[i] + ((size_t)e->parity * 4 + pass0) * 2 * cs, cs, G, st));
-    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, S.y[i], S.aux[i], LRELU, S.a[i], rows, cs, G, st));
-    in = S.a[i];
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, D_CB[i], cs, st));
+    if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
+    JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
+                                    BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
+    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
+                                   at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
+    in = at(S.a[i], (size_t)g0 * rows * cs);
   }
+  return JCK_OK;
+}
+
+// Heads + backward of G batches stored back to back from `x_in` (real_noisy | fake | xhat are consecutive) after
+// d_batched_forward has filled every group: ONE launch per layer and direction instead of G, BatchNorm statistics per
+// group (= per batch, as in the separate passes, train/dcgan_trainer.py:162,173,118).  Groups [0, G-1) are loss passes
+// (targets / accumulator slots given per group) and contribute weight gradients; the LAST group is the penalty pass (head
+// mode 1, gradient w.r.t. its input image -> dset[0].gx, norms -> dset[0].norms).  Weight gradients run on `side`.
+static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pass0, const float* targets, const int* slot_loss,
+                          const int* slot_p, hipStream_t st, hipStream_t side, bool forward_done = false) {
+  auto& S = e->bset;
+  const size_t esz = e->esz;
+  const int gw = G - 1;
+  auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
+  if (!forward_done) JCK_TRY(d_batched_forward(e, x_in, B, 0, G, pass0, st));
   for (int g = 0; g < G; ++g) {
     const bool pen = g == G - 1;
     JCK_TRY(jck_head_fwd(e->prec, at(S.a[3], (size_t)g * B * FEAT), e->d_head_wp, nullptr, B, FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
                          S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], st));
   }
+  int bslots[4] = {0, 0, 0, 0};
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
                             at(S.g[3], (size_t)gw * B * FEAT), nullptr, st));
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
-                                   e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+    if (i < 3 && e->fuse_bnbwd)
+      JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
+                                e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+    else
+      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
+                                     e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
-    if (i > 0)
+    if (i > 0 && e->fuse_bnbwd) {
+      JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
+                                S.y[i - 1], S.aux[i - 1], LRELU, B, st));
+      if (bslots[i - 1] % G) JCK_FAIL(JCK_E_ARG, "batched D pass: backward statistic slots do not split by group");
+    } else if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, S.g[i], e->d_up[i], S.g[i - 1], nullptr, nullptr, 0, G * B, hb / 2, hb / 2, cs, cb, st));
     else
       JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)gw * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
@@ -601,10 +637,17 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
-    JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
     const long long rows = (long long)B * hs * hs;
-    JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
-                           e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
+    if (e->fuse_bnbwd) {
+      JCK_TRY(jck_conv_down_bnbwd(e->prec, gbig, e->g_down[i], e->g_gr[i], e->g_bn[i].stats, &e->g_bn[i].slots, B, 2 * hs, 2 * hs, cb, cs,
+                                  e->g_y[i], e->g_bn[i].aux, 0.f, 0, st));
+      JCK_TRY(jck_bn_bwd_finish(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].stats, e->g_bn[i].slots, e->g_bn[i].sums,
+                                e->g_gr[i], e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, 1, 1, st));
+    } else {
+      JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
+      JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
+                             e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
+    }
     gbig = e->g_gr[i];
   }
   // the split-K workspace belongs to the side stream: G.conv1's weight gradient goes there too
@@ -648,6 +691,25 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   };
   switch (phase) {
     case JCK_PHASE_D_LOSS:
+      if (e->batched == 4) {                          // as 3, but D(real)'s forward runs beside G's forward
+        if (!in->real_nchw || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw, z and alpha");
+        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
+        HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
+        JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
+        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, e->sB));   // :171
+        HIPCHK(hipEventRecord(e->evF, e->sB));
+        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                             // :162
+        HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
+        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
+        JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                                   // :173, 118
+        const float tg[2] = {0.9f, 0.1f};
+        const int sl[2] = {0, 1}, sp[2] = {3, 4};
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, true));             // :163-176, 178
+        e->gp_done = true;
+        return JCK_OK;
+      }
       if (e->batched == 3) {                          // [real | fake | penalty] as one 3B pass after G's forward
         if (!in->real_nchw || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw, z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));

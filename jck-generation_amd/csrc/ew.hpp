@@ -256,12 +256,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // stage 2: sums[0..2C) = sum over workgroups; dgamma += s2, dbeta += s1 (when given).  One workgroup per 4 channels.
 static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                                                 long long group_stride = 0, int grad_groups = 1) {
+                                                                 long long group_stride = 0, int grad_groups = 1,
+                                                                 long long partial_group_stride = -1) {
   __shared__ float sh[4][8];
   const int c0 = blockIdx.x * 4;
   // grouped: blockIdx.y = group; only groups < grad_groups contribute to dgamma / dbeta (float atomics: with <= 2 adders
   // on a zeroed gradient the sum does not depend on their order)
-  partial += (long long)blockIdx.y * group_stride; sums += (long long)blockIdx.y * group_stride;
+  partial += (long long)blockIdx.y * (partial_group_stride >= 0 ? partial_group_stride : group_stride);
+  sums += (long long)blockIdx.y * group_stride;
   const bool atomic = gridDim.y > 1;
   if ((int)blockIdx.y >= grad_groups) { dgamma = nullptr; dbeta = nullptr; }
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};

@@ -51,6 +51,14 @@ struct IgemmParams {
   long long out_split_stride;
   int out_f32;            // store fp32 regardless of T (split-K slabs)
   long long w_phase_stride;
+  // BatchNorm-backward statistics instead of forward ones (dgrad launches): with bn_y != nullptr the stats slots receive
+  // sum(g_z) and sum(g_z * xhat) of the layer whose input gradient this launch produces - g_z = g_a * act'(z),
+  // z = y*scale + shift, xhat = (y - mean)*invstd, y = that layer's saved conv output (same layout as `out`), aux = its
+  // [scale | shift | mean | invstd] table ([groups][4*cstat]; group = pixel row / bn_group_rows when bn_group_rows > 0)
+  const void* bn_y;
+  const float* bn_aux;
+  float bn_slope;
+  int bn_group_rows;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -74,45 +82,109 @@ template <class P, int BCH, int BPIX> struct IgemmCfg {
 };
 
 
+// this lane's 4 consecutive saved-output values per accumulator fragment, loaded BEFORE the main loop when the launch
+// computes BatchNorm-backward statistics (the loads complete under the k-loop instead of stalling the epilogue)
+template <class P> struct BnRaw;
+template <> struct BnRaw<PrecBf16> { typedef u32x2 R; };
+template <> struct BnRaw<PrecF32> { typedef f32x4 R; };
+__device__ __forceinline__ void bn_unpack(u32x2 r, float (&v)[4]) {
+  v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+  v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void bn_unpack(f32x4 r, float (&v)[4]) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
+
+template <int FN>
+__device__ __forceinline__ void igemm_pixel_offsets(const IgemmParams& p, int lane, int wpix, int m0, long long (&poff)[FN]) {
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int m = m0 + wpix * FN * 16 + j * 16 + (lane & 15);
+    const int n = m >> p.logOHW;
+    const int rem = m & ((1 << p.logOHW) - 1);
+    poff[j] = m < p.M ? (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY + (long long)(rem & ((1 << p.logOW) - 1)) * p.osX
+                      : -1;
+  }
+}
+
+template <class P, int FM, int FN>
+__device__ __forceinline__ void igemm_bn_prefetch(const IgemmParams& p, int lane, int wch, int wpix, int z, int m0, int ch0,
+                                                  typename BnRaw<P>::R (&ypre)[FM][FN]) {
+  typedef typename P::T T;
+  typedef typename BnRaw<P>::R R;
+  long long poff[FN];
+  igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
+  const T* by = reinterpret_cast<const T*>(p.bn_y);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      R r = {};
+      if (ch < p.NchStore && poff[j] >= 0) r = *reinterpret_cast<const R*>(by + poff[j] + p.obase[z] + ch);
+      ypre[i][j] = r;
+    }
+  }
+}
+
 // Shared epilogue: optional BatchNorm partial statistics, bias, tanh, NHWC store of 4 consecutive channels per lane.
-template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN>
+template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN, bool BNB>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z, int zraw,
-                                               int bidx, int bidy, int m0, int ch0) {
+                                               int bidx, int bidy, int m0, int ch0, typename BnRaw<P>::R (&ypre)[BNB ? FM : 1][BNB ? FN : 1]) {
   typedef typename P::T T;
   // ---- epilogue --------------------------------------------------------------------------------------
+  long long poff[FN];                                               // output offset of this lane's pixel in tile column j (-1: past M)
+  igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
   if (p.stats) {
     // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
-    const long long slot = (((long long)zraw * p.gx + bidx) * nyrep + yrep) * WPIXN + wpix;
+    // pixel tile slowest, so that the slots of consecutive pixel ranges (BatchNorm groups) are consecutive too
+    const long long slot = (((long long)bidx * p.gz + zraw) * nyrep + yrep) * WPIXN + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
+    const float* aux = p.bn_aux + (p.bn_group_rows > 0 ? (long long)(m0 / p.bn_group_rows) * 4 * p.cstat : 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
+      const bool chok = ch < p.NchStore;
+      const int cc = ch & (p.cstat - 1);
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BNB) {
+        // backward statistics: s = sum g_z, q = sum g_z * xhat
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, is = sc;
+        if (chok) {
+          sc = *reinterpret_cast<const f32x4*>(aux + cc); sh = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc);
+          mu = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc); is = *reinterpret_cast<const f32x4*>(aux + 3 * p.cstat + cc);
+        }
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) {
+          float yv[4];
+          bn_unpack(ypre[i][j], yv);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[i][j][r];
+            const float zz = yv[r] * sc[r] + sh[r];
+            const float gz = zz > 0.f ? v : p.bn_slope * v;
+            s[r] += gz;
+            q[r] += gz * ((yv[r] - mu[r]) * is[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
-      if ((lane & 15) == 0) {
-        const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
-        if (ch < p.NchStore) {
-          const int cc = ch & (p.cstat - 1);
-          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
-          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
-        }
+      if ((lane & 15) == 0 && chok) {
+        *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
       }
     }
   }
   T* outp = reinterpret_cast<T*>(p.out);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int m = m0 + wpix * FN * 16 + j * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    const int n = m >> p.logOHW;
-    const int rem = m & ((1 << p.logOHW) - 1);
-    const long long off0 = (long long)n * p.osN + (long long)(rem >> p.logOW) * p.osY +
-                           (long long)(rem & ((1 << p.logOW) - 1)) * p.osX;
+    if (poff[j] < 0) continue;
+    const long long off0 = poff[j];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
@@ -134,7 +206,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
   }
 }
 
-template <class P, int BCH, int BPIX, int NSUB, int NST = 2>
+template <class P, int BCH, int BPIX, int NSUB, int NST = 2, bool BNB = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   typedef typename P::T T;        // activation storage type
   typedef typename P::W W;        // LDS / packed-weight element type (bf16_t or float)
@@ -293,6 +365,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   };
 
+  typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
+  if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
   // software pipeline: LDS double buffer + NST register stages; k-step k lives in stage k % NST
   load_tiles(0, st[0]);
   store_tiles(0, st[0]);
@@ -313,7 +387,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -325,7 +399,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
 
-template <int BCH, int BPIX, int NSTG>
+template <int BCH, int BPIX, int NSTG, bool BNB = false>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
   typedef PrecBf16 P;
   typedef IgemmCfg<P, BCH, BPIX> C;
@@ -426,6 +500,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     }
   };
 
+  typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
+  if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);   // older than every DMA: done by the first wait
   // prologue: NSTG-1 stages in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s) issue(s, s);
@@ -446,5 +522,5 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
     st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dead tail loads before the epilogue reuses nothing of LDS
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
 }

@@ -81,10 +81,13 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
   typedef IgemmCfg<P, BCH, BPIX> C;
   constexpr int variant = (P::IS_F32 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
   ProfScope prof(variant, p.flops, st);
-  auto kern = igemm_kernel<P, BCH, BPIX, NSUB>;
+  auto kern = p.bn_y ? igemm_kernel<P, BCH, BPIX, NSUB, 2, true> : igemm_kernel<P, BCH, BPIX, NSUB, 2, false>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<P, BCH, BPIX, NSUB, 2, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<P, BCH, BPIX, NSUB, 2, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -105,10 +108,13 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
   constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
   constexpr int variant = BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
   ProfScope prof(variant, p.flops, st);
-  auto kern = igemm_dma_kernel<BCH, BPIX, NSTG>;
+  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true> : igemm_dma_kernel<BCH, BPIX, NSTG, false>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -193,8 +199,11 @@ extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)e
 static const int g_use_thin = getenv("JCK_THIN") ? atoi(getenv("JCK_THIN")) : 1;
 #define IMG_GPW 8
 static int launch_img_down(const void* x, const void* w, void* out, float* stats, int* slots, int N, int Hb, int Wb, double flops,
-                           hipStream_t st) {
+                           hipStream_t st, const void* bn_y = nullptr, const float* bn_aux = nullptr, float bn_slope = 0.f,
+                           int bn_group_images = 0) {
   ImgDownParams q = {};
+  q.bn_y = bn_y; q.bn_aux = bn_aux; q.bn_slope = bn_slope;
+  q.bn_group_groups = bn_group_images > 0 ? bn_group_images * (Hb / 2) * (Wb / 2) / 16 : 0;
   const int OH = Hb / 2, OW = Wb / 2;
   q.x = x; q.w = w; q.out = out; q.stats = stats;
   q.ngroups = N * OH * (OW / 16); q.H = Hb; q.W = Wb; q.logOH = ilog2(OH); q.logG = ilog2(OW / 16);
@@ -225,9 +234,11 @@ static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, 
   return JCK_OK;
 }
 
-extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
-                             int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
+static int conv_down_impl(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
+                          int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float bn_slope,
+                          int bn_group_images, void* stream) {
   const int cbp = jck_pad_chan(Cb);
+  if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_down: shapes must be powers of two (Hb,Wb,Cb) and Cs % 4 == 0");
   if ((long long)N * Hb * Wb * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_down: tensor exceeds 2^31 elements");
@@ -241,14 +252,29 @@ extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* sma
   p.cstat = Cs; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
   if (stats && !is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
-  if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH))
-    return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream);
+  p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * OH * OW : 0;
+  if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH) &&
+      (bn_group_images == 0 || (bn_group_images * OH * OW) % (16 * 4 * IMG_GPW) == 0))
+    return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream, bn_y, bn_aux, bn_slope,
+                           bn_group_images);
   return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream, stats_slots);
 }
+extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
+                             int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
+  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream);
+}
+extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
+                                   int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope,
+                                   int group_images, void* stream) {
+  if (!bn_y) JCK_FAIL(JCK_E_ARG, "conv_down_bnbwd: bn_y is NULL");
+  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, bn_y, bn_aux, slope, group_images, stream);
+}
 
-extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
-                           int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
+static int conv_up_impl(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
+                        int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float bn_slope,
+                        int bn_group_images, void* stream) {
   const int cbp = jck_pad_chan(Cb);
+  if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_up: shapes must be powers of two (Hs,Ws,Cs>=16)");
   if ((long long)N * Hs * Ws * 4 * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_up: tensor exceeds 2^31 elements");
@@ -286,7 +312,19 @@ extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* 
   p.w_phase_stride = (long long)rows * p.K;
   if (p.K % 64 != 0) JCK_FAIL(JCK_E_ARG, "conv_up: 4*Cs must be a multiple of 64");
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
+  p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * Hs * Ws : 0;
   return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
+}
+extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
+                           int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
+  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, epi_tanh, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream);
+}
+extern "C" int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
+                                 int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope,
+                                 int group_images, void* stream) {
+  if (!bn_y) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: bn_y is NULL");
+  if (jck_pad_chan(Cb) == 4) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: not available for <=4-channel outputs");
+  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, bn_y, bn_aux, slope, group_images, stream);
 }
 
 extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
@@ -569,6 +607,24 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// Second half of the BatchNorm backward when the statistics came from a dgrad launch (jck_conv_*_bnbwd): reduce the
+// [groups][slots_per_group][2][C] slots, add dgamma / dbeta (groups < grad_groups), apply.
+extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,
+                                 int slots_per_group, float* sums, void* g_y, float* dgamma, float* dbeta, long long rows_per_group,
+                                 int C, int groups, int grad_groups, void* stream) {
+  if (!is_pow2(C) || C < 8 || groups < 1 || slots_per_group < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_finish: bad shape");
+  const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, slots, slots_per_group, sums, dgamma,
+                     dbeta, C, gstride, grad_groups, (long long)slots_per_group * 2 * C);
+  HIPCHK(hipGetLastError());
+  const long long total8 = rows_per_group * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
+                                      gstride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

@@ -186,6 +186,63 @@ def test_bn_act(G, prec, cfg):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [("up", 4, 8, 256, 128, 2), ("up", 2, 16, 128, 64, 0), ("down", 4, 16, 128, 256, 0),
+                                 ("down", 4, 64, 3, 64, 2), ("down", 3, 32, 3, 64, 0)])
+def test_dgrad_with_bn_backward_stats(G, prec, cfg):
+    """conv dgrad whose epilogue also leaves sum(g_z), sum(g_z*xhat) of the BatchNorm+activation in front of it, followed by
+    jck_bn_bwd_finish, against autograd through batch_norm -> (leaky_)relu -> conv; grouped = independent BN batches."""
+    kind, n, hin, cin, cout, gimg = cfg      # gimg = images per BatchNorm group (0: one group)
+    slope = 0.2 if kind == "up" else 0.0
+    g = torch.Generator().manual_seed(11)
+    groups = n // gimg if gimg else 1
+    hout = 2 * hin if kind == "up" else hin // 2
+    y = G.rnd(torch.randn(n, cout, hout, hout, generator=g) * 1.3 + 0.2, prec).requires_grad_(True)    # saved conv output of layer L
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    wr = G.rnd(w, prec)
+    gin = G.rnd(torch.randn(n, cin, hin, hin, generator=g), prec)            # gradient arriving at the conv that consumed a_L
+    # reference: g_a = dgrad(gin); then backward through act and per-group batch norm
+    ga = F.conv_transpose2d(gin, wr, None, 2, 1) if kind == "up" else F.conv2d(gin, wr, None, 2, 1)
+    per = gimg if gimg else n
+    parts = []
+    for k in range(groups):
+        yy = y[k * per:(k + 1) * per]
+        bn = F.batch_norm(yy, None, None, gamma, beta, True, 0.1, 1e-5)
+        parts.append(F.leaky_relu(bn, slope) if slope else F.relu(bn))
+    torch.cat(parts).backward(ga)
+    # library: aux per group, fused dgrad + statistics, finish
+    yd = G.to_nhwc(y.detach(), prec)
+    c = cout
+    rows = per * hout * hout
+    aux = torch.empty(groups, 4 * c, device="cuda")
+    for k in range(groups):
+        yf = yd[k * per:(k + 1) * per].float().reshape(rows, c)
+        st = torch.stack([yf.sum(0), (yf ** 2).sum(0)]).contiguous()
+        G.lib.jck_bn_finalize(st, 1, float(rows), gamma.detach().cuda(), beta.detach().cuda(), None, None, None, 0.1, 1e-5,
+                              aux[k], c, G.cur_stream())
+    out = torch.empty_like(yd)
+    stats, slots = G.stats_buf(n * hout * hout, c)
+    if kind == "up":
+        G.lib.jck_conv_up_bnbwd(prec, G.to_nhwc(gin, prec), G.pack_up(w, prec), out, stats, ctypes.byref(slots), n, hin, hin, cin,
+                                cout, yd, aux, slope, gimg, G.cur_stream())
+    else:
+        G.lib.jck_conv_down_bnbwd(prec, G.to_nhwc(gin, prec), G.pack_down(w, prec), out, stats, ctypes.byref(slots), n, hin, hin,
+                                  cin, cout, yd, aux, slope, gimg, G.cur_stream())
+    assert slots.value % groups == 0
+    sums = torch.full((groups * G.lib.jck_bn_bwd_ws_floats(c),), float("nan"), device="cuda")
+    dgam, dbet = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    gy = torch.empty_like(yd)
+    G.lib.jck_bn_bwd_finish(prec, out, yd, aux, slope, stats, slots.value // groups, sums, gy, dgam, dbet, rows, c, groups,
+                            groups, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(G.from_nhwc(out), ga, G.TOL[prec], "dgrad")
+    G.check(G.from_nhwc(gy), y.grad, 3e-5 if prec == 1 else 3e-2, "dx")
+    G.check(dgam.cpu(), gamma.grad, 3e-5 if prec == 1 else 1e-2, "dgamma")
+    G.check(dbet.cpu(), beta.grad, 3e-5 if prec == 1 else 1e-2, "dbeta")
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_head(G, prec):
     b, c = 16, 512
     g = torch.Generator().manual_seed(6)
