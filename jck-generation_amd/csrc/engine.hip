@@ -316,6 +316,13 @@ extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, 
   if (ws_bytes < e->ws_bytes) JCK_FAIL(JCK_E_WS, "workspace too small: need " + std::to_string(e->ws_bytes));
   if (((uintptr_t)workspace) % 256) JCK_FAIL(JCK_E_ARG, "workspace must be 256-byte aligned");
   e->carve(reinterpret_cast<unsigned char*>(workspace));
+  // the repack kernel writes only real (channel, channel) pairs: the padding rows / channels of the packed operands must
+  // read as zero -> clear that region once (from the first packed operand up to the first activation buffer)
+  {
+    unsigned char* p0 = reinterpret_cast<unsigned char*>(e->d_down[0]);
+    unsigned char* p1 = reinterpret_cast<unsigned char*>(e->dset[0].y[0]);
+    HIPCHK(hipMemset(p0, 0, (size_t)(p1 - p0)));
+  }
   e->gp = g_params; e->gg = g_grads; e->gm = g_m; e->gv = g_v; e->gbn = g_bn; e->gnbt = g_nbt;
   e->dp = d_params; e->dg = d_grads; e->dm = d_m; e->dv = d_v; e->dbn = d_bn; e->dnbt = d_nbt;
   e->bound = true;
@@ -334,13 +341,11 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
     chunk += (int)((total + PACK_CHUNK - 1) / PACK_CHUNK);
     ++n;
   };
-  auto add_down = [&](const float* w, int Cs, int Cb, void* wp) {
-    const int cbp = jck_pad_chan(Cb), rows = jck_pad_rows(Cs);
-    add(0, w, wp, (long long)rows * 16 * cbp, Cs, Cb, ilog2(cbp));
-  };
+  // totals are (output channel, input channel) pairs: one thread each (ew.hpp: pack_multi_kernel)
+  auto add_down = [&](const float* w, int Cs, int Cb, void* wp) { add(0, w, wp, (long long)Cs * Cb, Cs, Cb, ilog2(jck_pad_chan(Cb))); };
   auto add_up = [&](const float* w, int Cs, int Cb, void* wp) {
-    if (Cb <= 4) add(2, w, wp, 16ll * 9 * Cs, Cs, Cb, 0);
-    else add(1, w, wp, 4ll * jck_pad_rows(Cb) * 4 * Cs, Cs, Cb, jck_pad_rows(Cb));
+    if (Cb <= 4) add(2, w, wp, (long long)Cs * Cb, Cs, Cb, 0);
+    else add(1, w, wp, (long long)Cs * Cb, Cs, Cb, jck_pad_rows(Cb));
   };
   if (net == 1) {
     for (int i = 0; i < 4; ++i) {
@@ -348,9 +353,9 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
       add_down(w, D_CS[i], D_CB[i], e->d_down[i]);
       add_up(w, D_CS[i], D_CB[i], e->d_up[i]);
     }
-    if (e->family == 0) add(4, e->P(e->LD, e->dp, NAMES_CW[4]), e->d_head_wp, 16ll * 512, 512, 0, 0);
+    if (e->family == 0) add(4, e->P(e->LD, e->dp, NAMES_CW[4]), e->d_head_wp, 512, 512, 0, 0);
   } else {
-    add(3, e->P(e->LG, e->gp, NAMES_CW[0]), e->g1_w, 16ll * G_C1 * z_pad(e->family), z_dim(e->family), G_C1, z_pad(e->family));
+    add(3, e->P(e->LG, e->gp, NAMES_CW[0]), e->g1_w, (long long)z_dim(e->family) * G_C1, z_dim(e->family), G_C1, z_pad(e->family));
     for (int i = 0; i < 4; ++i) {
       const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
       add_up(w, G_CS[i], G_CB[i], e->g_up[i]);

@@ -539,10 +539,12 @@ static __global__ void pack_head_kernel(const float* __restrict__ w, int C, floa
 }
 
 // Every packed operand of one network in ONE launch (the optimiser step is followed by 9-10 repacks; as separate launches
-// their ~4.5 us floor each left the GPU idle for ~45 us twice per step).  Jobs are cut into 2048-element chunks; a
-// workgroup finds its job from the chunk prefix table.
+// their ~4.5 us floor each left the GPU idle for ~45 us twice per step).  A thread owns one (output channel, input channel)
+// pair of a conv weight: it reads the pair's 16 taps (64 contiguous bytes) once and writes the 16 operand elements, with
+// the lane-fastest index chosen per layout so that every store instruction covers contiguous elements.  Padding rows and
+// channels are never written: they stay zero from the zero-initialised workspace.  256 pairs per workgroup.
 #define PACK_MAX_JOBS 12
-#define PACK_CHUNK 2048
+#define PACK_CHUNK 256
 struct PackJob { const float* w; void* wp; long long total; int kind, a, b, c; };   // kind: 0 down 1 up 2 up16 3 g1 4 head
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; int first_chunk[PACK_MAX_JOBS + 1]; int n; };
 template <typename W>
@@ -550,18 +552,63 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_chunk[ji + 1]) ++ji;
   const PackJob& J = jobs.j[ji];
-  const long long base = (long long)(blockIdx.x - jobs.first_chunk[ji]) * PACK_CHUNK;
+  const long long u = (long long)(blockIdx.x - jobs.first_chunk[ji]) * PACK_CHUNK + threadIdx.x;
+  if (u >= J.total) return;
+  W* wp = reinterpret_cast<W*>(J.wp);
+  float v[16];
+  auto load16 = [&](const float* src) {
 #pragma unroll
-  for (int u = 0; u < PACK_CHUNK / 256; ++u) {
-    const long long i = base + u * 256 + threadIdx.x;
-    if (i >= J.total) break;
-    switch (J.kind) {
-      case 0: stf(reinterpret_cast<W*>(J.wp) + i, pack_down_val(J.w, J.a, J.b, J.c, i)); break;
-      case 1: stf(reinterpret_cast<W*>(J.wp) + i, pack_up_val(J.w, J.a, J.b, J.c, i)); break;
-      case 2: stf(reinterpret_cast<W*>(J.wp) + i, pack_up16_val(J.w, J.a, J.b, i)); break;
-      case 3: stf(reinterpret_cast<W*>(J.wp) + i, pack_g1_val(J.w, J.a, J.b, J.c, i)); break;
-      default: { const int t = (int)(i / J.a), c = (int)(i % J.a); reinterpret_cast<float*>(J.wp)[i] = J.w[c * 16 + t]; } break;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+      v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
     }
+  };
+  switch (J.kind) {
+    case 0: {   // down: a = Cs, b = Cb, c = logCbPad; unit = (cs, cb), cb fastest; wp[cs][t*CbPad + cb]
+      const int Cb = J.b, cs = (int)(u / Cb), cb = (int)(u % Cb);
+      load16(J.w + ((long long)cs * Cb + cb) * 16);
+      W* d = wp + (((long long)cs * 16) << J.c) + cb;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) stf(d + ((long long)t << J.c), v[t]);
+    } break;
+    case 1: {   // up: a = Cs, b = Cb, c = CbPad; unit = (cb, cs), cs fastest; wp[phase][cb][t4*Cs + cs]
+      const int Cs = J.a, Cb = J.b, cb = (int)(u / Cs), cs = (int)(u % Cs);
+      load16(J.w + ((long long)cs * Cb + cb) * 16);
+      const long long K = 4ll * Cs, per = (long long)J.c * K;
+#pragma unroll
+      for (int phase = 0; phase < 4; ++phase)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int kh = c_up_k[phase >> 1][t >> 1], kw = c_up_k[phase & 1][t & 1];
+          stf(wp + phase * per + (long long)cb * K + (long long)t * Cs + cs, v[kh * 4 + kw]);
+        }
+    } break;
+    case 2: {   // up16: a = Cs, b = Cb; unit = (c, cs), cs fastest; wp[phase*4 + c][t9*Cs + cs], unused (phase, offset) pairs stay 0
+      const int Cs = J.a, Cb = J.b, c = (int)(u / Cs), cs = (int)(u % Cs);
+      load16(J.w + ((long long)cs * Cb + c) * 16);
+      const long long K = 9ll * Cs;
+#pragma unroll
+      for (int phase = 0; phase < 4; ++phase)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int dy = t9 / 3 - 1, dx = t9 % 3 - 1, ph = phase >> 1, pw = phase & 1;
+          const int kh = ph == 0 ? (dy == 0 ? 1 : (dy == -1 ? 3 : -1)) : (dy == 1 ? 0 : (dy == 0 ? 2 : -1));
+          const int kw = pw == 0 ? (dx == 0 ? 1 : (dx == -1 ? 3 : -1)) : (dx == 1 ? 0 : (dx == 0 ? 2 : -1));
+          if (kh >= 0 && kw >= 0) stf(wp + (long long)(phase * 4 + c) * K + (long long)t9 * Cs + cs, v[kh * 4 + kw]);
+        }
+    } break;
+    case 3: {   // g1: a = Ci, b = Co, c = CiPad; unit = (co, ci), ci fastest; wp[(t*Co + co)][ci]
+      const int Ci = J.a, Co = J.b, co = (int)(u / Ci), ci = (int)(u % Ci);
+      load16(J.w + ((long long)ci * Co + co) * 16);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) stf(wp + ((long long)t * Co + co) * J.c + ci, v[t]);
+    } break;
+    default: {  // head: a = C; unit = c; wp[t*C + c] fp32
+      const int c = (int)u;
+      load16(J.w + (long long)c * 16);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) reinterpret_cast<float*>(J.wp)[(long long)t * J.a + c] = v[t];
+    } break;
   }
 }
 

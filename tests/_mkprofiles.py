@@ -1,0 +1,84 @@
+"""Turns the rocprofv3 output of tests/_prof.sh (gpurun_out/prof) into the committed round artifacts under profiles/:
+rNN_bench_kernel_stats.csv, rNN_bench_domain_stats.csv, rNN_traffic.json (HBM bytes per launch from the separate
+FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the gfx950 guide prescribes, KB -> bytes) and rNN_summary.md.
+Usage: python tests/_mkprofiles.py r01 [bench.json ...]   (development aid; reads only gpurun_out/ and profiles/)"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    return name.split("(")[0].strip()
+
+
+def counters(path):
+    """{kernel: {counter: [values per dispatch]}}"""
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return out
+    for r in csv.DictReader(open(path)):
+        out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    for f in ("bench_kernel_stats.csv", "bench_domain_stats.csv"):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, f"{tag}_{f}"))
+    stdout = open(os.path.join(SRC, "bench_stdout.log")).read()
+    line = [l for l in stdout.splitlines() if l.startswith("{")][-1]
+    prof_bench = json.loads(line)
+    nsteps = prof_bench["steps"] + prof_bench["warmup"]
+    rows = list(csv.DictReader(open(os.path.join(SRC, "bench_kernel_stats.csv"))))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    fetch = counters(os.path.join(SRC, "pmc_fetch_counter_collection.csv"))
+    write = counters(os.path.join(SRC, "pmc_write_counter_collection.csv"))
+    traffic = {}
+    for k, d in fetch.items():
+        if "FETCH_SIZE" not in d or k not in write:
+            continue
+        fs, ws = d["FETCH_SIZE"], write[k].get("WRITE_SIZE", [0.0])
+        traffic[k] = {"launches": len(fs), "fetch_size_kb_avg": sum(fs) / len(fs), "write_size_kb_avg": sum(ws) / len(ws),
+                      "read_bytes": sum(fs) / len(fs) * 2 * 1024, "write_bytes": sum(ws) / len(ws) * 1024}
+    traffic = dict(sorted(traffic.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]) * kv[1]["launches"]))
+    json.dump(traffic, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
+    sq = counters(os.path.join(SRC, "pmc_sq_counter_collection.csv"))
+    mf = counters(os.path.join(SRC, "pmc_mfma_counter_collection.csv"))
+    md = [f"# Round {tag} rocprofv3 summary (MI355X, `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps "
+          f"{prof_bench['steps']} --warmup {prof_bench['warmup']} --no-cpu-baseline --no-roofline`)", "",
+          f"{nsteps} traced steps. Sum of kernel durations {tot / nsteps / 1e6:.3f} ms/step (weight gradients run on a second "
+          f"HIP stream beside the dgrad chain, so the sum can exceed the wall time); the profiled run itself reported "
+          f"{prof_bench['ms_per_step']} ms/step, the un-profiled bench is in `profiles/{tag}_bench.json`.", "",
+          "| ms/step | launches/step | avg us | kernel |", "|---|---|---|---|"]
+    for r in rows[:40]:
+        n, t = int(r["Calls"]), float(r["TotalDurationNs"])
+        md.append(f"| {t / nsteps / 1e6:.4f} | {n / nsteps:.1f} | {t / n / 1e3:.2f} | `{r['Name'][:100]}` |")
+    md += ["", "## HBM traffic per launch from PMC (separate passes; FETCH_SIZE doubled per the gfx950 correction, KB -> bytes)", "",
+           "| kernel | launches | FETCH_SIZE avg (KB) | read bytes (x2 x1024) | WRITE_SIZE avg (KB) | write bytes |", "|---|---|---|---|---|---|"]
+    for k, v in list(traffic.items())[:24]:
+        md.append(f"| `{k}` | {v['launches']} | {v['fetch_size_kb_avg']:.0f} | {v['read_bytes'] / 1e6:.2f} MB | "
+                  f"{v['write_size_kb_avg']:.0f} | {v['write_bytes'] / 1e6:.2f} MB |")
+    cols = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA"]
+    cols2 = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]
+    md += ["", "## SQ counters, averages per launch", "",
+           "| kernel | " + " | ".join(c.replace("SQ_", "") for c in cols + cols2) + " |", "|" + "---|" * (len(cols + cols2) + 1)]
+    for k in sq:
+        if not any(s in k for s in ("igemm", "wgrad", "img_")):
+            continue
+        vals = [sq[k].get(c, []) for c in cols] + [mf.get(k, {}).get(c, []) for c in cols2]
+        md.append(f"| `{k}` | " + " | ".join(f"{sum(v) / len(v):.3g}" if v else "-" for v in vals) + " |")
+    open(os.path.join(DST, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
+    for extra in sys.argv[2:]:
+        shutil.copy(extra, os.path.join(DST, f"{tag}_{os.path.basename(extra)}"))
+    print("wrote profiles/%s_*" % tag)
+
+
+if __name__ == "__main__":
+    main()
