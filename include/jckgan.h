@@ -120,6 +120,14 @@ int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux
 /* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */
 int jck_img_prep(int prec, const float* img_nchw, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,
                  void* stream);
+/* Device-resident input pipeline: gathers B images by index from a uint8 dataset [Ntot][3][Hs][Ws] kept in HBM (idx NULL:
+ * the first B) and applies the reference's transform chain on the fly - Resize(2x) exactly as PIL's bilinear upscale
+ * (horizontal then vertical pass, each rounded to uint8), ToTensor, Normalize(0.5,0.5)
+ * (preprocess/dcgan_data_preprocessor.py:38-43) - then the instance-noise mix keep*x + mix*noise
+ * (train/dcgan_trainer.py:160).  out_nhwc4 [B][2Hs][2Ws][4] (element type of prec) and/or out_nchw fp32 [B][3][2Hs][2Ws]
+ * (the transformed image without noise); either may be NULL. */
+int jck_img_prep_u8(int prec, const unsigned char* data, const int64_t* idx, const float* noise, float keep, float mix,
+                    void* out_nhwc4, float* out_nchw, int B, int Hs, int Ws, void* stream);
 int jck_nhwc4_to_nchw(int prec, const void* in, float* out_nchw, int N, int HW, void* stream);
 /* out = keep*x + mix*noise for an NHWC4 x                                      train/dcgan_trainer.py:171 */
 int jck_axpy_noise(int prec, const void* x, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,
@@ -236,6 +244,10 @@ typedef struct jck_step_inputs {
   /* family 1 (CGAN) only: */
   const int64_t* labels;   /* [B,100] one-hot int64 (preprocess/cgan_data_preprocessor.py:11-16) */
   const float* drop_mask[4]; /* [B,256] 0/1 keep masks of nn.Dropout(0.25) for the 4 D passes (real, fake, GP, G phase) */
+  /* device-resident dataset (optional; used instead of real_nchw when real_u8 != NULL): uint8 [Ntot,3,32,32] + the batch's
+   * indices int64 [B]; the step applies the input transform itself (jck_img_prep_u8) */
+  const unsigned char* real_u8;
+  const int64_t* real_idx;
 } jck_step_inputs;
 int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */

@@ -664,6 +664,13 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
   return JCK_OK;
 }
 
+// the real batch -> NHWC4 with instance noise (:160): from an fp32 NCHW tensor, or gathered from the device-resident uint8
+// dataset with the input transform applied on the fly
+static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_t st) {
+  if (in->real_u8) return jck_img_prep_u8(e->prec, in->real_u8, in->real_idx, in->noise_real, 0.9f, 0.1f, e->real_noisy, nullptr, B, 32, 32, st);
+  return jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, 64 * 64, st);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------------------
@@ -697,14 +704,14 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   switch (phase) {
     case JCK_PHASE_D_LOSS:
       if (e->batched == 4) {                          // as 3, but D(real)'s forward runs beside G's forward
-        if (!in->real_nchw || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw, z and alpha");
+        if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
         JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
         JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, e->sB));   // :171
         HIPCHK(hipEventRecord(e->evF, e->sB));
-        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                             // :162
         HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
         JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
@@ -716,10 +723,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         return JCK_OK;
       }
       if (e->batched == 3) {                          // [real | fake | penalty] as one 3B pass after G's forward
-        if (!in->real_nchw || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw, z and alpha");
+        if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
-        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
         JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));   // :171
         JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
@@ -733,7 +740,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_D_REAL:
     case JCK_PHASE_D_FAKE: {
       if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
-        if (!in->real_nchw) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw");
+        if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw (or real_u8)");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                   // D.zero_grad()  :155
         if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
@@ -748,7 +755,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
       }
       if (phase != JCK_PHASE_D_FAKE) {
-        JCK_TRY(jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, HW, st));   // :160
+        JCK_TRY(prep_real(e, in, B, st));   // :160
         if (ov_gp && phase == JCK_PHASE_D_LOSS) HIPCHK(hipEventRecord(e->evReal, st));           // penalty pass needs only this
         JCK_TRY(d_forward(e, DR, e->real_noisy, B, 0, in->drop_mask[0], st));                      // :162
         JCK_TRY(d_head(e, DR, B, 0.9f, 0, 0, 3, st));                                             // :163,165

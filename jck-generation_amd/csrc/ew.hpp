@@ -20,12 +20,58 @@ __global__ void img_prep_kernel(const float* __restrict__ img, const float* __re
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const long long s = (n * 3 + c) * HW + px;
-      float x = keep * img[s];
-      if (noise) x += mix * noise[s];
+      float x = __fmul_rn(keep, img[s]);
+      if (noise) x = __fmaf_rn(mix, noise[s], x);                  // explicit: the same rounding in every kernel that mixes noise
       v[c] = x;
     }
     v[3] = 0.f;
     st4(out + i * 4, v);
+  }
+}
+
+// Device-resident input pipeline: a uint8 dataset [Ntot][3][Hs][Ws] (the CIFAR pickle layout) stays in HBM and a batch is
+// gathered by index and pushed through the reference's transform chain on the fly (preprocess/dcgan_data_preprocessor.py:
+// 38-43): Resize(2x) as PIL does it for a bilinear upscale - horizontal pass, then vertical pass, EACH rounded to uint8 with
+// the 3:1 / 1:3 weights (out = (3a + b + 2) >> 2; the clamped border taps reduce to a) -, ToTensor (/255),
+// Normalize(0.5, 0.5), then the instance-noise mix of train/dcgan_trainer.py:160.  Bit-exact against PIL for the image
+// (tests/golden/resize_u8.json).  out_nhwc4: [B][2Hs][2Ws][4] T (or nullptr); out_nchw: [B][3][2Hs][2Ws] fp32 transformed
+// image WITHOUT noise (or nullptr).
+__device__ __forceinline__ int up2_pil(int o, int L, int a_km1, int a_k, int a_kp1) {
+  (void)L;
+  return (o & 1) ? (3 * a_k + a_kp1 + 2) >> 2 : (a_km1 + 3 * a_k + 2) >> 2;
+}
+template <typename T>
+__global__ void img_prep_u8_kernel(const unsigned char* __restrict__ data, const long long* __restrict__ idx,
+                                   const float* __restrict__ noise, float keep, float mix, T* __restrict__ out_nhwc4,
+                                   float* __restrict__ out_nchw, int B, int Hs, int Ws) {
+  const int H = 2 * Hs, W = 2 * Ws;
+  const long long total = (long long)B * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long n = i / ((long long)W * H);
+    const unsigned char* src = data + (idx ? idx[n] : n) * 3ll * Hs * Ws;
+    const int kx = x >> 1, ky = y >> 1;
+    const int xm = max(kx - 1, 0), xp = min(kx + 1, Ws - 1), ym = max(ky - 1, 0), yp = min(ky + 1, Hs - 1);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned char* pl = src + (long long)c * Hs * Ws;
+      int hrow[3];                                                   // horizontal pass on source rows ym, ky, yp
+      const int rows[3] = {ym, ky, yp};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const unsigned char* row = pl + rows[r] * Ws;
+        hrow[r] = up2_pil(x, Ws, row[xm], row[kx], row[xp]);
+      }
+      const int u8 = up2_pil(y, Hs, hrow[0], hrow[1], hrow[2]);
+      const float t = ((float)u8 / 255.0f - 0.5f) / 0.5f;           // ToTensor, Normalize(0.5, 0.5)
+      if (out_nchw) out_nchw[((n * 3 + c) * H + y) * W + x] = t;
+      float o = __fmul_rn(keep, t);
+      if (noise) o = __fmaf_rn(mix, noise[((n * 3 + c) * H + y) * W + x], o);
+      v[c] = o;
+    }
+    v[3] = 0.f;
+    if (out_nhwc4) st4(out_nhwc4 + i * 4, v);
   }
 }
 

@@ -632,6 +632,16 @@ extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const
 // ---------------------------------------------------------------------------------------------------------
 // images, heads
 // ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_img_prep_u8(int prec, const unsigned char* data, const int64_t* idx, const float* noise, float keep, float mix,
+                               void* out_nhwc4, float* out_nchw, int B, int Hs, int Ws, void* stream) {
+  if (!data || B < 1 || Hs < 1 || Ws < 1) JCK_FAIL(JCK_E_ARG, "img_prep_u8: bad arguments");
+  if (!out_nhwc4 && !out_nchw) return JCK_OK;
+  DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_u8_kernel<T>, dim3(ew_grid((long long)B * 4 * Hs * Ws)), dim3(256), 0,
+                                      (hipStream_t)stream, data, (const long long*)idx, noise, keep, mix, (T*)out_nhwc4, out_nchw, B,
+                                      Hs, Ws));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 extern "C" int jck_img_prep(int prec, const float* img, const float* noise, float keep, float mix, void* out, int N, int HW,
                             void* stream) {
   DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0,

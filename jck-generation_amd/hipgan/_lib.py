@@ -13,7 +13,8 @@ vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_d
 
 class StepInputs(C.Structure):
     _fields_ = [("real_nchw", vp), ("noise_real", vp), ("z", vp), ("noise_fake", vp), ("alpha", vp),
-                ("lr", f32), ("grad_scale", f32), ("step", i32), ("labels", vp), ("drop_mask", vp * 4)]
+                ("lr", f32), ("grad_scale", f32), ("step", i32), ("labels", vp), ("drop_mask", vp * 4),
+                ("real_u8", vp), ("real_idx", vp)]
 
 
 # name -> (restype, argtypes)      (keep in sync with include/jckgan.h; tests/test_abi.py checks the symbol list)
@@ -46,6 +47,7 @@ PROTOS = {
     "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "jck_img_prep_u8": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
     "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),
     "jck_axpy_noise": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_interp": (i32, [i32, vp, vp, vp, vp, i32, i32, vp]),

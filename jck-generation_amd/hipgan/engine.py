@@ -39,6 +39,28 @@ def _layout(family, net):
     return out
 
 
+class DeviceBatch:
+    """A training batch as indices into a uint8 image dataset that lives in HBM ([N,3,32,32], the CIFAR pickle layout).
+    The step gathers and transforms it on the device (jck_img_prep_u8: the reference's Resize(64) / ToTensor /
+    Normalize(0.5, 0.5), preprocess/dcgan_data_preprocessor.py:38-43, bit-exact) - no per-step host->device image copy."""
+
+    def __init__(self, data_u8, idx):
+        if data_u8.dtype != torch.uint8 or not data_u8.is_cuda or not data_u8.is_contiguous():
+            raise JckError("DeviceBatch: dataset must be a contiguous uint8 CUDA tensor")
+        self.data = data_u8
+        self.idx = idx.to(data_u8.device, torch.int64).contiguous()
+
+    def size(self, dim=0):
+        return (self.idx.numel(), 3, 64, 64)[dim]
+
+    def materialize(self):
+        """The transformed batch as fp32 NCHW [B,3,64,64] (what the reference's DataLoader would have yielded)."""
+        b = self.idx.numel()
+        out = torch.empty(b, 3, 64, 64, dtype=torch.float32, device=self.data.device)
+        lib.jck_img_prep_u8(PREC_F32, self.data, self.idx, None, 1.0, 0.0, None, out, b, 32, 32, cur_stream())
+        return out
+
+
 class DcganEngine:
     """One DCGAN training state resident in HBM + the native step schedule."""
 
@@ -179,10 +201,16 @@ class DcganEngine:
     # ---- the step ---------------------------------------------------------------------------------------
     def _inputs(self, real, noise, lr, grad_scale):
         B = self.batch
-        if real is not None and (real.shape != (B, 3, 64, 64) or real.dtype != torch.float32):
-            raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
         si = StepInputs()
         keep = []
+        if isinstance(real, DeviceBatch):           # indices into a uint8 dataset resident in HBM: the step transforms them itself
+            if real.size(0) != B or tuple(real.data.shape[1:]) != (3, 32, 32):
+                raise JckError(f"DeviceBatch must index {B} images of a uint8 [N,3,32,32] dataset")
+            keep += [real.data, real.idx]
+            si.real_u8, si.real_idx = real.data.data_ptr(), real.idx.data_ptr()
+            real = None
+        elif real is not None and (real.shape != (B, 3, 64, 64) or real.dtype != torch.float32):
+            raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
 
         def ptr(t, shape):
             if t is None:

@@ -7,7 +7,7 @@ import pickle
 
 import torch
 
-from preprocess.dcgan_data_preprocessor import CIFAR_DIR, DCGANDataPreprocessor, _TensorSource
+from preprocess.dcgan_data_preprocessor import CIFAR_DIR, DCGANDataPreprocessor, DeviceLoader, _TensorSource
 
 
 class OneHotEncoder:
@@ -36,6 +36,8 @@ class CGANDataPreprocessor(DCGANDataPreprocessor):
         if self._train is None:
             self.transform_data()
         onehot = torch.nn.functional.one_hot(torch.tensor(self.targets, dtype=torch.int64), 100).to(torch.int64)
+        if self._train.dtype == torch.uint8:                                       # device-resident dataset: labels live in HBM too
+            return DeviceLoader(self._train, self.batch_size, onehot=onehot.to(self._train.device), seed=12345), self._metric
         ds = torch.utils.data.TensorDataset(self._train, onehot)
         sampler = None
         if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -11,12 +11,12 @@ import torch
 import torch.nn as nn
 
 from hipgan.dist import GradReducer
-from hipgan.engine import SCALAR_NAMES, CganEngine
+from hipgan.engine import SCALAR_NAMES, CganEngine, DeviceBatch
 from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
 from logger.utils import time_to_str
 from model.CGAN import weights_init
-from train.dcgan_trainer import EVAL_EVERY, LOG_EVERY, DCGANTrainer, _make_grid, _save_png
+from train.dcgan_trainer import EVAL_EVERY, LOG_EVERY, DCGANTrainer, _as_tensor, _make_grid, _save_png
 from train.trainer import Trainer
 from utils import require_gpu
 
@@ -151,7 +151,7 @@ class CGANTrainer(DCGANTrainer):
         best = {"fid": 1e10, "intra": 1e10, "is": 0}
         if self.rank == 0:
             real_batch = next(iter(loader))
-            _save_png(os.path.join(self.model_save_path, "real_image.png"), _make_grid(real_batch[0][:64], padding=5, normalize=True),
+            _save_png(os.path.join(self.model_save_path, "real_image.png"), _make_grid(_as_tensor(real_batch[0])[:64], padding=5, normalize=True),
                       "real images")
         image_save_path = os.path.join(self.model_save_path, "img")
         os.makedirs(image_save_path, exist_ok=True)
@@ -162,7 +162,7 @@ class CGANTrainer(DCGANTrainer):
         iters = 0
         for epoch in range(self.epoch):
             for i, data in enumerate(loader):
-                real = data[0].to(dev, torch.float32, non_blocking=True).contiguous()
+                real = data[0] if isinstance(data[0], DeviceBatch) else data[0].to(dev, torch.float32, non_blocking=True).contiguous()
                 labels = data[1].to(dev, torch.int64, non_blocking=True).contiguous()
                 b = real.size(0)
                 eng = self._engine_for(b)

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from hipgan import JckError
 from hipgan.dist import GradReducer
-from hipgan.engine import SCALAR_NAMES, DcganEngine
+from hipgan.engine import SCALAR_NAMES, DcganEngine, DeviceBatch
 from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
 from logger.utils import time_to_str
@@ -28,6 +28,11 @@ from train.trainer import Trainer
 from utils import require_gpu
 
 EVAL_EVERY, LOG_EVERY = 500, 100          # train/dcgan_trainer.py:198,191
+
+
+def _as_tensor(batch):
+    """fp32 NCHW view of a loader batch (a DeviceBatch is transformed on the device first)."""
+    return batch.materialize() if isinstance(batch, DeviceBatch) else batch
 
 
 def _make_grid(images, nrow=8, padding=2, normalize=True):
@@ -202,7 +207,7 @@ class DCGANTrainer(Trainer):
         if self.rank == 0:
             real_batch = next(iter(loader))
             _save_png(os.path.join(self.model_save_path, "real_image.png"),
-                      _make_grid(real_batch[0][:64], padding=5, normalize=True), "real images")
+                      _make_grid(_as_tensor(real_batch[0])[:64], padding=5, normalize=True), "real images")
         history = torch.zeros(max(n_iter, 1), len(SCALAR_NAMES), device=self.device)     # every step's scalars, on the device
         reduce = self.reducer.start if self.reducer else None
         start = time.time()
@@ -210,7 +215,7 @@ class DCGANTrainer(Trainer):
         iters = 0
         for epoch in range(self.epoch):
             for i, data in enumerate(loader):
-                real = data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
+                real = data[0] if isinstance(data[0], DeviceBatch) else data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
                 eng = self._engine_for(real.size(0))
                 noise = None
                 if self.host_rng:           # reference order: train/dcgan_trainer.py:160,168,171,111

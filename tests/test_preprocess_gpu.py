@@ -1,0 +1,97 @@
+"""Device-resident input pipeline: jck_img_prep_u8 against the oracle transform (bit-exact image, pinned to Pillow by
+tests/golden/resize_u8.json) and a full engine step fed by indices against the same step fed by the transformed tensor."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+def test_img_prep_u8_is_bit_exact(G):
+    from make_golden_resize import inputs
+    from oracle.preprocess_oracle import transform
+    x = inputs(7, 6, 32)
+    data = torch.from_numpy(x).cuda()
+    idx = torch.tensor([5, 0, 3, 3, 1], dtype=torch.int64, device="cuda")
+    b = idx.numel()
+    ref = torch.from_numpy(transform(x))[idx.cpu()]
+    out = torch.empty(b, 3, 64, 64, device="cuda")
+    G.lib.jck_img_prep_u8(G.PREC_F32, data, idx, None, 1.0, 0.0, None, out, b, 32, 32, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+    # NHWC4 output with the instance-noise mix (train/dcgan_trainer.py:160), both precisions; idx = NULL takes the first B
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(b, 3, 64, 64, generator=g)
+    for prec in (G.PREC_F32, G.PREC_BF16):
+        o = torch.full((b, 64, 64, 4), 7.0, dtype=G.DT[prec], device="cuda")
+        G.lib.jck_img_prep_u8(prec, data, None, noise.cuda(), 0.9, 0.1, o, None, b, 32, 32, G.cur_stream())
+        torch.cuda.synchronize()
+        want = 0.9 * torch.from_numpy(transform(x))[:b] + 0.1 * noise
+        G.check(G.from_nhwc(o, 3), want, 1e-6 if prec == G.PREC_F32 else 1e-2, "noisy image")
+        assert float(o[..., 3].float().abs().max()) == 0.0
+
+
+def test_step_from_device_batch_equals_step_from_tensor():
+    """Same weights, same noise: a step that gathers + transforms its batch from the uint8 dataset in HBM must give the
+    scalars and weights of a step that is handed the transformed fp32 tensor."""
+    from hipgan.engine import DcganEngine, DeviceBatch
+    from model import DCGAN
+    B = 16
+    g = torch.Generator().manual_seed(11)
+    data = (torch.rand(64, 3, 32, 32, generator=g) * 255).to(torch.uint8).cuda()
+    idx = torch.randperm(64, generator=g)[:B]
+    torch.manual_seed(12345)
+    net_g, net_d = DCGAN.Generator(), DCGAN.Discriminator()
+    net_g.apply(DCGAN.weights_init)
+    net_d.apply(DCGAN.weights_init)
+    res = []
+    for mode in ("tensor", "indices"):
+        eng = DcganEngine(batch=B, prec="f32", device="cuda:0")
+        eng.load_state(net_g.state_dict(), net_d.state_dict())
+        batch = DeviceBatch(data, idx)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        for _ in range(2):
+            noise = eng.draw_noise(gen)
+            eng.step_async(batch.materialize() if mode == "tensor" else batch, noise, 2e-4)
+        sc = eng.scalars()
+        gs, ds = eng.state_dicts()
+        res.append((sc, gs, ds))
+    (s0, g0, d0), (s1, g1, d1) = res
+    # the loss scalars and conv5's weight gradient are accumulated with float atomics (order varies run to run), so the two
+    # runs agree to rounding, not bitwise; Adam turns a rounding-level sign change of a ~0 gradient into a 2*lr weight step
+    for k in s0:
+        assert abs(s0[k] - s1[k]) <= 1e-3 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])      # second step: flips of step 1 feed in
+    for a, b in ((g0, g1), (d0, d1)):
+        for k in a:
+            x, y = a[k].double(), b[k].double()
+            assert float((x - y).abs().max()) <= 2 * 2 * 2e-4 + 1e-9, k
+            assert float((x - y).abs().mean()) <= 2e-5, k                          # 0.1 lr on average
+
+
+def test_device_loader_covers_dataset_and_feeds_trainer_batches():
+    from preprocess.dcgan_data_preprocessor import DeviceLoader
+    data = torch.arange(40, dtype=torch.uint8).view(40, 1, 1, 1).expand(40, 3, 32, 32).contiguous().cuda()
+    onehot = torch.nn.functional.one_hot(torch.arange(40) % 100, 100).cuda()
+    ld = DeviceLoader(data, 16, onehot=onehot, seed=1)
+    assert len(ld) == 3
+    seen = []
+    for batch in ld:
+        img, lab = batch
+        t = img.materialize()
+        assert t.shape == (img.size(0), 3, 64, 64)
+        ids = ((t[:, 0, 0, 0] * 0.5 + 0.5) * 255).round().long().cpu()          # constant images: pixel value = index
+        assert torch.equal(lab.argmax(1).cpu(), ids % 100)
+        seen += ids.tolist()
+    assert sorted(seen) == list(range(40))
+    assert [b[0].size(0) for b in ld] == [16, 16, 8]                            # ragged last batch, second epoch reshuffled
