@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="dcgan", choices=["dcgan", "cgan"],
                     help="dcgan = the headline config (BASELINE.json configs[1]); cgan = configs[3] (label-concat path, 10 classes)")
+    ap.add_argument("--input", default="tensor", choices=["tensor", "u8"],
+                    help="tensor: fp32 NCHW batches resident in HBM (default); u8: index batches into a uint8 32x32 dataset "
+                         "resident in HBM, Resize/ToTensor/Normalize done inside the step (the training pipeline's form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -136,6 +139,10 @@ def main():
     eng.load_state(net_g.state_dict(), net_d.state_dict())
     gen = torch.Generator(device=dev).manual_seed(2024 + rank)
     batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    if a.input == "u8":
+        from hipgan.engine import DeviceBatch
+        data = (torch.rand(50000, 3, 32, 32, device=dev, generator=gen) * 255).to(torch.uint8)        # CIFAR-sized
+        batches = [DeviceBatch(data, torch.randint(0, 50000, (B,), device=dev, generator=gen)) for _ in range(4)]
     # CGAN: 10-class synthetic labels as one-hot int64 [B,100] (classes 0-9 of the reference's 100-wide encoding)
     labels = [torch.nn.functional.one_hot(torch.randint(0, 10, (B,), device=dev, generator=gen), 100).to(torch.int64)
               for _ in range(4)] if cgan else None
@@ -175,7 +182,7 @@ def main():
     out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256" if not cgan else "images/sec (G+D step) CGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": a.prec if a.prec == "bf16" else "f32(split-bf16x3)",
-           "data": "synthetic",
+           "data": "synthetic" if a.input == "tensor" else "synthetic uint8 dataset in HBM, transformed in the step",
            "config": {"workload": (f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
                                    f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})") if not cgan else
                                   (f"CGAN 64x64x3, 10-class synthetic one-hot labels, batch {B} per GPU, full step incl. the "

@@ -128,6 +128,12 @@ int jck_img_prep(int prec, const float* img_nchw, const float* noise_nchw, float
  * (the transformed image without noise); either may be NULL. */
 int jck_img_prep_u8(int prec, const unsigned char* data, const int64_t* idx, const float* noise, float keep, float mix,
                     void* out_nhwc4, float* out_nchw, int B, int Hs, int Ws, void* stream);
+/* Evaluation branch (train/dcgan_trainer.py:202-206, train/cgan_trainer.py:227-231): out = (resize(pre_scale*in + pre_shift,
+ * [OH,OW]) - mean[c]) / std[c], bilinear with align_corners = False exactly as aten::upsample_bilinear2d (what
+ * torchvision.transforms.functional.resize does to a tensor; an upscale, so antialiasing is moot).  NCHW fp32 in / out;
+ * mean / std: device float[C]. */
+int jck_resize_norm(const float* in, float* out, int N, int C, int H, int W, int OH, int OW, float pre_scale, float pre_shift,
+                    const float* mean, const float* stdv, void* stream);
 int jck_nhwc4_to_nchw(int prec, const void* in, float* out_nchw, int N, int HW, void* stream);
 /* out = keep*x + mix*noise for an NHWC4 x                                      train/dcgan_trainer.py:171 */
 int jck_axpy_noise(int prec, const void* x, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,

@@ -75,6 +75,31 @@ __global__ void img_prep_u8_kernel(const unsigned char* __restrict__ data, const
   }
 }
 
+// Evaluation branch (train/dcgan_trainer.py:202-206): fake = 0.5*fake + 0.5; F.resize(fake, [OH, OW]) (bilinear,
+// align_corners = False: src = scale*(dst + 0.5) - 0.5 clamped at 0, as aten::upsample_bilinear2d computes it in fp32);
+// (fake - mean[c]) / std[c].  One pass, NCHW fp32 in and out.
+static __global__ void resize_norm_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int H, int W, int OH,
+                                          int OW, float pre_scale, float pre_shift, const float* __restrict__ mean,
+                                          const float* __restrict__ stdv) {
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  const long long total = (long long)N * C * OH * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const long long nc = i / ((long long)OW * OH);
+    const int c = (int)(nc % C);
+    const float fy = fmaxf(sh * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = in + nc * H * W;
+    auto at = [&](int yy, int xx) { return __fmaf_rn(pre_scale, p[yy * W + xx], pre_shift); };
+    const float top = __fmaf_rn(hx, at(y0, x0), __fmul_rn(lx, at(y0, x1)));
+    const float bot = __fmaf_rn(hx, at(y1, x0), __fmul_rn(lx, at(y1, x1)));
+    const float v = __fmaf_rn(hy, top, __fmul_rn(ly, bot));
+    out[i] = (v - mean[c]) / stdv[c];
+  }
+}
+
 // NHWC4 T -> NCHW f32 (module boundary)
 template <typename T>
 __global__ void nhwc4_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int N, int HW) {

@@ -632,6 +632,14 @@ extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const
 // ---------------------------------------------------------------------------------------------------------
 // images, heads
 // ---------------------------------------------------------------------------------------------------------
+extern "C" int jck_resize_norm(const float* in, float* out, int N, int C, int H, int W, int OH, int OW, float pre_scale,
+                               float pre_shift, const float* mean, const float* stdv, void* stream) {
+  if (!in || !out || !mean || !stdv || N < 1 || C < 1 || H < 1 || W < 1 || OH < 1 || OW < 1) JCK_FAIL(JCK_E_ARG, "resize_norm: bad arguments");
+  hipLaunchKernelGGL(resize_norm_kernel, dim3(ew_grid((long long)N * C * OH * OW)), dim3(256), 0, (hipStream_t)stream, in, out, N, C, H,
+                     W, OH, OW, pre_scale, pre_shift, mean, stdv);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 extern "C" int jck_img_prep_u8(int prec, const unsigned char* data, const int64_t* idx, const float* noise, float keep, float mix,
                                void* out_nhwc4, float* out_nchw, int B, int Hs, int Ws, void* stream) {
   if (!data || B < 1 || Hs < 1 || Ws < 1) JCK_FAIL(JCK_E_ARG, "img_prep_u8: bad arguments");

@@ -47,6 +47,7 @@ PROTOS = {
     "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
+    "jck_resize_norm": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp]),
     "jck_img_prep_u8": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
     "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),
     "jck_axpy_noise": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),

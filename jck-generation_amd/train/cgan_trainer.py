@@ -16,7 +16,7 @@ from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
 from logger.utils import time_to_str
 from model.CGAN import weights_init
-from train.dcgan_trainer import EVAL_EVERY, LOG_EVERY, DCGANTrainer, _as_tensor, _make_grid, _save_png
+from train.dcgan_trainer import EVAL_EVERY, LOG_EVERY, DCGANTrainer, _as_tensor, _make_grid, _save_png, inception_input
 from train.trainer import Trainer
 from utils import require_gpu
 
@@ -116,10 +116,7 @@ class CGANTrainer(DCGANTrainer):
         fake = eng.sample(fixed_noise, fixed_labels)                # 1000 images = ONE BatchNorm batch, as in the reference
         denorm = (0.5 * fake + 0.5).cpu()
         if self.metric is not None:
-            x = torch.nn.functional.interpolate(0.5 * fake + 0.5, size=[299, 299], mode="bilinear", align_corners=False)
-            mean = torch.tensor([0.485, 0.456, 0.406], device=x.device).view(1, 3, 1, 1)
-            std = torch.tensor([0.229, 0.224, 0.225], device=x.device).view(1, 3, 1, 1)
-            x = ((x - mean) / std).cpu()
+            x = inception_input(fake).cpu()                         # :227-231 in one device pass
             mk = lambda: torch.utils.data.DataLoader(x, batch_size=128, shuffle=False)
             inception_score, fid, intra = self.metric.inception_score(mk()), self.metric.fid(mk()), self.metric.intra_fid(x)
             self.logger.debug(f"inception score: {inception_score}\tfid: {fid}\tintra fid: {intra}")

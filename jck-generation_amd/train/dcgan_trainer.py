@@ -30,6 +30,20 @@ from utils import require_gpu
 EVAL_EVERY, LOG_EVERY = 500, 100          # train/dcgan_trainer.py:198,191
 
 
+def inception_input(fake):
+    """[-1,1] images [N,3,64,64] on the device -> what the metric network is fed (reference :202-206): 0.5*x + 0.5,
+    F.resize to 299x299 (bilinear), ImageNet normalisation - fused in jck_resize_norm."""
+    from hipgan import lib
+    from hipgan._lib import cur_stream
+    fake = fake.to(torch.float32).contiguous()
+    n = fake.size(0)
+    out = torch.empty(n, 3, 299, 299, dtype=torch.float32, device=fake.device)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=fake.device)
+    std = torch.tensor([0.229, 0.224, 0.225], device=fake.device)
+    lib.jck_resize_norm(fake, out, n, 3, fake.size(2), fake.size(3), 299, 299, 0.5, 0.5, mean, std, cur_stream())
+    return out
+
+
 def _as_tensor(batch):
     """fp32 NCHW view of a loader batch (a DeviceBatch is transformed on the device first)."""
     return batch.materialize() if isinstance(batch, DeviceBatch) else batch
@@ -181,11 +195,7 @@ class DCGANTrainer(Trainer):
         if self.metric is None:
             self.save_model("latest", iters, 0.0, fake.cpu())
             return
-        fake = 0.5 * fake + 0.5
-        fake = torch.nn.functional.interpolate(fake, size=[299, 299], mode="bilinear", align_corners=False)
-        mean = torch.tensor([0.485, 0.456, 0.406], device=fake.device).view(1, 3, 1, 1)
-        std = torch.tensor([0.229, 0.224, 0.225], device=fake.device).view(1, 3, 1, 1)
-        fake = ((fake - mean) / std).cpu()
+        fake = inception_input(fake).cpu()                       # :202-206 in one device pass
         loader = torch.utils.data.DataLoader(fake, batch_size=64)
         inception_score = self.metric.inception_score(loader)
         fid = self.metric.fid(torch.utils.data.DataLoader(fake, batch_size=64))

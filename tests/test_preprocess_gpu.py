@@ -95,3 +95,27 @@ def test_device_loader_covers_dataset_and_feeds_trainer_batches():
         seen += ids.tolist()
     assert sorted(seen) == list(range(40))
     assert [b[0].size(0) for b in ld] == [16, 16, 8]                            # ragged last batch, second epoch reshuffled
+
+
+def test_resize_norm_matches_aten_bilinear(G):
+    """Evaluation branch (train/dcgan_trainer.py:202-206) against the ops the reference calls, run by PyTorch on the CPU."""
+    g = torch.Generator().manual_seed(4)
+    fake = torch.tanh(torch.randn(5, 3, 64, 64, generator=g))
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    ref = torch.nn.functional.interpolate(0.5 * fake + 0.5, size=[299, 299], mode="bilinear", align_corners=False)
+    ref = (ref - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    out = torch.empty(5, 3, 299, 299, device="cuda")
+    G.lib.jck_resize_norm(fake.cuda(), out, 5, 3, 64, 64, 299, 299, 0.5, 0.5, mean.cuda(), std.cuda(), G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(out.cpu(), ref, 2e-6, "resize + normalise")
+    from train.dcgan_trainer import inception_input
+    assert torch.equal(inception_input(fake.cuda()).cpu(), out.cpu())
+    # non-square, downscale factor and generic affine
+    x = torch.randn(2, 4, 20, 12, generator=g)
+    m, s = torch.zeros(4), torch.ones(4)
+    ref = torch.nn.functional.interpolate(2.0 * x - 1.0, size=[33, 47], mode="bilinear", align_corners=False)
+    out = torch.empty(2, 4, 33, 47, device="cuda")
+    G.lib.jck_resize_norm(x.cuda(), out, 2, 4, 20, 12, 33, 47, 2.0, -1.0, m.cuda(), s.cuda(), G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(out.cpu(), ref, 2e-6, "generic resize")
