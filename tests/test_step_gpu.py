@@ -22,14 +22,24 @@ def _noise(B, seed):
             "n2": torch.randn(B, 3, 64, 64, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g)}
 
 
-def _run(B, steps, prec, lr=2e-4, teacher_forced=True):
+def mnist_shaped(n):
+    """BASELINE.json configs[0]: MNIST-shaped synthetic input, adapted as SURVEY section 8(d) prescribes - [n,1,28,28] gray
+    in [0,1] (seeded), repeated to 3 channels, bilinear resize to 64x64, Normalize(0.5, 0.5); the nets only take 3x64x64."""
+    g = torch.Generator().manual_seed(2024)
+    x = torch.rand(n, 1, 28, 28, generator=g)
+    x = x * (torch.rand(n, 1, 28, 28, generator=g) > 0.6)                # mostly-black strokes-on-background statistics
+    x = torch.nn.functional.interpolate(x.repeat(1, 3, 1, 1), size=64, mode="bilinear", align_corners=False)
+    return (x - 0.5) / 0.5
+
+
+def _run(B, steps, prec, lr=2e-4, teacher_forced=True, images=None):
     from hipgan.engine import DcganEngine
     from oracle.gan_oracle import GanOracle
     from util import synth_images
     orc = GanOracle("dcgan", lr=lr, seed=12345)
     eng = DcganEngine(batch=B, prec=prec)
     eng.load_state(orc.g, orc.d)
-    imgs = synth_images(B * steps)
+    imgs = synth_images(B * steps) if images is None else images(B * steps)
     out = []
     for s in range(steps):
         real, nz = imgs[s * B:(s + 1) * B], _noise(B, 100 + s)
@@ -192,3 +202,31 @@ def test_bf16_trajectory_statistics():
     floor = sum(sd["rel_d"][10:30]) / 20
     assert sum(rd[10:30]) / 20 < max(3 * floor, 0.15), (rd, floor)
     assert rd[0] < 3e-2
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_config0_mnist_shaped_batch64(prec, tol):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): batch 64, MNIST-shaped input; per-step losses of the
+    HIP path against the oracle (= the reference's trainer arithmetic) from identical state."""
+    orc, eng, out = _run(64, 2, prec, images=mnist_shaped)
+    for s, (ref, got, dgr, ggr) in enumerate(out):
+        for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+            assert _rel(got[k], ref[k]) < tol, (s, k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_full_size_step_batch256(prec, tol):
+    """BASELINE.json configs[1] at its full size (batch 256: the batched three-pass D schedule, 128x128 LDS-DMA tiles,
+    split-K weight gradients at their production shapes): one step against the oracle, plus what must hold at any size -
+    D(x), D(G(z)) are means of probabilities, loss_d = loss_real + loss_fake + 10 gp, and BatchNorm saw 4 D and 1 G batches."""
+    orc, eng, out = _run(256, 1, prec)
+    ref, got, dgr, ggr = out[0]
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(got[k], ref[k]) < tol, (k, got[k], ref[k])
+    assert 0.0 < got["d_x"] < 1.0 and 0.0 < got["d_gz1"] < 1.0 and 0.0 < got["d_gz2"] < 1.0
+    assert abs(got["loss_d"] - (got["loss_real"] + got["loss_fake"] + 10.0 * got["gp"])) < 1e-4 * max(1.0, abs(got["loss_d"]))
+    assert int(eng.named_views("d")["norm1.num_batches_tracked"]) == 4 and int(eng.named_views("g")["norm1.num_batches_tracked"]) == 1
+    # D's gradients come from identical weights.  G's come through the D that Adam has just stepped: an element of D whose
+    # gradient was within rounding of 0 moved the other way (2*lr), which at batch 256 shows as ~1e-2 in G's gradients.
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3 if prec == "f32" else 1.2e-1)
+    _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2 if prec == "f32" else 2e-1)
