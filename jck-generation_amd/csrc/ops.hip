@@ -386,26 +386,36 @@ static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t
   return JCK_OK;
 }
 
-static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-  constexpr int LDSB = 2 * 2 * WGD_BKP * 256;
-  ProfScope prof(10, p.flops, st);
+template <int NSTG, int NW>
+static int launch_wgrad_dma_t(const WgradParams& q, int grid, hipStream_t st) {
+  constexpr int LDSB = NSTG * 2 * WGD_BKP * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
-  WgradParams q = p;
-  q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
-  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(pl.gx * pl.gy * pl.Z), dim3(256), LDSB, st, q);
+  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, NW>), dim3(grid), dim3(NW * 64), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
+}
+static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+  ProfScope prof(10, p.flops, st);
+  WgradParams q = p;
+  q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
+  const int grid = pl.gx * pl.gy * pl.Z;
+  static const int stg = getenv("JCK_WGRAD_STG") ? atoi(getenv("JCK_WGRAD_STG")) : 2;
+  // 8 waves: +7 % on the isolated product, -1 % on the whole step (more waves competing with the dgrad chain): default 4
+  static const int nw = getenv("JCK_WGRAD_WAVES") ? atoi(getenv("JCK_WGRAD_WAVES")) : 4;
+  if (nw == 8) return stg == 3 ? launch_wgrad_dma_t<3, 8>(q, grid, st) : launch_wgrad_dma_t<2, 8>(q, grid, st);
+  return stg == 3 ? launch_wgrad_dma_t<3, 4>(q, grid, st) : launch_wgrad_dma_t<2, 4>(q, grid, st);
 }
 
 template <class P>
 static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, hipStream_t st) {
   static const int use_dma = getenv("JCK_WGRAD_DMA") ? atoi(getenv("JCK_WGRAD_DMA")) : 1;
   if (use_dma && !P::IS_F32 && pl.BG == 128 && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
-      pl.mchunk % WGD_BKP == 0)
+      pl.mchunk % WGD_BKP == 0 && p.logOW <= 6 &&
+      ((1 << p.logOHW) <= WGD_BKP || p.H == p.sy * ((1 << p.logOHW) >> p.logOW)))     // constant 64-pixel address step (wgrad.hpp)
     return launch_wgrad_dma(p, pl, st);
   if (pl.BG == 128 && pl.BS == 128 && nsub == 1) return launch_wgrad_t<P, 128, 128, 1>(p, pl, st);
   if (pl.BG == 128 && pl.BS == 64 && nsub == 1) return launch_wgrad_t<P, 128, 64, 1>(p, pl, st);

@@ -277,8 +277,14 @@ static __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float*
 static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page_w[64];
 
 #define WGD_BKP 64
-static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
-  constexpr int BG = 128, BS = 128, FM = 4, FN = 4;
+// NW = 4 or 8 waves per workgroup.  The fill rate of a CU scales with the number of waves that issue LDS-DMA (an issuing wave
+// stalls ~0.1 us per 1 KiB piece and cannot feed the MFMA meanwhile): 8 waves each issue half the pieces and own a 64x32
+// part of the tile, without the extra split-K slabs that a second 4-wave workgroup per CU would cost.
+template <int NSTG, int NW>
+static __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(const WgradParams p) {
+  constexpr int BG = 128, BS = 128, FM = 4, FN = NW == 8 ? 2 : 4;
+  constexpr int NQ = 16 / NW;                                        // DMA rounds per operand tile: 4 rows per wave and round
+  constexpr int SW = 128 / (NW / 2);                                 // small-side columns per wave: 64 (4 waves) or 32 (8 waves)
   constexpr int ROWB = 256;                                          // bytes per tile row (128 bf16)
   constexpr int TILE_BYTES = WGD_BKP * ROWB;                         // 16 KB per operand tile
   constexpr int STG_BYTES = 2 * TILE_BYTES;
@@ -315,36 +321,56 @@ static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue = [&](int mbase, int stage) {
+  // Per-lane gather state of the 4 + 4 DMA pieces, advanced by 64 pixel rows per k-step instead of being re-derived: the
+  // image rows of consecutive images are contiguous, so 64 more pixels are a CONSTANT byte step on both operands
+  // (64/OHW images when an image has <= 64 output pixels, else 64/OW output rows = sy*64/OW input rows; H = sy*OH);
+  // only the vertical bound check follows oy.  32-bit byte offsets (operands < 2 GiB).
+  const int OHW = 1 << p.logOHW, OW = 1 << p.logOW, OH = OHW >> p.logOW;
+  const bool small_img = OHW <= WGD_BKP;
+  const unsigned binc = (unsigned)((small_img ? (WGD_BKP / OHW) * p.H * p.W : (WGD_BKP / OW) * p.sy * p.W) << p.logCb) * 2u;
+  const unsigned sinc = (unsigned)(WGD_BKP * p.CsStride) * 2u;
+  const int doy = small_img ? 0 : WGD_BKP / OW;
+  unsigned boff[NQ], soff[NQ];
+  int oyq[NQ], mq[NQ], dyq[NQ];
+  bool bokx[NQ], sokc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int row = q * (4 * NW) + wave * 4 + r4;                      // 0..63 inside the tile
+    const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));        // logical 16-byte chunk fetched by this lane
+    const int m = mz0 + row;
+    const int n = m >> p.logOHW;
+    const int rem = m & (OHW - 1);
+    const int oy = rem >> p.logOW, ox = rem & (OW - 1);
+    // gathered side: column g0 + lc*8 -> (tap, cb)
+    const int col = cb_base + lc * 8;
+    const bool second = col >= Cb;                                     // only when Cb == 64
+    const int dyv = second ? dyB : dyA, dxv = second ? dxB : dxA;
+    const bool tv = second ? tvB : tvA;
+    const int cb = second ? col - Cb : col;
+    const int ix = ox * p.sx + dxv;
+    boff[q] = (unsigned)(((((n * p.H + oy * p.sy + dyv) * p.W + ix) << p.logCb) + cb) * 2);
+    bokx[q] = tv && (unsigned)ix < (unsigned)p.W;
+    oyq[q] = oy; dyq[q] = dyv; mq[q] = m;
+    soff[q] = (unsigned)((m * p.CsStride + s0 + lc * 8) * 2);
+    sokc[q] = s0 + lc * 8 < p.CsStride;
+  }
+  auto issue = [&](int stage) {
     unsigned char* gt = lds + stage * STG_BYTES;
     unsigned char* st = gt + TILE_BYTES;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = q * 16 + wave * 4 + r4;                          // 0..63 inside the tile
-      const int lc = pc ^ (((row & 3) << 2) | ((row >> 2) & 3));      // logical 16-byte chunk fetched by this lane
-      const int m = mbase + row;
-      const bool rok = m < mz1;
-      const int n = m >> p.logOHW;
-      const int rem = m & ((1 << p.logOHW) - 1);
-      const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
-      // gathered side: column g0 + lc*8 -> (tap, cb)
-      const int col = cb_base + lc * 8;
-      const bool second = col >= Cb;                                   // only when Cb == 64
-      const int dyv = second ? dyB : dyA, dxv = second ? dxB : dxA;
-      const bool tv = second ? tvB : tvA;
-      const int cb = second ? col - Cb : col;
-      const int iy = iy0 + dyv, ix = ix0 + dxv;
-      const bool ok = rok && tv && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const long long goff = ((((long long)n * p.H + iy) * p.W + ix) << p.logCb) + cb;
-      const unsigned char* gsrc = ok ? bigb + goff * 2 : zp;
-      __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(gt + (q * 16 + wave * 4) * ROWB), 16, 0, 0);
-      const bool sok = rok && (s0 + lc * 8 < p.CsStride);
-      const unsigned char* ssrc = sok ? sb_ + ((long long)m * p.CsStride + s0 + lc * 8) * 2 : zp;
-      __builtin_amdgcn_global_load_lds((gptr_t)ssrc, (lptr_t)(st + (q * 16 + wave * 4) * ROWB), 16, 0, 0);
+    for (int q = 0; q < NQ; ++q) {
+      const bool rok = mq[q] < mz1;
+      const bool ok = rok && bokx[q] && (unsigned)(oyq[q] * p.sy + dyq[q]) < (unsigned)p.H;
+      const unsigned char* gsrc = ok ? bigb + boff[q] : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(gt + (q * (4 * NW) + wave * 4) * ROWB), 16, 0, 0);
+      const unsigned char* ssrc = (rok && sokc[q]) ? sb_ + soff[q] : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)ssrc, (lptr_t)(st + (q * (4 * NW) + wave * 4) * ROWB), 16, 0, 0);
+      boff[q] += binc; soff[q] += sinc; mq[q] += WGD_BKP;
+      oyq[q] = (oyq[q] + doy) & (OH - 1);
     }
   };
 
-  const int wg = wave >> 1, ws = wave & 1;
+  const int wg = NW == 8 ? wave >> 2 : wave >> 1, ws = NW == 8 ? wave & 3 : wave & 1;
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -373,7 +399,7 @@ static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int c0 = ws * 64 + j * 16;
+        const int c0 = ws * SW + j * 16;
         b[j] = join_tr(lds_tr4(tr_addr(st, row, c0)), lds_tr4(tr_addr(st, row + 4, c0)));
       }
 #pragma unroll
@@ -384,19 +410,30 @@ static __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams
   };
 
   const int nk = (mz1 > mz0) ? (mz1 - mz0 + WGD_BKP - 1) / WGD_BKP : 0;
-  issue(mz0, 0);                                                      // rows past mz1 read the zero page
+  // NSTG LDS stages (2: two workgroups share a CU; 3-4: one workgroup per CU keeps 2-3 k-steps of loads in flight - the
+  // split-K plan launches ~one workgroup per CU).  8 DMA pieces per stage and wave: the counted wait leaves the NSTG-2
+  // youngest stages in flight; stages past the end read the zero page and are never consumed.
+#pragma unroll
+  for (int s0_ = 0; s0_ < NSTG - 1; ++s0_) issue(s0_);
+  int st_c = 0, st_i = NSTG - 1;
   for (int k = 0; k < nk; ++k) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (2 * NQ * (NSTG - 2) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (2 * NQ * (NSTG - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (2 * NQ * (NSTG - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(NSTG == 2, "add the vmcnt literal");
     __builtin_amdgcn_s_barrier();
-    issue(mz0 + (k + 1) * WGD_BKP, (k + 1) & 1);                      // past the end: all zero page, never read
-    compute(k & 1);
+    issue(st_i);
+    compute(st_c);
+    st_c = (st_c + 1 == NSTG) ? 0 : st_c + 1;
+    st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float* part = p.part + (long long)bz * p.CsRows * p.ncols;
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int cs = s0 + ws * 64 + j * 16 + (lane & 15);
+    const int cs = s0 + ws * SW + j * 16 + (lane & 15);
     if (cs >= p.CsRows) continue;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
