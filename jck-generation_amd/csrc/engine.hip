@@ -691,7 +691,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
-  hipStream_t sA = e->overlap ? e->sA : nullptr;
+  static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
+  hipStream_t sA = (e->overlap && wgrad_side) ? e->sA : nullptr;
   const bool ov_g = e->overlap, ov_gp = e->overlap && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
