@@ -75,6 +75,20 @@ def main():
         vals = [sq[k].get(c, []) for c in cols] + [mf.get(k, {}).get(c, []) for c in cols2]
         md.append(f"| `{k}` | " + " | ".join(f"{sum(v) / len(v):.3g}" if v else "-" for v in vals) + " |")
     open(os.path.join(DST, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
+    # one step as a timeline: start offset, duration, HIP stream, kernel (from the kernel trace of the stats run)
+    import re
+    tr = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], r["Kernel_Name"], r["Grid_Size_X"])
+          for r in csv.DictReader(open(os.path.join(SRC, "bench_kernel_trace.csv")))]
+    tr.sort()
+    marks = [e[0] for e in tr if "step_tail" in e[3]]
+    if len(marks) >= 3:
+        a, b = marks[-3], marks[-2]
+        lines = [f"# one traced step of `bench.py` ({(b - a) / 1e3:.1f} us under rocprofv3): start us | duration us | HIP stream | kernel | grid"]
+        for st, en, sid, name, grid in tr:
+            if a < st <= b:
+                nm = re.sub(r"\(.*", "", name.replace("void ", "")).replace("unsigned short", "bf16")[:60]
+                lines.append(f"{(st - a) / 1e3:8.1f} {(en - st) / 1e3:7.1f} s{sid} {nm} g{grid}")
+        open(os.path.join(DST, f"{tag}_timeline.txt"), "w").write("\n".join(lines) + "\n")
     for extra in sys.argv[2:]:
         shutil.copy(extra, os.path.join(DST, f"{tag}_{os.path.basename(extra)}"))
     print("wrote profiles/%s_*" % tag)
