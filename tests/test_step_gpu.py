@@ -230,3 +230,19 @@ def test_full_size_step_batch256(prec, tol):
     # gradient was within rounding of 0 moved the other way (2*lr), which at batch 256 shows as ~1e-2 in G's gradients.
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3 if prec == "f32" else 1.2e-1)
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2 if prec == "f32" else 2e-1)
+
+
+@pytest.mark.parametrize("env", [{"JCK_BATCHED": "0"}, {"JCK_BATCHED": "2"}, {"JCK_BATCHED": "4"}, {"JCK_OVERLAP": "0"},
+                                 {"JCK_FUSE_BNBWD": "1"}, {"JCK_BATCHED": "0", "JCK_FUSE_BNBWD": "1"}])
+def test_alternative_schedules_give_the_same_step(env, monkeypatch):
+    """The schedules kept behind environment switches (per-pass D passes with stream overlap, the 2B / split-forward batched
+    variants, no overlap at all, BatchNorm-backward statistics in the dgrad epilogue) must all be the same arithmetic: one
+    exact-fp32 step of each against the oracle.  The switches are read when an engine is created."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    orc, eng, out = _run(16, 1, "f32")
+    ref, got, dgr, ggr = out[0]
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(got[k], ref[k]) < 1e-3, (env, k, got[k], ref[k])
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
+    _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
