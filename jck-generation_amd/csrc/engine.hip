@@ -562,8 +562,23 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
 // have run (d_forward(xhat), d_head(mode 1), d_backward(wgrad=false, xgrad=true)), so d_g[i] = gy_i, d_bn[i].sums = first-
 // backward sums, g_h = gradient at the Linear(8392,256) output, d_gx = g_x, norms = ||g_x[n]||.  Accumulates
 // lambda * dGP/dtheta into D's gradient arena.  Derivation + fp64 check: tests/test_gp_double_backward_math.py.
-static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st) {
+// `side` (optional): the weight-gradient products run there beside the v-chain / reverse sweep; they share the split-K
+// workspace, so everything that uses it is ordered on that one stream, and the main stream joins it before the reverse sweep
+// (which overwrites the v_i the v-chain products read and runs the Linear weight gradient on the main stream) and at the end.
+static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st,
+                              hipStream_t side = nullptr) {
   const size_t esz = e->esz;
+  auto fork = [&](int k) -> hipStream_t {            // work enqueued on the returned stream starts after everything on st so far
+    if (!side) return st;
+    (void)hipEventRecord(e->evW[k], st);
+    (void)hipStreamWaitEvent(side, e->evW[k], 0);
+    return side;
+  };
+  auto join = [&]() {
+    if (!side) return;
+    (void)hipEventRecord(e->evWdone, side);
+    (void)hipStreamWaitEvent(st, e->evWdone, 0);
+  };
   HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->prob_gp, e->prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
   JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, 64 * 64, e->d_u0, st));
@@ -573,7 +588,7 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // g_{a_{i-1}} = convT(gy_i; W_i):  dW_i += wgrad(gy_i, u_{i-1}),  v_i = conv(u_{i-1}; W_i)
-    JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
     JCK_TRY(jck_conv_down(e->prec, u, e->d_down[i], e->d_v[i], nullptr, nullptr, B, hb, hb, cb, cs, st));
     JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], e->d_y[i], e->d_g[i], e->d_bn[i].aux, e->d_bn[i].sums, e->P(e->LD, e->dp, NAMES_NW[i]),
                            LRELU, e->bn2_ws[i], e->d_v[i], e->d_xdir[i], e->P(e->LD, e->dg, NAMES_NW[i]), rows, cs, st));
@@ -581,12 +596,13 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
   }
   // head: gc[:, :8192] = gh W1 -> adj(gh) = [u4 | 0] W1^T, dW1 += gh^T [u4 | 0]; gh = gh' * m/(1-p); gh' = ds w2; ds = p(1-p)
   JCK_TRY(jck_concat_rows(e->prec, e->d_v[3], FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
-  JCK_TRY(jck_linear_wgrad(e->prec, e->gh_b1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
+  JCK_TRY(jck_linear_wgrad(e->prec, e->gh_b1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
   JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), e->prob_gp, B, L1_OUT, e->rs,
                        e->P(e->LD, e->dg, "linear2.weight"), st));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
+  join();
   JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[3], st));
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
@@ -594,10 +610,11 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
     JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], e->d_y[i], e->d_xdir[i], e->d_bn[i].aux, e->P(e->LD, e->dp, NAMES_NW[i]), e->bn2_ws[i],
                             LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, st));
     const void* big = i == 0 ? xhat : e->d_a[i - 1];
-    JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, st));
+    JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
     if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, e->d_v[i], e->d_up[i], e->d_v[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
+  join();
   return JCK_OK;
 }
 
@@ -799,7 +816,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
-        JCK_TRY(gp_double_backward(e, e->xhat, B, 10.0f, in->drop_mask[2], st));
+        static const bool cg_side = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
+        JCK_TRY(gp_double_backward(e, e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side ? sA : nullptr));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
       }
       return JCK_OK;
