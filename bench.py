@@ -115,12 +115,20 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    # test hooks (tests/test_bench_multirank_gpu.py rehearses the N > 1 control flow on a one-GPU box): every rank on
+    # cuda:0 and gloo instead of RCCL (RCCL needs one device per rank).  Never set by the driver.
+    if os.environ.get("JCK_BENCH_ONE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("JCK_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from hipgan.engine import CganEngine, DcganEngine
     from hipgan.dist import GradReducer
@@ -196,12 +204,15 @@ def main():
     out["step_mfma"] = {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                         "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
-    if rank == 0 and not a.no_roofline:
-        import ctypes as C
-        lib.jck_prof_enable(1)
+    if not a.no_roofline:
+        # every rank runs the three extra steps (they contain the gradient all-reduce); rank 0 times its launches
+        if rank == 0:
+            lib.jck_prof_enable(1)
         for i in range(3):
             one_step(i)
         torch.cuda.synchronize()
+    if rank == 0 and not a.no_roofline:
+        import ctypes as C
         lib.jck_prof_enable(0)
         cap = 32
         names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()

@@ -1,0 +1,33 @@
+"""bench.py with N > 1 ranks: the control flow the driver runs on the 8-GPU node (barriers, gradient all-reduce inside the
+timed steps AND inside the roofline leg, max-over-ranks timing, one JSON line from rank 0), rehearsed with two ranks on the
+one GPU of this box over gloo (test hooks JCK_BENCH_ONE_GPU / JCK_BENCH_BACKEND; RCCL needs one device per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_terminates_and_reports_whole_job_rate():
+    env = dict(os.environ, JCK_BENCH_ONE_GPU="1", JCK_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--batch", "16"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert abs(out["value"] - 2 * 16 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]      # whole-job images/sec
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in out                              # N = 1 only
+    for k in ("loss_d", "loss_g", "gp"):
+        v = out["losses_last_step"][k]
+        assert v == v and abs(v) < 1e3
