@@ -246,3 +246,14 @@ def test_alternative_schedules_give_the_same_step(env, monkeypatch):
         assert _rel(got[k], ref[k]) < 1e-3, (env, k, got[k], ref[k])
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
+
+
+def test_batched_schedule_with_a_non_power_of_two_batch():
+    """Batch 24 (ragged last batches are multiples of 8 for CIFAR's 50000 = 195*256 + 80): the batched 3B D pass with groups
+    of 24 images - tiles, statistic slots and BatchNorm groups must still line up."""
+    orc, eng, out = _run(24, 2, "f32")
+    for s, (ref, got, dgr, ggr) in enumerate(out):
+        for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+            assert _rel(got[k], ref[k]) < 1e-3, (s, k, got[k], ref[k])
+    ref, got, dgr, ggr = out[-1]
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
