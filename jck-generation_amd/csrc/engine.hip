@@ -111,7 +111,7 @@ struct jck_engine {
   void *d_down[4], *d_up[4];
   float *d_head_wp, *d_head_dwp;
   void *g1_w, *g_up[4], *g_down[4];
-  // activations: two complete D sets (set 1 lets the gradient-penalty pass run on a side stream beside the D(fake) pass)
+  // activations: three B-image D sets for the per-pass schedules (each pass that may run concurrently has its own)
   struct DSet { void *y[4], *a[4], *g[4], *gx; BnBuf bn[4]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
   void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
   void*& d_gx = dset[0].gx;

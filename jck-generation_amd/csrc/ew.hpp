@@ -248,22 +248,6 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
   }
 }
 
-// applies `npass` deferred (mean, unbiased var) records in order - bitwise the same recurrence as npass sequential updates
-static __global__ void bn_running_update_kernel(const float* __restrict__ slots, int npass, long long pass_stride, float momentum,
-                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                long long* __restrict__ nbt, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += npass;
-  if (c >= C) return;
-  float rm = running_mean[c], rv = running_var[c];
-  for (int p = 0; p < npass; ++p) {
-    rm = (1.f - momentum) * rm + momentum * slots[p * pass_stride + c];
-    rv = (1.f - momentum) * rv + momentum * slots[p * pass_stride + C + c];
-  }
-  running_mean[c] = rm;
-  running_var[c] = rv;
-}
-
 // a = act(scale[c]*y + shift[c]), act = x>0 ? x : slope*x
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ aux, float slope,
@@ -707,22 +691,8 @@ __global__ void pad_rows_kernel(const float* __restrict__ in, int B, int Ci, int
 
 // acc: 0 loss_real 1 loss_fake 2 loss_g 3 sum p(real) 4 sum p(fake) 5 sum p(g phase) 6 sum (||g||-1)^2
 // out: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake      (train/dcgan_trainer.py:179,192-193)
-static __global__ void scalars_finalize_kernel(const float* __restrict__ acc, float invB, float lambda_gp, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float lr = acc[0] * invB, lf = acc[1] * invB, gp = acc[6] * invB;
-    out[0] = (lr + lf) + lambda_gp * gp;
-    out[1] = acc[2] * invB;
-    out[2] = acc[3] * invB;
-    out[3] = acc[4] * invB;
-    out[4] = acc[5] * invB;
-    out[5] = gp;
-    out[6] = lr;
-    out[7] = lf;
-  }
-}
-
 // End of a step in ONE launch: the deferred BatchNorm running-stat records of D's four layers (blockIdx.y = layer, same
-// recurrence as bn_running_update_kernel) and the logged scalars (blockIdx.y = 4).
+// recurrence as sequential momentum updates) and the logged scalars (blockIdx.y = 4).
 struct TailLayer { const float* rec; float* rm; float* rv; long long* nbt; int C; };
 struct TailJobs { TailLayer l[4]; int npass; float momentum; const float* acc; float invB, lambda_gp; float* out; };
 static __global__ void step_tail_kernel(const TailJobs t) {
