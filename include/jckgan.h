@@ -272,6 +272,10 @@ int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_
 /* debug probe: lane l of one wave returns the 8 elements wgrad's transposed LDS read hands it from a
  * [32][ld] 16-bit tile: out[l*8+j] must equal in[(8*(l>>4)+j)*ld + (l&15)] */
 int jck_debug_tr_read(const void* in, int ld, void* out, void* stream);
+/* development probe: per-wave s_memtime totals {wait+barrier, DMA issue, LDS reads+MFMA, whole kernel} of the last
+ * weight-gradient launch made with JCK_WGRAD_STAMP=1 (n = number of 64-bit values to copy, 4 per wave, 8 waves per workgroup
+ * slot, first 1024 workgroups); synchronises the device */
+int jck_debug_wgrad_stamps(unsigned long long* out, int n);
 
 #ifdef __cplusplus
 }

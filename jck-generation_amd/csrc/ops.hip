@@ -406,6 +406,28 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
   static const int stg = getenv("JCK_WGRAD_STG") ? atoi(getenv("JCK_WGRAD_STG")) : 2;
   // 8 waves: +7 % on the isolated product, -1 % on the whole step (more waves competing with the dgrad chain): default 4
   static const int nw = getenv("JCK_WGRAD_WAVES") ? atoi(getenv("JCK_WGRAD_WAVES")) : 4;
+  static const int stamp = getenv("JCK_WGRAD_STAMP") ? atoi(getenv("JCK_WGRAD_STAMP")) : 0;
+  static const int wsp = getenv("JCK_WGRAD_WS") ? atoi(getenv("JCK_WGRAD_WS")) : 1;
+  if (wsp) {                                         // wave-specialised: 4 loader + 4 consumer waves, 3 stages (96 KB)
+    constexpr int LDSB = 3 * 2 * WGD_BKP * 256;
+    static bool attr_ws = false;
+    if (!attr_ws) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+      attr_ws = true;
+    }
+    if (stamp) hipLaunchKernelGGL((wgrad_dma_kernel<3, 4, true, true>), dim3(grid), dim3(512), LDSB, st, q);
+    else hipLaunchKernelGGL((wgrad_dma_kernel<3, 4, false, true>), dim3(grid), dim3(512), LDSB, st, q);
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
+  if (stamp) {
+    constexpr int LDSB = 2 * 2 * WGD_BKP * 256;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    hipLaunchKernelGGL((wgrad_dma_kernel<2, 4, true>), dim3(grid), dim3(256), LDSB, st, q);
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   if (nw == 8) return stg == 3 ? launch_wgrad_dma_t<3, 8>(q, grid, st) : launch_wgrad_dma_t<2, 8>(q, grid, st);
   return stg == 3 ? launch_wgrad_dma_t<3, 4>(q, grid, st) : launch_wgrad_dma_t<2, 4>(q, grid, st);
 }
@@ -954,5 +976,12 @@ extern "C" int jck_cgan_z(int prec, const float* z, const int64_t* labels, int B
   DISPATCH_T(prec, hipLaunchKernelGGL(cgan_z_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, z,
                                       (const long long*)labels, B, NZ, NL, CiPad, (T*)out));
   HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// development probe: copies the per-wave stamp totals of the last stamped wgrad_dma launch (see wgrad.hpp) to the host
+extern "C" int jck_debug_wgrad_stamps(unsigned long long* out, int n) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgd_stamps), (size_t)n * sizeof(unsigned long long)));
   return JCK_OK;
 }

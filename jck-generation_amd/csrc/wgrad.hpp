@@ -280,8 +280,17 @@ static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page_w[64
 // NW = 4 or 8 waves per workgroup.  The fill rate of a CU scales with the number of waves that issue LDS-DMA (an issuing wave
 // stalls ~0.1 us per 1 KiB piece and cannot feed the MFMA meanwhile): 8 waves each issue half the pieces and own a 64x32
 // part of the tile, without the extra split-K slabs that a second 4-wave workgroup per CU would cost.
-template <int NSTG, int NW>
-static __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(const WgradParams p) {
+// STAMP (development): per-wave s_memtime totals of the three parts of a k-step - [0] wait + barrier, [1] DMA issue,
+// [2] LDS reads + MFMA - and [3] the whole kernel, read back with jck_debug_wgrad_stamps
+static __device__ unsigned long long g_wgd_stamps[1024 * 8 * 4];
+// WS (wave-specialised, 8 waves, NW = 4, NSTG = 3): the stamps show a 4-wave workgroup spending 38 % of a k-step stalled in the
+// issue of its 8 LDS-DMA pieces (the fill path pushes back at ~35 B/clk/CU - its hardware rate) and 45 % in LDS reads + MFMA,
+// one after the other in each wave's instruction stream, while waiting for data takes 2 %.  With WS waves 4-7 only issue the
+// DMA (two stages ahead) and waves 0-3 only read fragments and feed the MFMA, one loader and one consumer per SIMD, so the
+// two halves of a k-step overlap; one s_barrier per k-step hands a landed stage over and frees the stage read last.
+template <int NSTG, int NW, bool STAMP = false, bool WS = false>
+static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(const WgradParams p) {
+  static_assert(!WS || (NW == 4 && NSTG == 3), "wave specialisation: 4 loader + 4 consumer waves, 3 LDS stages");
   constexpr int BG = 128, BS = 128, FM = 4, FN = NW == 8 ? 2 : 4;
   constexpr int NQ = 16 / NW;                                        // DMA rounds per operand tile: 4 rows per wave and round
   constexpr int SW = 128 / (NW / 2);                                 // small-side columns per wave: 64 (4 waves) or 32 (8 waves)
@@ -292,7 +301,9 @@ static __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(const WgradPa
   unsigned char* lds = smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_raw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = WS ? (wave_raw & 3) : wave_raw;                   // index inside the role (loader / consumer)
+  const bool loader = WS && wave_raw >= 4;
   // XCD-aware order (workgroup id % 8 = XCD, each with its own 4 MB L2): every XCD takes a contiguous run of logical tiles,
   // column tile fastest, then row tile, then pixel chunk - the tiles of one pixel chunk read the same rows of both operands
   // (other taps / channel chunks), so a chunk's 1.5-4.5 MB working set is fetched into ONE L2 instead of all eight
@@ -413,22 +424,74 @@ static __global__ __launch_bounds__(NW * 64) void wgrad_dma_kernel(const WgradPa
   // NSTG LDS stages (2: two workgroups share a CU; 3-4: one workgroup per CU keeps 2-3 k-steps of loads in flight - the
   // split-K plan launches ~one workgroup per CU).  8 DMA pieces per stage and wave: the counted wait leaves the NSTG-2
   // youngest stages in flight; stages past the end read the zero page and are never consumed.
+  unsigned long long tw = 0, ti = 0, tc = 0, t0 = 0, tk0 = 0;
+  if constexpr (STAMP) tk0 = __builtin_amdgcn_s_memtime();
+  if constexpr (WS) {
+    if (loader) {
+      issue(0); issue(1);                                             // stages 0, 1 in flight
+      int slot = 2;
+      for (int k = 0; k < nk; ++k) {
+        if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // stage k has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                                 // consumers may read stage k; stage k-1 is free
+        if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tw += t1 - t0; t0 = t1; }
+        issue(slot);                                                  // stage k+2 (past the end: zero page, never read)
+        if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); ti += t1 - t0; }
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      int slot = 0;
+      for (int k = 0; k < nk; ++k) {
+        if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tw += t1 - t0; t0 = t1; }
+        compute(slot);
+        if constexpr (STAMP) {
+          asm volatile("s_nop 0" ::: "memory");
+          const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tc += t1 - t0;
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+    }
+    if constexpr (STAMP) {
+      if (lane == 0 && wgid < 1024) {
+        unsigned long long* d = g_wgd_stamps + ((long long)wgid * 8 + wave_raw) * 4;
+        d[0] = tw; d[1] = ti; d[2] = tc; d[3] = __builtin_amdgcn_s_memtime() - tk0;
+      }
+    }
+    if (loader) return;
+  } else {
 #pragma unroll
   for (int s0_ = 0; s0_ < NSTG - 1; ++s0_) issue(s0_);
   int st_c = 0, st_i = NSTG - 1;
   for (int k = 0; k < nk; ++k) {
+    if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
     if constexpr (NSTG == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (2 * NQ * (NSTG - 2) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (2 * NQ * (NSTG - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (2 * NQ * (NSTG - 2) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(NSTG == 2, "add the vmcnt literal");
     __builtin_amdgcn_s_barrier();
+    if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tw += t1 - t0; t0 = t1; }
     issue(st_i);
+    if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); ti += t1 - t0; t0 = t1; }
     compute(st_c);
+    if constexpr (STAMP) {
+      asm volatile("s_nop 0" ::: "memory");
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tc += t1 - t0;
+    }
     st_c = (st_c + 1 == NSTG) ? 0 : st_c + 1;
     st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (STAMP) {
+    if (lane == 0 && wgid < 1024) {
+      unsigned long long* d = g_wgd_stamps + ((long long)wgid * 8 + wave) * 4;
+      d[0] = tw; d[1] = ti; d[2] = tc; d[3] = __builtin_amdgcn_s_memtime() - tk0;
+    }
+  }
+  }   // !WS
 
   float* part = p.part + (long long)bz * p.CsRows * p.ncols;
 #pragma unroll
