@@ -399,8 +399,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
 
-template <int BCH, int BPIX, int NSTG, bool BNB = false>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
+// WS (wave-specialised, 512 threads, NSTG = 3): waves 4-7 only issue the LDS-DMA (two stages ahead), waves 0-3 only read
+// fragments and feed the MFMA - see wgrad_dma_kernel in wgrad.hpp for the measurement behind it.  Used when the launch has
+// about one workgroup per CU, where a 4-wave workgroup would serialise DMA issue and MFMA in every wave.
+template <int BCH, int BPIX, int NSTG, bool BNB = false, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmParams p) {
+  static_assert(!WS || NSTG == 3, "wave specialisation uses 3 LDS stages");
   typedef PrecBf16 P;
   typedef IgemmCfg<P, BCH, BPIX> C;
   constexpr int FM = C::FM, FN = C::FN, LD = IG_BK;                 // unpadded 128-byte rows
@@ -409,8 +413,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* lds = smem_raw;                                    // the ONLY shared object (hipcc wait-insertion trap)
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;                // position inside the role (loader / consumer)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = WS && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
   const int nwg = gridDim.x;
   int wgid;
   {
@@ -501,6 +506,31 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmParams p) {
   };
 
   typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
+  if constexpr (WS) {
+    if (loader) {
+      issue(0, 0); issue(1, 1);                                       // stages 0, 1 in flight
+      int slot = 2;
+      for (int k = 0; k < nk; ++k) {
+        if constexpr (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage k has landed (this wave's pieces)
+        else if constexpr (NLD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else static_assert(NLD == 8 || NLD == 6, "add the vmcnt literal");
+        __builtin_amdgcn_s_barrier();                                 // consumers may read stage k; stage k-1 is free
+        issue(k + 2, slot);                                           // past the end: re-loads the last tile, never read
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+    if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
+    int slot = 0;
+    for (int k = 0; k < nk; ++k) {
+      __builtin_amdgcn_s_barrier();
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
+    return;
+  }
   if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);   // older than every DMA: done by the first wait
   // prologue: NSTG-1 stages in flight
 #pragma unroll

@@ -103,17 +103,17 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
   return JCK_OK;
 }
 
-template <int BCH, int BPIX, int NSTG>
+template <int BCH, int BPIX, int NSTG, bool WS = false>
 static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
   constexpr int variant = BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
   ProfScope prof(variant, p.flops, st);
-  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true> : igemm_dma_kernel<BCH, BPIX, NSTG, false>;
+  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true, WS> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true, WS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false, WS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
@@ -124,7 +124,7 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX>::WPIX);
   }
-  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(256), LDSB, st, q);
+  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(WS ? 512 : 256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -142,6 +142,15 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     static const int f_stg = getenv("JCK_DMA_STG") ? atoi(getenv("JCK_DMA_STG")) : 0;
     if (f_tile == 128 && f_stg == 3) return launch_igemm_dma<128, 128, 3>(p, nch_pad, phases, st, slots);
     if (f_tile == 64 && f_stg == 3) return launch_igemm_dma<128, 64, 3>(p, nch_pad, phases, st, slots);
+    // wave-specialised variants (JCK_IGEMM_WS: 0 off, 1 = launches with at most ws_max workgroups of 128x64, 2 = all)
+    static const int ws_mode = getenv("JCK_IGEMM_WS") ? atoi(getenv("JCK_IGEMM_WS")) : 1;
+    static const long long ws_max = getenv("JCK_IGEMM_WS_MAX") ? atoll(getenv("JCK_IGEMM_WS_MAX")) : 1024;
+    const long long wgs64 = (long long)cdiv(p.M, 64) * (nch_pad / 128) * phases;
+    if (f_tile == 0 && ws_mode == 2) {
+      if (wgs >= 512) return launch_igemm_dma<128, 128, 3, true>(p, nch_pad, phases, st, slots);
+      return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
+    }
+    if (f_tile == 0 && ws_mode == 1 && wgs < 512 && wgs64 <= ws_max) return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
     if (f_tile == 128 || (f_tile == 0 && wgs >= 512)) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
     return launch_igemm_dma<128, 64, 2>(p, nch_pad, phases, st, slots);
   }
@@ -154,8 +163,11 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
-    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases)
+    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
+      static const int ws64 = getenv("JCK_IGEMM_WS64") ? atoi(getenv("JCK_IGEMM_WS64")) : 0;
+      if (ws64) return launch_igemm_dma<64, 128, 3, true>(p, nch_pad, phases, st, slots);
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
+    }
     if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st, slots);
   }
