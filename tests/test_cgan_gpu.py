@@ -70,3 +70,25 @@ def test_cgan_state_layout_matches_reference_keys():
     assert list(gs.keys()) == gold["ckpt_g_keys"] and list(ds.keys()) == gold["ckpt_d_keys"]
     assert ds["linear1.weight"].shape == (256, 8392) and ds["label_embedding.weight"].shape == (200, 100)
     assert gs["conv1.weight"].shape == (200, 512, 4, 4)
+
+
+@pytest.mark.parametrize("prec,tol,gtol", [("f32", 1e-3, 3e-2), ("bf16", 5e-2, 4e-1)])
+def test_cgan_full_size_step_batch256(prec, tol, gtol):
+    """BASELINE.json configs[3] at its full size (batch 256, 10-class one-hot labels in the 100-wide encoding): one step against
+    the oracle - production tile shapes, split-K Linear(8392,256), wave-specialised kernels, the double backward at scale."""
+    from hipgan.engine import CganEngine
+    from oracle.gan_oracle import GanOracle
+    from util import synth_images
+    B = 256
+    orc = GanOracle("cgan", lr=2e-4, seed=12345)
+    eng = CganEngine(batch=B, prec=prec)
+    eng.load_state(orc.g, orc.d)
+    real = synth_images(B)
+    g = torch.Generator().manual_seed(77)
+    lab = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 100).to(torch.int64)
+    nz = _noise(B, 900, lab)
+    ref = orc.step(real, lab, nz)
+    got = eng.step(real.cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4)
+    for k in ("loss_real", "loss_fake", "gp", "loss_d", "loss_g", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(got[k], ref[k]) < tol, (k, got[k], ref[k])
+    _cmp(eng.named_views("d", "grads"), orc.d_grads, gtol, "d_grads")
