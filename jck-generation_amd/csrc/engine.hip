@@ -261,19 +261,12 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
   if (family != 0 || !e->overlap || batch % 8 != 0 || (e->batched < 2 || e->batched > 4)) e->batched = 0;
   e->carve(nullptr);
-  e->defer_join = !(getenv("JCK_DEFER_JOIN") && atoi(getenv("JCK_DEFER_JOIN")) == 0);
   // BatchNorm-backward statistics in the dgrad epilogue (jck_conv_*_bnbwd): correct and tested, but measured 4 % SLOWER than
   // the separate reduction pass at B=256 (the extra epilogue work lengthens every workgroup's tail) - opt-in
   e->fuse_bnbwd = getenv("JCK_FUSE_BNBWD") && atoi(getenv("JCK_FUSE_BNBWD")) != 0;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
-    // queue priorities (JCK_PRIO=1): the weight-gradient and penalty streams are off the critical path -> low; G's forward
-    // gates D(fake) -> high
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // lo = numerically largest = lowest priority
-    const bool prio = getenv("JCK_PRIO") && atoi(getenv("JCK_PRIO")) != 0;
-    const int pr[3] = {prio ? lo : 0, prio ? hi : 0, prio ? lo : 0};
-    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(ss[i], hipStreamNonBlocking, pr[i]));
+    for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
     hipEvent_t* ev[9] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
   }

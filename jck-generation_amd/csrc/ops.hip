@@ -138,36 +138,23 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   static const int use_dma = getenv("JCK_IGEMM_DMA") ? atoi(getenv("JCK_IGEMM_DMA")) : 1;
   if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && p.ksplit <= 1 && !p.rows_are_phases) {
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
-    static const int f_tile = getenv("JCK_DMA_TILE") ? atoi(getenv("JCK_DMA_TILE")) : 0;     // experiments: force a configuration
-    static const int f_stg = getenv("JCK_DMA_STG") ? atoi(getenv("JCK_DMA_STG")) : 0;
-    if (f_tile == 128 && f_stg == 3) return launch_igemm_dma<128, 128, 3>(p, nch_pad, phases, st, slots);
-    if (f_tile == 64 && f_stg == 3) return launch_igemm_dma<128, 64, 3>(p, nch_pad, phases, st, slots);
-    // wave-specialised variants (JCK_IGEMM_WS: 0 off, 1 = launches with at most ws_max workgroups of 128x64, 2 = all)
+    // wave-specialised variant for the launches that would run 128x64 tiles (< 512 tiles of 128x128: one or two workgroups
+    // per CU); JCK_IGEMM_WS=0 disables.  128x128 WS (one workgroup per CU) and WS for the 64-channel tile measured slower.
     static const int ws_mode = getenv("JCK_IGEMM_WS") ? atoi(getenv("JCK_IGEMM_WS")) : 1;
-    static const long long ws_max = getenv("JCK_IGEMM_WS_MAX") ? atoll(getenv("JCK_IGEMM_WS_MAX")) : 1024;
-    const long long wgs64 = (long long)cdiv(p.M, 64) * (nch_pad / 128) * phases;
-    if (f_tile == 0 && ws_mode == 2) {
-      if (wgs >= 512) return launch_igemm_dma<128, 128, 3, true>(p, nch_pad, phases, st, slots);
-      return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
-    }
-    if (f_tile == 0 && ws_mode == 1 && wgs < 512 && wgs64 <= ws_max) return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
-    if (f_tile == 128 || (f_tile == 0 && wgs >= 512)) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
+    if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
+    if (ws_mode) return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
     return launch_igemm_dma<128, 64, 2>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad % 128 == 0) {
     if (nsub != 1) JCK_FAIL(JCK_E_ARG, "igemm: 4-channel gather with >=128 output rows unsupported");
     // keep >= ~256 workgroups in flight: halve the pixel tile for small pixel counts
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
-    static const long long min_wgs = getenv("JCK_IGEMM_MIN_WGS") ? atoll(getenv("JCK_IGEMM_MIN_WGS")) : 256;
-    if (wgs >= min_wgs) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st, slots);
+    if (wgs >= 256) return launch_igemm_t<P, 128, 128, 1>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
-    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
-      static const int ws64 = getenv("JCK_IGEMM_WS64") ? atoi(getenv("JCK_IGEMM_WS64")) : 0;
-      if (ws64) return launch_igemm_dma<64, 128, 3, true>(p, nch_pad, phases, st, slots);
+    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases)
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
-    }
     if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st, slots);
   }
@@ -220,17 +207,13 @@ static int launch_img_down(const void* x, const void* w, void* out, float* stats
   q.x = x; q.w = w; q.out = out; q.stats = stats;
   q.ngroups = N * OH * (OW / 16); q.H = Hb; q.W = Wb; q.logOH = ilog2(OH); q.logG = ilog2(OW / 16);
   q.x_bytes = (unsigned)((long long)N * Hb * Wb * 4 * 2);
-  static const int gpw = getenv("JCK_IMG_GPW") ? atoi(getenv("JCK_IMG_GPW")) : IMG_GPW;
-  const int grid = cdiv(q.ngroups, 4 * gpw);
+  const int grid = cdiv(q.ngroups, 4 * IMG_GPW);       // 8 groups per wave: 2 / 4 / 16 measured 20.0 / 14.7 / 13.2 us against 13.6
   if (stats) {
     if (!slots) JCK_FAIL(JCK_E_ARG, "conv_down: stats requested without a slot-count output");
     *slots = grid;
   }
   ProfScope prof(18, flops, st);
-  if (gpw == 2) hipLaunchKernelGGL(img_down_kernel<2>, dim3(grid), dim3(256), 0, st, q);
-  else if (gpw == 4) hipLaunchKernelGGL(img_down_kernel<4>, dim3(grid), dim3(256), 0, st, q);
-  else if (gpw == 16) hipLaunchKernelGGL(img_down_kernel<16>, dim3(grid), dim3(256), 0, st, q);
-  else hipLaunchKernelGGL(img_down_kernel<IMG_GPW>, dim3(grid), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(img_down_kernel<IMG_GPW>, dim3(grid), dim3(256), 0, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -398,15 +381,18 @@ static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t
   return JCK_OK;
 }
 
-template <int NSTG, int NW>
+// LDS-DMA weight gradient: wave-specialised (4 loader + 4 consumer waves, 3 stages = 96 KB) by default; JCK_WGRAD_WS=0 selects
+// the 4-wave, 2-stage form (48.4 vs 33.7 us at B=256 on the isolated product; 3-4 stages or 8 symmetric waves: within 7 %).
+// JCK_WGRAD_STAMP=1 (development) launches the instrumented twin read back by jck_debug_wgrad_stamps.
+template <int NSTG, bool STAMP, bool WS>
 static int launch_wgrad_dma_t(const WgradParams& q, int grid, hipStream_t st) {
   constexpr int LDSB = NSTG * 2 * WGD_BKP * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, 4, STAMP, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, NW>), dim3(grid), dim3(NW * 64), LDSB, st, q);
+  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, 4, STAMP, WS>), dim3(grid), dim3(WS ? 512 : 256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -415,33 +401,10 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
   WgradParams q = p;
   q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
   const int grid = pl.gx * pl.gy * pl.Z;
-  static const int stg = getenv("JCK_WGRAD_STG") ? atoi(getenv("JCK_WGRAD_STG")) : 2;
-  // 8 waves: +7 % on the isolated product, -1 % on the whole step (more waves competing with the dgrad chain): default 4
-  static const int nw = getenv("JCK_WGRAD_WAVES") ? atoi(getenv("JCK_WGRAD_WAVES")) : 4;
   static const int stamp = getenv("JCK_WGRAD_STAMP") ? atoi(getenv("JCK_WGRAD_STAMP")) : 0;
   static const int wsp = getenv("JCK_WGRAD_WS") ? atoi(getenv("JCK_WGRAD_WS")) : 1;
-  if (wsp) {                                         // wave-specialised: 4 loader + 4 consumer waves, 3 stages (96 KB)
-    constexpr int LDSB = 3 * 2 * WGD_BKP * 256;
-    static bool attr_ws = false;
-    if (!attr_ws) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-      attr_ws = true;
-    }
-    if (stamp) hipLaunchKernelGGL((wgrad_dma_kernel<3, 4, true, true>), dim3(grid), dim3(512), LDSB, st, q);
-    else hipLaunchKernelGGL((wgrad_dma_kernel<3, 4, false, true>), dim3(grid), dim3(512), LDSB, st, q);
-    HIPCHK(hipGetLastError());
-    return JCK_OK;
-  }
-  if (stamp) {
-    constexpr int LDSB = 2 * 2 * WGD_BKP * 256;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    hipLaunchKernelGGL((wgrad_dma_kernel<2, 4, true>), dim3(grid), dim3(256), LDSB, st, q);
-    HIPCHK(hipGetLastError());
-    return JCK_OK;
-  }
-  if (nw == 8) return stg == 3 ? launch_wgrad_dma_t<3, 8>(q, grid, st) : launch_wgrad_dma_t<2, 8>(q, grid, st);
-  return stg == 3 ? launch_wgrad_dma_t<3, 4>(q, grid, st) : launch_wgrad_dma_t<2, 4>(q, grid, st);
+  if (wsp) return stamp ? launch_wgrad_dma_t<3, true, true>(q, grid, st) : launch_wgrad_dma_t<3, false, true>(q, grid, st);
+  return stamp ? launch_wgrad_dma_t<2, true, false>(q, grid, st) : launch_wgrad_dma_t<2, false, false>(q, grid, st);
 }
 
 template <class P>
