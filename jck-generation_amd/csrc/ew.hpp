@@ -776,24 +776,26 @@ __global__ void label_embed_fwd_kernel(const long long* __restrict__ labels, con
   stf(cbuf + (long long)b * ld + col0 + j, s > 0.f ? s : slope * s);
 }
 // dW[j][i] += sum_b ue[b][j]*act'(pre) * onehot[b][i];  db[j] += sum_b ...      ue taken from gc[b][col0 + j] (type T)
+// One workgroup per output unit j: its B masked gradients go to LDS once, thread i < NI walks the label column i (coalesced
+// across the workgroup), thread NI sums the bias gradient.  (One thread per (j, i) re-reading gc took 116 us at B = 256.)
 template <typename T>
-__global__ void label_embed_bwd_kernel(const T* __restrict__ gc, int ld, int col0, const float* __restrict__ pre,
-                                       const long long* __restrict__ labels, float slope, int B, int NI, int NO,
-                                       float* __restrict__ dW, float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (j, k) plus NO threads for the bias
-  if (i < NO * NI) {
-    const int j = i / NI, k = i % NI;
+__global__ __launch_bounds__(128) void label_embed_bwd_kernel(const T* __restrict__ gc, int ld, int col0, const float* __restrict__ pre,
+                                                              const long long* __restrict__ labels, float slope, int B, int NI,
+                                                              int NO, float* __restrict__ dW, float* __restrict__ db) {
+  extern __shared__ float gj[];                       // [B]
+  const int j = blockIdx.x;
+  for (int b = threadIdx.x; b < B; b += blockDim.x)
+    gj[b] = ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
+  __syncthreads();
+  for (int i = threadIdx.x; i <= NI; i += blockDim.x) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float g = ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
-      s += g * (float)labels[(long long)b * NI + k];
+    if (i < NI) {
+      for (int b = 0; b < B; ++b) s += gj[b] * (float)labels[(long long)b * NI + i];
+      dW[j * NI + i] += s;
+    } else {
+      for (int b = 0; b < B; ++b) s += gj[b];
+      db[j] += s;
     }
-    dW[i] += s;
-  } else if (i < NO * NI + NO) {
-    const int j = i - NO * NI;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
-    db[j] += s;
   }
 }
 
@@ -826,14 +828,18 @@ __global__ void dropout_kernel(const T* __restrict__ x, const float* __restrict_
     stf(y + i, ldf(x + i) * mask[i] * scale);
 }
 
-// column sums of a [B][N] matrix of T into fp32 (bias gradients): db[j] += sum_b g[b][j]
+// column sums of a [B][N] matrix of T into fp32 (bias gradients): db[j] += sum_b g[b][j].  64 columns x 4 row lanes per
+// workgroup, LDS reduce over the lanes (deterministic).
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ g, int B, int N, int ld, float* __restrict__ db) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, int B, int N, int ld, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int jl = threadIdx.x & 63, ln = threadIdx.x >> 6, j = blockIdx.x * 64 + jl;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += ldf(g + (long long)b * ld + j);
-  db[j] += s;
+  if (j < N)
+    for (int b = ln; b < B; b += 4) s += ldf(g + (long long)b * ld + j);
+  red[ln][jl] = s;
+  __syncthreads();
+  if (ln == 0 && j < N) db[j] += red[0][jl] + red[1][jl] + red[2][jl] + red[3][jl];
 }
 
 // u = coef * (norm - 1) / norm * g      gradient of  lambda * mean_n (||g_n|| - 1)^2  w.r.t. g  (coef = 2*lambda/B)
@@ -929,13 +935,22 @@ __global__ __launch_bounds__(256) void bn2_reduce_kernel(const T* __restrict__ a
   }
 }
 
-// sums[q*C + c] = sum over workgroups of partial[blk][q][c]      (NA * C outputs, one thread each: nblk <= 256)
-static __global__ void bn2_sums_kernel(const float* __restrict__ partial, int nblk, int NA, int C, float* __restrict__ sums) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NA * C) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += partial[(long long)k * NA * C + i];
-  sums[i] = s;
+// sums[i] = sum over workgroups of partial[blk][i], i < NA*C (a multiple of 4): one workgroup per 4 outputs, 256 lanes over
+// the partials with 16-byte loads (one thread per output looping over 256 strided partials took 64 us for C = 64)
+static __global__ __launch_bounds__(256) void bn2_sums_kernel(const float* __restrict__ partial, int nblk, int NA, int C,
+                                                              float* __restrict__ sums) {
+  __shared__ float sh[4][4];
+  const int i0 = blockIdx.x * 4, n = NA * C;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = threadIdx.x; k < nblk; k += 256) s += *reinterpret_cast<const f32x4*>(partial + (long long)k * n + i0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = wave_sum(s[j]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[threadIdx.x >> 6][j] = s[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) sums[i0 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
 // v-chain apply:  u = act'(z) * (gamma/sigma) (v - mean v - xhat * mean(v xhat))                 (may overwrite v)

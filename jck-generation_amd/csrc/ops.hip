@@ -844,7 +844,7 @@ extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float*
 }
 extern "C" int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
                                    int B, int NI, int NO, float* dW, float* db, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(cdiv(NO * NI + NO, 256)), dim3(256), 0, (hipStream_t)stream,
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NO), dim3(128), (size_t)B * sizeof(float), (hipStream_t)stream,
                                       (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db));
   HIPCHK(hipGetLastError());
   return JCK_OK;
@@ -872,7 +872,7 @@ extern "C" int jck_dropout(int prec, const void* x, const float* mask, float sca
   return JCK_OK;
 }
 extern "C" int jck_colsum(int prec, const void* g, int B, int N, int ld, float* db, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, (const T*)g, B, N, ld, db));
+  DISPATCH_T(prec, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, (const T*)g, B, N, ld, db));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -904,7 +904,7 @@ extern "C" int jck_bn2_vchain(int prec, const void* v, const void* y, const void
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 3 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)v, (const T*)y, (const T*)gy, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn2_sums_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws);
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(3 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn2_vchain_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const T*)v,
@@ -927,7 +927,7 @@ extern "C" int jck_bn2_reverse(int prec, const void* ua, const void* y, const vo
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 4 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)ua, (const T*)y, (const T*)xdir, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn2_sums_kernel, dim3(cdiv(4 * C, 256)), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws);
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(4 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn2_reverse_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
