@@ -189,7 +189,7 @@ def main():
 
     out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256" if not cgan else "images/sec (G+D step) CGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "ms_per_step": round(ms, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": a.prec if a.prec == "bf16" else "f32(split-bf16x3)",
+           "scaling": "weak", "vs_baseline": None, "dtype": a.prec,
            "data": "synthetic" if a.input == "tensor" else "synthetic uint8 dataset in HBM, transformed in the step",
            "config": {"workload": (f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
                                    f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})") if not cgan else
@@ -224,7 +224,8 @@ def main():
             d = rows[0]
             out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                               "traffic": pmc_traffic(d["kernel"]), "avg_launch_ms": round(d["avg_ms"], 5),
+                               "traffic": (pmc_traffic(d["kernel"]) or {}).get("bytes_per_launch"),      # HBM bytes per launch (PMC)
+                               "traffic_detail": pmc_traffic(d["kernel"]), "avg_launch_ms": round(d["avg_ms"], 5),
                                "launches_per_step": d["launches_per_step"],
                                "method": "HIP events around every launch on the launch stream, 3 extra steps after the timed region"}
             out["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
