@@ -1,10 +1,12 @@
-"""Model selector for `main.py -m` (same values and string form as the reference's enums.py)."""
+"""Model selector for `main.py -m`: members DCGAN and CGAN whose value and string form are their own name, so argparse
+can both parse `-m DCGAN` (`type=ModelEnum`) and print the choices bare (the reference's enums.py has the same surface)."""
 import enum
 
 
-class ModelEnum(enum.Enum):
-    DCGAN = "DCGAN"
-    CGAN = "CGAN"
-
-    def __str__(self) -> str:      # argparse shows / parses the bare value
+class _NamedByValue(enum.Enum):
+    def __str__(self) -> str:
         return str(self.value)
+
+
+MODEL_NAMES = ("DCGAN", "CGAN")
+ModelEnum = _NamedByValue("ModelEnum", [(name, name) for name in MODEL_NAMES], module=__name__)
