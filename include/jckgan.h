@@ -257,6 +257,12 @@ typedef struct jck_step_inputs {
 } jck_step_inputs;
 int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
+/* Data-parallel overlap: after PHASE_D_LOSS of the batched schedule the tail of D's gradient arena (conv4.weight, norm4.*,
+ * conv5.weight: 76 % of its bytes) is final long before the phase ends.  Returns 1 with that [offset, offset+numel) range
+ * (floats) and, when `stream` is not NULL, makes `stream` wait for the event that marks it final - start the all-reduce of
+ * that slice on `stream`; returns 0 when the step has no early bucket.  (The all-reduce the reference would need before
+ * optimizer_d.step(), train/dcgan_trainer.py:180, under DistributedDataParallel.) */
+int jck_engine_grad_bucket(jck_engine*, int net, void* stream, long long* offset, long long* numel);
 const float* jck_engine_scalars(const jck_engine*);
 const float* jck_engine_scalars_at(const jck_engine*, int step);   /* buffer of the given (1-based) step's parity */
 /* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */

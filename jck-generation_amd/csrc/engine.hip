@@ -125,7 +125,8 @@ struct jck_engine {
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr, evBucket = nullptr;
+  bool bucket_ready = false;            // evBucket was recorded in this step's PHASE_D_LOSS (gradients of conv4.weight .. conv5.weight final)
   bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
   void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
@@ -267,7 +268,7 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
-    hipEvent_t* ev[9] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    hipEvent_t* ev[10] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
   }
   *out = e;
@@ -278,7 +279,7 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[9] = {e->evW[0], e->evW[1], e->evW[2], e->evW[3], e->evWdone, e->ev0, e->evF, e->evReal, e->evGP};
+    hipEvent_t ev[10] = {e->evW[0], e->evW[1], e->evW[2], e->evW[3], e->evWdone, e->ev0, e->evF, e->evReal, e->evGP, e->evBucket};
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -537,6 +538,13 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
     hipStream_t ws = st;
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
+    if (i == 3 && G == 3) {
+      // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
+      // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
+      // (jck_engine_grad_bucket)
+      HIPCHK(hipEventRecord(e->evBucket, ws));
+      e->bucket_ready = true;
+    }
     if (i > 0 && e->fuse_bnbwd) {
       JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
                                 S.y[i - 1], S.aux[i - 1], LRELU, B, st));
@@ -697,6 +705,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   DSet& D1 = e->dset[1];
   DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
   e->parity = in->step & 1;
+  if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL) e->bucket_ready = false;
   e->acc = e->acc2 + 16 * e->parity;
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
@@ -850,6 +859,22 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
   }
   JCK_FAIL(JCK_E_ARG, "unknown phase");
+}
+
+// Early gradient bucket of PHASE_D_LOSS (batched schedule): returns 1 and the [offset, offset + numel) range of D's gradient
+// arena whose values are final as soon as the recorded event fires, and - when `stream` is not NULL - makes `stream` wait
+// for that event (and consumes it); returns 0 when this step has no early bucket (per-pass schedules, CGAN).
+extern "C" int jck_engine_grad_bucket(jck_engine* e, int net, void* stream, long long* offset, long long* numel) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (net != 1 || !e->bucket_ready || !e->evBucket) return 0;
+  const long long off = find(e->LD, NAMES_CW[3])->offset;
+  if (offset) *offset = off;
+  if (numel) *numel = (long long)e->LD.n_params - off;
+  if (stream) {
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evBucket, 0));
+    e->bucket_ready = false;
+  }
+  return 1;
 }
 
 extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }

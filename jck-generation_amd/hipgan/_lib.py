@@ -88,6 +88,7 @@ PROTOS = {
     "jck_engine_bind": (i32, [vp, vp, sz] + [vp] * 12),
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
+    "jck_engine_grad_bucket": (i32, [vp, i32, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "jck_engine_scalars": (vp, [vp]),
     "jck_engine_scalars_at": (vp, [vp, i32]),
     "jck_engine_sample": (i32, [vp, vp, vp, i32, vp, vp]),
@@ -149,6 +150,10 @@ class _Lib:
                     if not a.is_contiguous():
                         raise JckError(f"{name}: non-contiguous tensor argument")
             r = fn(*[_arg(a) for a in args])
+            if fn.restype is i32 and name == "jck_engine_grad_bucket":      # 0 / 1 are answers, negatives are errors
+                if r < 0:
+                    raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
+                return r
             if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect") \
                     and r != 0:
                 raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")

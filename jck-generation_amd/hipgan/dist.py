@@ -1,9 +1,13 @@
 """Data-parallel gradient exchange: one flat fp32 all-reduce per network over RCCL (torch.distributed "nccl").
 
 The all-reduce is issued asynchronously: ProcessGroupNCCL runs it on its own HIP stream after the work already queued
-on the compute stream, so kernels enqueued afterwards (the gradient-penalty pass, which produces no gradients in
-DCGAN) overlap it on xGMI.  `start(flat)` returns a callable that makes the compute stream wait for the result.
+on the issuing stream.  In the batched schedule the tail of D's arena (conv4.weight .. conv5.weight, 76 % of the bytes) is
+final right after the first weight-gradient product of the backward pass: the engine records an event there
+(jck_engine_grad_bucket) and that slice is reduced from a side stream under the rest of the backward; in the per-pass
+schedule the gradient-penalty pass (no gradients in DCGAN) runs under the whole all-reduce.  `start(flat)` returns a callable that makes the compute stream wait for the result.
 Gradients are SUM-reduced; the 1/world factor is folded into the Adam kernel (grad_scale)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -12,9 +16,28 @@ class GradReducer:
     def __init__(self, world, group=None):
         self.world = world
         self.group = group
+        self._comm = None
 
-    def start(self, flat):
+    def start(self, flat, early=None):
+        """All-reduce (SUM) of a flat gradient arena; returns a callable that makes the current stream wait for it.
+        early = (offset, wait_on): flat[offset:] is already final once `wait_on(stream_handle)` has made a stream wait for
+        the engine's bucket event - that slice is reduced on a side stream at once, under the rest of the backward pass,
+        and only flat[:offset] waits for the end of the phase (JCK_DDP_BUCKETS=0: one all-reduce of the whole arena)."""
         if self.world == 1:
             return None
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return work.wait
+        works = []
+        if early is not None and os.environ.get("JCK_DDP_BUCKETS", "1") != "0":
+            off, wait_on = early
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            wait_on(self._comm.cuda_stream)
+            with torch.cuda.stream(self._comm):
+                works.append(dist.all_reduce(flat[off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            works.append(dist.all_reduce(flat[:off], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        def wait():
+            for w in works:
+                w.wait()
+        return wait

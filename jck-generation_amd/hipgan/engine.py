@@ -295,7 +295,7 @@ class DcganEngine:
             self.join()
             lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
         if self.family == 0:
-            handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
+            handle = self._reduce_d(reduce_d) if reduce_d else None
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
         else:                                                      # CGAN back-propagates the penalty: reduce after it
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
@@ -322,6 +322,20 @@ class DcganEngine:
         self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
         self._packed_version = self._shared["version"]
         self._keep = keep
+
+    def _reduce_d(self, reduce_d):
+        """Starts D's gradient all-reduce; hands the reducer the early bucket of the batched schedule when it takes one."""
+        import inspect
+        flat = self.arenas["d_grads"]
+        off, num = C.c_longlong(), C.c_longlong()
+        try:
+            takes_early = "early" in inspect.signature(reduce_d).parameters
+        except (TypeError, ValueError):
+            takes_early = False
+        if takes_early and lib.jck_engine_grad_bucket(self._h, 1, None, C.byref(off), C.byref(num)) == 1:
+            h = self._h
+            return reduce_d(flat, early=(off.value, lambda stream: lib.jck_engine_grad_bucket(h, 1, stream, None, None)))
+        return reduce_d(flat)
 
     def record_scalars(self, dst_row):
         """Copies the step scalars (device float[8]) into `dst_row` on the stream that produced them - no host sync and no
