@@ -119,3 +119,26 @@ def test_resize_norm_matches_aten_bilinear(G):
     G.lib.jck_resize_norm(x.cuda(), out, 2, 4, 20, 12, 33, 47, 2.0, -1.0, m.cuda(), s.cuda(), G.cur_stream())
     torch.cuda.synchronize()
     G.check(out.cpu(), ref, 2e-6, "generic resize")
+
+
+def test_device_loader_rank_sharding():
+    """Under torch.distributed every rank walks a strided share of ONE permutation (DistributedSampler semantics): together
+    the ranks cover the dataset, the shares have equal length (wrap-around padding) and a rank's epochs differ."""
+    from preprocess.dcgan_data_preprocessor import DeviceLoader
+    n, world = 50, 4
+    data = torch.arange(n, dtype=torch.uint8).view(n, 1, 1, 1).expand(n, 3, 32, 32).contiguous().cuda()
+    seen, lens = [], []
+    first_epochs = []
+    for rank in range(world):
+        ld = DeviceLoader(data, 8, seed=7)
+        ld.rank, ld.world = rank, world                    # what __init__ reads from torch.distributed
+        ld.n_local = (n + world - 1) // world
+        ids = torch.cat([b[0].idx for b in ld]).cpu()
+        first_epochs.append(ids)
+        assert ids.numel() == 13 and len(ld) == 2
+        lens.append(ids.numel())
+        seen += ids.tolist()
+        ids2 = torch.cat([b[0].idx for b in ld]).cpu()
+        assert not torch.equal(ids, ids2)                  # reshuffled next epoch
+    assert set(seen) == set(range(n)) and len(seen) == 52  # 2 wrap-around duplicates
+    assert len(set(lens)) == 1
