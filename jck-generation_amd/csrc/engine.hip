@@ -260,7 +260,8 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
   // batched D passes need whole tiles per group: 16*B rows at the last layer, tiles of up to 128 rows
   e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
-  if (family != 0 || !e->overlap || batch % 8 != 0 || (e->batched < 2 || e->batched > 4)) e->batched = 0;
+  if (!e->overlap || batch % 8 != 0 || (e->batched < 2 || e->batched > 4)) e->batched = 0;
+  if (family == 1 && e->batched) e->batched = 3;     // CGAN: [real | fake] conv stacks as one 2B pass (the penalty pass stays apart)
   e->carve(nullptr);
   // BatchNorm-backward statistics in the dgrad epilogue (jck_conv_*_bnbwd): correct and tested, but measured 4 % SLOWER than
   // the separate reduction pass at B=256 (the extra epilogue work lengthens every workgroup's tail) - opt-in
@@ -397,17 +398,21 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 }
 
 // D forward up to (not including) the sigmoid head.  family 1: concat + Linear(8392,256) + Dropout (model/CGAN.py:117-122)
+// CGAN head up to the dropped-out hidden layer from the conv features a4 [B][8192] (model/CGAN.py:111-121): concat with the
+// label embedding, Linear(8392,256), Dropout.  Leaves cbuf, pre_e, h_pre, h_drop for the matching d_head_backward.
+static int cg_head_forward(jck_engine* e, const void* a4, int B, const float* drop_mask, hipStream_t st) {
+  if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
+  JCK_TRY(jck_concat_rows(e->prec, a4, FEAT, e->cbuf, L1_KPAD, B, st));
+  JCK_TRY(jck_label_embed_fwd(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
+                              e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, FEAT, e->pre_e, st));
+  JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
+  return jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
+                           e->h_drop, B, L1_OUT, st);
+}
+
 static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
   JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st));
-  if (e->family == 1) {
-    if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
-    JCK_TRY(jck_concat_rows(e->prec, e->d_a[3], FEAT, e->cbuf, L1_KPAD, B, st));
-    JCK_TRY(jck_label_embed_fwd(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
-                                e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, FEAT, e->pre_e, st));
-    JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
-    JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
-                              e->h_drop, B, L1_OUT, st));
-  }
+  if (e->family == 1) return cg_head_forward(e, e->d_a[3], B, drop_mask, st);
   return JCK_OK;
 }
 
@@ -504,6 +509,47 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
   return JCK_OK;
 }
 
+// Backward of the conv stack for G groups whose gradients w.r.t. a4 are in bset.g[3]: BatchNorm backward grouped, ONE dgrad
+// launch per layer over all groups, ONE weight-gradient launch per layer over the first gw groups (on `side` when given),
+// and - xgrad_last - the gradient w.r.t. the input image of the LAST group -> dset[0].gx.  Joins `side` before returning.
+static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int gw, bool xgrad_last, hipStream_t st, hipStream_t side) {
+  auto& S = e->bset;
+  const size_t esz = e->esz;
+  auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
+  int bslots[4] = {0, 0, 0, 0};
+  for (int i = 3; i >= 0; --i) {
+    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+    const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    if (i < 3 && e->fuse_bnbwd)
+      JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
+                                e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+    else
+      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
+                                     e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+    const void* big = i == 0 ? x_in : S.a[i - 1];
+    hipStream_t ws = st;
+    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
+    if (i == 3 && e->family == 0 && G == 3) {
+      // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
+      // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
+      // (jck_engine_grad_bucket)
+      HIPCHK(hipEventRecord(e->evBucket, ws));
+      e->bucket_ready = true;
+    }
+    if (i > 0 && e->fuse_bnbwd) {
+      JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
+                                S.y[i - 1], S.aux[i - 1], LRELU, B, st));
+      if (bslots[i - 1] % G) JCK_FAIL(JCK_E_ARG, "batched D pass: backward statistic slots do not split by group");
+    } else if (i > 0)
+      JCK_TRY(jck_conv_up(e->prec, S.g[i], e->d_up[i], S.g[i - 1], nullptr, nullptr, 0, G * B, hb / 2, hb / 2, cs, cb, st));
+    else if (xgrad_last)
+      JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)(G - 1) * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+  }
+  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+  return JCK_OK;
+}
+
 // Heads + backward of G batches stored back to back from `x_in` (real_noisy | fake | xhat are consecutive) after
 // d_batched_forward has filled every group: ONE launch per layer and direction instead of G, BatchNorm statistics per
 // group (= per batch, as in the separate passes, train/dcgan_trainer.py:162,173,118).  Groups [0, G-1) are loss passes
@@ -521,41 +567,11 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
     JCK_TRY(jck_head_fwd(e->prec, at(S.a[3], (size_t)g * B * FEAT), e->d_head_wp, nullptr, B, FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
                          S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], st));
   }
-  int bslots[4] = {0, 0, 0, 0};
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
                             at(S.g[3], (size_t)gw * B * FEAT), nullptr, st));
-  for (int i = 3; i >= 0; --i) {
-    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
-    const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    if (i < 3 && e->fuse_bnbwd)
-      JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
-                                e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
-    else
-      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
-                                     e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
-    const void* big = i == 0 ? x_in : S.a[i - 1];
-    hipStream_t ws = st;
-    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
-    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
-    if (i == 3 && G == 3) {
-      // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
-      // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
-      // (jck_engine_grad_bucket)
-      HIPCHK(hipEventRecord(e->evBucket, ws));
-      e->bucket_ready = true;
-    }
-    if (i > 0 && e->fuse_bnbwd) {
-      JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
-                                S.y[i - 1], S.aux[i - 1], LRELU, B, st));
-      if (bslots[i - 1] % G) JCK_FAIL(JCK_E_ARG, "batched D pass: backward statistic slots do not split by group");
-    } else if (i > 0)
-      JCK_TRY(jck_conv_up(e->prec, S.g[i], e->d_up[i], S.g[i - 1], nullptr, nullptr, 0, G * B, hb / 2, hb / 2, cs, cb, st));
-    else
-      JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)gw * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
-  }
+  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side));
   JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->norms, st));
-  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
 
@@ -723,7 +739,36 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   };
   switch (phase) {
     case JCK_PHASE_D_LOSS:
-      if (e->batched == 4) {                          // as 3, but D(real)'s forward runs beside G's forward
+      if (cg && e->batched) {
+        // CGAN: the real and fake passes (:181-198) share D's weights -> their conv stacks run as ONE 2B pass with grouped
+        // BatchNorm; the label / Linear / Dropout head runs per batch (forward and backward back to back, so the head
+        // buffers serve both), the back-propagated penalty keeps its own pass (PHASE_D_GP)
+        if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8)");
+        if (!in->z) JCK_FAIL(JCK_E_ARG, "G forward needs z");
+        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+        HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
+        JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));
+        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, e->sB));
+        HIPCHK(hipEventRecord(e->evF, e->sB));
+        JCK_TRY(prep_real(e, in, B, st));
+        HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
+        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 2, 0, st));
+        auto& S = e->bset;
+        const float tg[2] = {0.9f, 0.1f};
+        for (int g = 0; g < 2; ++g) {
+          void* a4 = (unsigned char*)S.a[3] + (size_t)g * B * FEAT * e->esz;
+          void* g4 = (unsigned char*)S.g[3] + (size_t)g * B * FEAT * e->esz;
+          JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
+          JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, tg[g],
+                               0, S.prob + g * B, S.ds + g * B, e->acc, g, 3 + g, st));
+          JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, true, in->drop_mask[g], g4, st));
+        }
+        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 2, 2, false, st, sA));
+        return JCK_OK;
+      }
+      if (!cg && e->batched == 4) {                   // as 3, but D(real)'s forward runs beside G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
@@ -742,7 +787,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         e->gp_done = true;
         return JCK_OK;
       }
-      if (e->batched == 3) {                          // [real | fake | penalty] as one 3B pass after G's forward
+      if (!cg && e->batched == 3) {                   // [real | fake | penalty] as one 3B pass after G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155

@@ -92,3 +92,9 @@ def test_cgan_full_size_step_batch256(prec, tol, gtol):
     for k in ("loss_real", "loss_fake", "gp", "loss_d", "loss_g", "d_x", "d_gz1", "d_gz2"):
         assert _rel(got[k], ref[k]) < tol, (k, got[k], ref[k])
     _cmp(eng.named_views("d", "grads"), orc.d_grads, gtol, "d_grads")
+
+
+def test_cgan_per_pass_schedule_still_matches(monkeypatch):
+    """JCK_BATCHED=0 keeps the separate real / fake passes (also what batches that are not a multiple of 8 run)."""
+    monkeypatch.setenv("JCK_BATCHED", "0")
+    test_cgan_step_parity("f32", 8, 1e-3, 2e-2)
