@@ -582,7 +582,29 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
 // `side` (optional): the weight-gradient products run there beside the v-chain / reverse sweep; they share the split-K
 // workspace, so everything that uses it is ordered on that one stream, and the main stream joins it before the reverse sweep
 // (which overwrites the v_i the v-chain products read and runs the Linear weight gradient on the main stream) and at the end.
-static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st,
+// where the penalty pass left its forward / first-backward tensors: activation set 0 (per-pass schedule) or the last group
+// of the batched set
+struct GpSrc { const void *y[4], *a[4], *g[4]; const float *aux[4], *sums[4], *prob; };
+static GpSrc gp_src_dset0(jck_engine* e) {
+  GpSrc r;
+  for (int i = 0; i < 4; ++i) { r.y[i] = e->d_y[i]; r.a[i] = e->d_a[i]; r.g[i] = e->d_g[i]; r.aux[i] = e->d_bn[i].aux; r.sums[i] = e->d_bn[i].sums; }
+  r.prob = e->prob;
+  return r;
+}
+static GpSrc gp_src_group(jck_engine* e, int g, int B) {
+  GpSrc r;
+  auto& S = e->bset;
+  for (int i = 0; i < 4; ++i) {
+    const size_t off = (size_t)g * B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i] * e->esz;
+    r.y[i] = (const unsigned char*)S.y[i] + off; r.a[i] = (const unsigned char*)S.a[i] + off; r.g[i] = (const unsigned char*)S.g[i] + off;
+    r.aux[i] = S.aux[i] + (size_t)g * 4 * D_CS[i];
+    r.sums[i] = S.sums[i] + (size_t)g * jck_bn_bwd_ws_floats(D_CS[i]);
+  }
+  r.prob = S.prob + (size_t)g * B;
+  return r;
+}
+
+static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st,
                               hipStream_t side = nullptr) {
   const size_t esz = e->esz;
   auto fork = [&](int k) -> hipStream_t {            // work enqueued on the returned stream starts after everything on st so far
@@ -597,7 +619,7 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
     (void)hipStreamWaitEvent(st, e->evWdone, 0);
   };
   HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->prob_gp, e->prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->prob_gp, P.prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
   JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, 64 * 64, e->d_u0, st));
   // ---- v-chain: adjoint of the first backward, swept forward through D
   const void* u = e->d_u0;
@@ -605,9 +627,9 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // g_{a_{i-1}} = convT(gy_i; W_i):  dW_i += wgrad(gy_i, u_{i-1}),  v_i = conv(u_{i-1}; W_i)
-    JCK_TRY(jck_conv_wgrad(e->prec, e->d_g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
+    JCK_TRY(jck_conv_wgrad(e->prec, P.g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
     JCK_TRY(jck_conv_down(e->prec, u, e->d_down[i], e->d_v[i], nullptr, nullptr, B, hb, hb, cb, cs, st));
-    JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], e->d_y[i], e->d_g[i], e->d_bn[i].aux, e->d_bn[i].sums, e->P(e->LD, e->dp, NAMES_NW[i]),
+    JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], P.y[i], P.g[i], P.aux[i], P.sums[i], e->P(e->LD, e->dp, NAMES_NW[i]),
                            LRELU, e->bn2_ws[i], e->d_v[i], e->d_xdir[i], e->P(e->LD, e->dg, NAMES_NW[i]), rows, cs, st));
     u = e->d_v[i];
   }
@@ -624,9 +646,9 @@ static int gp_double_backward(jck_engine* e, const void* xhat, int B, float lamb
   for (int i = 3; i >= 0; --i) {
     const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], e->d_y[i], e->d_xdir[i], e->d_bn[i].aux, e->P(e->LD, e->dp, NAMES_NW[i]), e->bn2_ws[i],
+    JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], P.y[i], e->d_xdir[i], P.aux[i], e->P(e->LD, e->dp, NAMES_NW[i]), e->bn2_ws[i],
                             LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, st));
-    const void* big = i == 0 ? xhat : e->d_a[i - 1];
+    const void* big = i == 0 ? xhat : P.a[i - 1];
     JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
     if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, e->d_v[i], e->d_up[i], e->d_v[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
@@ -740,32 +762,33 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   switch (phase) {
     case JCK_PHASE_D_LOSS:
       if (cg && e->batched) {
-        // CGAN: the real and fake passes (:181-198) share D's weights -> their conv stacks run as ONE 2B pass with grouped
-        // BatchNorm; the label / Linear / Dropout head runs per batch (forward and backward back to back, so the head
-        // buffers serve both), the back-propagated penalty keeps its own pass (PHASE_D_GP)
-        if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8)");
-        if (!in->z) JCK_FAIL(JCK_E_ARG, "G forward needs z");
+        // CGAN: the real, fake and penalty passes (:181-203) share D's weights -> their conv stacks run as ONE 3B pass with
+        // grouped BatchNorm.  The label / Linear / Dropout head runs per batch, forward and backward back to back, so the
+        // head buffers serve all three; the penalty group goes last and leaves them as its double backward (PHASE_D_GP)
+        // expects them.
+        if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
-        HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
-        JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));
-        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, e->sB));
-        HIPCHK(hipEventRecord(e->evF, e->sB));
         JCK_TRY(prep_real(e, in, B, st));
-        HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
-        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 2, 0, st));
+        JCK_TRY(g_forward(e, in->z, in->labels, B, st));
+        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));
+        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
+        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st));
         auto& S = e->bset;
         const float tg[2] = {0.9f, 0.1f};
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 3; ++g) {
+          const bool pen = g == 2;
           void* a4 = (unsigned char*)S.a[3] + (size_t)g * B * FEAT * e->esz;
           void* g4 = (unsigned char*)S.g[3] + (size_t)g * B * FEAT * e->esz;
           JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
-          JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, tg[g],
-                               0, S.prob + g * B, S.ds + g * B, e->acc, g, 3 + g, st));
-          JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, true, in->drop_mask[g], g4, st));
+          JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
+                               pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, st));
+          JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
         }
-        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 2, 2, false, st, sA));
+        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA));
+        JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, HW, e->acc, 6, e->norms, st));
+        e->gp_done = true;
         return JCK_OK;
       }
       if (!cg && e->batched == 4) {                   // as 3, but D(real)'s forward runs beside G's forward
@@ -855,6 +878,13 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_D_GP: {
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
+      if (e->gp_done && cg) {                         // forward and first backward ran as group 2 of the batched pass
+        e->gp_done = false;
+        static const bool cg_side2 = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
+        JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side2 ? sA : nullptr));
+        JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
+        return JCK_OK;
+      }
       if (e->gp_done) { e->gp_done = false; return JCK_OK; }    // computed inside the batched pass of PHASE_D_LOSS
       if (e->gp_inflight) {                           // started in PHASE_D_LOSS: just join
         HIPCHK(hipStreamWaitEvent(st, e->evGP, 0));
@@ -864,7 +894,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
         static const bool cg_side = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
-        JCK_TRY(gp_double_backward(e, e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side ? sA : nullptr));
+        JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side ? sA : nullptr));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
       }
       return JCK_OK;
