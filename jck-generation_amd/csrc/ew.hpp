@@ -767,13 +767,21 @@ template <typename T>
 __global__ void label_embed_fwd_kernel(const long long* __restrict__ labels, const float* __restrict__ W,
                                        const float* __restrict__ bias, float slope, int B, int NI, int NO, T* __restrict__ cbuf,
                                        int ld, int col0, float* __restrict__ pre) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * NO) return;
-  const int b = i / NO, j = i % NO;
-  float s = bias[j];
-  for (int k = 0; k < NI; ++k) s += W[j * NI + k] * (float)labels[(long long)b * NI + k];
-  if (pre) pre[i] = s;
-  stf(cbuf + (long long)b * ld + col0 + j, s > 0.f ? s : slope * s);
+  // one workgroup per image: the label row goes to LDS once; its zeros (99 of 100 for a one-hot row) are skipped - a
+  // workgroup-uniform branch, and adding an exact 0 * W changes nothing
+  extern __shared__ float lab[];                      // [NI]
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < NI; k += blockDim.x) lab[k] = (float)labels[(long long)b * NI + k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < NO; j += blockDim.x) {
+    float s = bias[j];
+    for (int k = 0; k < NI; ++k) {
+      const float l = lab[k];
+      if (l != 0.f) s += W[j * NI + k] * l;
+    }
+    if (pre) pre[b * NO + j] = s;
+    stf(cbuf + (long long)b * ld + col0 + j, s > 0.f ? s : slope * s);
+  }
 }
 // dW[j][i] += sum_b ue[b][j]*act'(pre) * onehot[b][i];  db[j] += sum_b ...      ue taken from gc[b][col0 + j] (type T)
 // One workgroup per output unit j: its B masked gradients go to LDS once, thread i < NI walks the label column i (coalesced
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(128) void label_embed_bwd_kernel(const T* __restric
   for (int i = threadIdx.x; i <= NI; i += blockDim.x) {
     float s = 0.f;
     if (i < NI) {
-      for (int b = 0; b < B; ++b) s += gj[b] * (float)labels[(long long)b * NI + i];
+      for (int b = 0; b < B; ++b) s += gj[b] * (float)labels[(long long)b * NI + i];      // (a per-lane zero test measured 3x slower)
       dW[j * NI + i] += s;
     } else {
       for (int b = 0; b < B; ++b) s += gj[b];

@@ -837,7 +837,7 @@ extern "C" int jck_linear_finish(int prec, const float* slab, int Z, const float
 }
 extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI,
                                    int NO, void* cbuf, int ld, int col0, float* pre, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_fwd_kernel<T>, dim3(cdiv(B * NO, 256)), dim3(256), 0, (hipStream_t)stream,
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_fwd_kernel<T>, dim3(B), dim3(256), (size_t)NI * sizeof(float), (hipStream_t)stream,
                                       (const long long*)labels, W, b, slope, B, NI, NO, (T*)cbuf, ld, col0, pre));
   HIPCHK(hipGetLastError());
   return JCK_OK;
