@@ -792,15 +792,40 @@ template <typename T>
 __global__ __launch_bounds__(256) void label_embed_bwd_kernel(const T* __restrict__ gc, int ld, int col0, const float* __restrict__ pre,
                                                               const long long* __restrict__ labels, float slope, int B, int NI,
                                                               int NO, float* __restrict__ dW, float* __restrict__ db) {
+  extern __shared__ float lcol[];                     // [B]: this label column, fetched by all threads at once
   const int i = blockIdx.x;
+  if (i >= NI) {
+    // bias gradient: workgroups NI.. take 64 units each, 4 row lanes per unit, LDS reduce (every row contributes)
+    __shared__ float red[4][64];
+    const int jl = threadIdx.x & 63, ln = threadIdx.x >> 6, j = (i - NI) * 64 + jl;
+    float s = 0.f;
+    if (j < NO)
+      for (int b = ln; b < B; b += 4) s += ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope);
+    red[ln][jl] = s;
+    __syncthreads();
+    if (ln == 0 && j < NO) db[j] += red[0][jl] + red[1][jl] + red[2][jl] + red[3][jl];
+    return;
+  }
+  __shared__ int nnz;
+  int* rows = reinterpret_cast<int*>(lcol + B);       // [B]: indices of the rows with a non-zero label, in order
+  for (int b = threadIdx.x; b < B; b += blockDim.x) lcol[b] = (float)labels[(long long)b * NI + i];
+  __syncthreads();
+  if (threadIdx.x == 0) {                             // ordered compaction (deterministic summation order)
+    int n = 0;
+    for (int b = 0; b < B; ++b)
+      if (lcol[b] != 0.f) rows[n++] = b;
+    nnz = n;
+  }
+  __syncthreads();
+  const int n = nnz;
   for (int j = threadIdx.x; j < NO; j += blockDim.x) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float l = i < NI ? (float)labels[(long long)b * NI + i] : 1.f;
-      if (l != 0.f) s += l * (ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope));
+#pragma unroll 4
+    for (int k = 0; k < n; ++k) {                     // no branch: the loads of several rows are in flight together
+      const int b = rows[k];
+      s += lcol[b] * (ldf(gc + (long long)b * ld + col0 + j) * (pre[b * NO + j] > 0.f ? 1.f : slope));
     }
-    if (i < NI) dW[j * NI + i] += s;
-    else db[j] += s;
+    dW[j * NI + i] += s;
   }
 }
 

@@ -844,7 +844,7 @@ extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float*
 }
 extern "C" int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
                                    int B, int NI, int NO, float* dW, float* db, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + 1), dim3(256), 0, (hipStream_t)stream,
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + cdiv(NO, 64)), dim3(256), (size_t)B * (sizeof(float) + sizeof(int)), (hipStream_t)stream,
                                       (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db));
   HIPCHK(hipGetLastError());
   return JCK_OK;
