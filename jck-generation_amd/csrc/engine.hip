@@ -512,7 +512,8 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
 // Backward of the conv stack for G groups whose gradients w.r.t. a4 are in bset.g[3]: BatchNorm backward grouped, ONE dgrad
 // launch per layer over all groups, ONE weight-gradient launch per layer over the first gw groups (on `side` when given),
 // and - xgrad_last - the gradient w.r.t. the input image of the LAST group -> dset[0].gx.  Joins `side` before returning.
-static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int gw, bool xgrad_last, hipStream_t st, hipStream_t side) {
+static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int gw, bool xgrad_last, hipStream_t st, hipStream_t side,
+                              bool with_gp_norm = false) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
@@ -546,6 +547,8 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
     else if (xgrad_last)
       JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)(G - 1) * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
+  // the penalty's norm does not need the weight gradients: it runs while the side stream finishes the last of them
+  if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->norms, st));
   if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
@@ -570,8 +573,7 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
                             at(S.g[3], (size_t)gw * B * FEAT), nullptr, st));
-  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side));
-  JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->norms, st));
+  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true));
   return JCK_OK;
 }
 
@@ -786,8 +788,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
                                pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, st));
           JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
         }
-        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA));
-        JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, HW, e->acc, 6, e->norms, st));
+        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
         e->gp_done = true;
         return JCK_OK;
       }
