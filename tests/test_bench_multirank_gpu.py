@@ -26,7 +26,8 @@ def test_two_rank_bench_terminates_and_reports_whole_job_rate():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
     assert abs(out["value"] - 2 * 16 / (out["ms_per_step"] * 1e-3)) < 1e-2 * out["value"]      # whole-job images/sec
-    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    # at batch 16 the dominant kernel runs at a fraction of a TFLOP/s: frac (4 decimals) may round to 0
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["achieved"] > 0 and 0 <= out["roofline"]["frac"] < 1
     assert "cpu_baseline" not in out                              # N = 1 only
     for k in ("loss_d", "loss_g", "gp"):
         v = out["losses_last_step"][k]
