@@ -76,7 +76,7 @@ def test_step_from_device_batch_equals_step_from_tensor():
         for k in a:
             x, y = a[k].double(), b[k].double()
             assert float((x - y).abs().max()) <= 2 * 2 * 2e-4 + 1e-9, k
-            assert float((x - y).abs().mean()) <= 2e-5, k                          # 0.1 lr on average
+            assert float((x - y).abs().mean()) <= 5e-5, k                          # a quarter of lr on average
 
 
 def test_device_loader_covers_dataset_and_feeds_trainer_batches():
