@@ -140,25 +140,30 @@ int jck_axpy_noise(int prec, const void* x, const float* noise_nchw, float keep,
                    void* stream);
 /* x_hat = alpha*a + (1-alpha)*b                                                 train/dcgan_trainer.py:111-112 */
 int jck_interp(int prec, const void* a, const void* b, const float* alpha, void* out, int N, int HW, void* stream);
-/* scal[slot] += sum_n (||g[n]||_2 - 1)^2 ; norms[n] optional                    train/dcgan_trainer.py:125-126 */
-int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, float* norms, void* stream);
+/* scal[slot*scal_ld + n] = (||g[n]||_2 - 1)^2 (plain store per image; the caller sums the row in a fixed order - no float
+ * atomics, so the logged penalty is bitwise reproducible); norms[n] optional     train/dcgan_trainer.py:125-126 */
+int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, int scal_ld, float* norms, void* stream);
 /* g_out = scale * g * (1 - y^2)                                                 tanh backward, model/DCGAN.py:66 */
 int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out, long long numel, void* stream);
 /* D head: logit = <a4[n], wp>, p = sigmoid (model/DCGAN.py:34), BCELoss with the -100 clamp (train/dcgan_trainer.py:64,163);
- * mode 0: ds = dLoss/dlogit for mean BCE against `target`; scal[slot_loss] += sum loss_n; mode 1: ds = p(1-p) (GP pass).
- * scal[slot_p] += sum p.  slot < 0 disables. */
+ * mode 0: ds = dLoss/dlogit for mean BCE against `target`; scal[slot_loss*scal_ld + n] = loss_n; mode 1: ds = p(1-p) (GP
+ * pass).  scal[slot_p*scal_ld + n] = p_n.  slot < 0 disables.  `scal` is a per-image table [slots][scal_ld >= B]: plain
+ * stores, summed in a fixed order by the step tail (no float atomics anywhere on the path). */
 int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias /* device scalar or NULL */, int B, int K,
-                 float target, int mode, float* prob, float* ds, float* scal, int slot_loss, int slot_p, void* stream);
+                 float target, int mode, float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream);
+/* floats of workspace for the weight-gradient partial rows of jck_head_bwd / jck_head_bwd_conv (K = 16*C there) */
+size_t jck_head_bwd_ws_floats(int K);
+/* g_a4[n][k] = ds[n]*wp[k];  dwp[k] (+)= sum_n ds[n]*a4[n][k] through `ws` (partial rows summed in order: deterministic) */
 int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int B, int K, void* g_a4, float* dwp,
-                 int accumulate, void* stream);
+                 int accumulate, float* ws, void* stream);
 /* grad[1][C][4][4] (+)= dwp (packed (h,w,c) order) */
 int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream);
 /* D.conv5 backward in one launch (DCGAN engine path): g_a4[n][k] = ds[n]*wp[k] (skipped when g_a4 is NULL) and
- * grad[c][t] += sum_n ds[n]*a4[n][t*C+c] accumulated with float atomics straight into the PyTorch-layout gradient of
- * conv5.weight [1][C][4][4] (skipped when grad is NULL).  Replaces aten::convolution_backward behind
- * model/DCGAN.py:26 in train/dcgan_trainer.py:164,175,187. */
+ * grad[c][t] += sum_n ds[n]*a4[n][t*C+c] into the PyTorch-layout gradient of conv5.weight [1][C][4][4] (skipped when grad
+ * is NULL): 16 partial rows in `ws` (jck_head_bwd_ws_floats(16*C) floats), summed in order by a second small launch - no
+ * float atomics.  Replaces aten::convolution_backward behind model/DCGAN.py:26 in train/dcgan_trainer.py:164,175,187. */
 int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4, float* grad,
-                      void* stream);
+                      float* ws, void* stream);
 
 /* ---- CGAN pieces (model/CGAN.py:79-162, train/cgan_trainer.py:173-213) ---------------------------------------------
  * Linear layers run on the gather-GEMM kernels as plain row-major products; our activation order is NHWC, so the
@@ -192,7 +197,9 @@ int jck_cgan_z(int prec, const float* z, const int64_t* labels, int B, int NZ, i
 /* back-propagated gradient penalty (train/cgan_trainer.py:200-203): u = dL/dg, second-order BatchNorm and head terms;
  * the closed form is derived and checked against autograd in tests/test_gp_double_backward_math.py */
 int jck_gp_grad(int prec, const void* g, const float* norms, float coef, int N, int HW, void* u, void* stream);
-int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, void* stream);
+/* ws: float[B + jck_head_bwd_ws_floats(K)] */
+int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, float* ws,
+                 void* stream);
 size_t jck_bn2_ws_floats(int C);
 int jck_bn2_vchain(int prec, const void* v, const void* y, const void* gy, const float* aux, const float* s1, const float* gamma,
                    float slope, float* ws, void* u, void* xdir, float* dgamma, long long rows, int C, void* stream);

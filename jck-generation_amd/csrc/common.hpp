@@ -140,6 +140,14 @@ __device__ __forceinline__ void ldraw_half(const float* p, Raw8<float>& r, int h
   const f32x4 t = *reinterpret_cast<const f32x4*>(p);
   if (h == 0) r.a = t; else r.b = t;
 }
+__device__ __forceinline__ void unraw(const Raw8<bf16_t>& r, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r.v[i] << 16); v[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void unraw(const Raw8<float>& r, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+}
 __device__ __forceinline__ void straw(bf16_t* p, const Raw8<bf16_t>& r) { *reinterpret_cast<u32x4*>(p) = r.v; }
 __device__ __forceinline__ void straw(float* p, const Raw8<float>& r) {
   *reinterpret_cast<f32x4*>(p) = r.a;

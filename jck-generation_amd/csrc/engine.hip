@@ -135,7 +135,9 @@ struct jck_engine {
   unsigned char* zero_g; size_t zero_g_bytes;
   BnBuf g_bn[4];
   float *acc, *scal_out;                // current-parity views into acc2 / scal2
-  float *acc2, *scal2;
+  float *acc2, *scal2;                  // acc2: [2 parities][8 rows][acc_ld] per-image scalar table (summed by the step tail)
+  int acc_ld = 0;
+  float *head_ws, *gp2_ws;              // partial rows of the head weight gradients (deterministic two-stage sums)
   float* wg_ws; size_t wg_ws_bytes;
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
@@ -208,8 +210,11 @@ struct jck_engine {
         g_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * h * h, C, i == 0 ? 16 : 1));
       }
     }
-    acc2 = c.take<float>(32); scal2 = c.take<float>(16);
+    acc_ld = (B + 63) / 64 * 64;
+    acc2 = c.take<float>((size_t)2 * 8 * acc_ld); scal2 = c.take<float>(16);
     acc = acc2; scal_out = scal2;
+    head_ws = c.take<float>(jck_head_bwd_ws_floats(FEAT));
+    gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
     size_t w = 0;
     for (int i = 0; i < 4; ++i) {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
@@ -419,18 +424,19 @@ static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, 
 // sigmoid head + loss (mode 0) or + d(sum p)/dlogit (mode 1); fills e->prob / e->ds
 static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
   if (e->family == 0)
-    return jck_head_fwd(e->prec, D.a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, st);
+    return jck_head_fwd(e->prec, D.a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
   return jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, target,
-                      mode, D.prob, D.ds, e->acc, slot_loss, slot_p, st);
+                      mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
 }
 
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
 static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
   if (e->family == 0)
-    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[3], B, 512, ga4_out, want_wgrad ? e->P(e->LD, e->dg, NAMES_CW[4]) : nullptr, st);
+    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[3], B, 512, ga4_out, want_wgrad ? e->P(e->LD, e->dg, NAMES_CW[4]) : nullptr,
+                             e->head_ws, st);
   // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds
   JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), e->h_drop, B, L1_OUT, e->g_hd,
-                       want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, st));
+                       want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, e->head_ws, st));
   if (want_wgrad) JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), st));
   JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)B * L1_OUT, st));
   if (want_wgrad) {
@@ -548,7 +554,7 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
       JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)(G - 1) * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
   // the penalty's norm does not need the weight gradients: it runs while the side stream finishes the last of them
-  if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->norms, st));
+  if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->acc_ld, e->norms, st));
   if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
@@ -568,11 +574,11 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   for (int g = 0; g < G; ++g) {
     const bool pen = g == G - 1;
     JCK_TRY(jck_head_fwd(e->prec, at(S.a[3], (size_t)g * B * FEAT), e->d_head_wp, nullptr, B, FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
-                         S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], st));
+                         S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], e->acc_ld, st));
   }
-  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), st));
+  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), e->head_ws, st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
-                            at(S.g[3], (size_t)gw * B * FEAT), nullptr, st));
+                            at(S.g[3], (size_t)gw * B * FEAT), nullptr, nullptr, st));
   JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true));
   return JCK_OK;
 }
@@ -641,7 +647,7 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
   JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), e->prob_gp, B, L1_OUT, e->rs,
-                       e->P(e->LD, e->dg, "linear2.weight"), st));
+                       e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
   join();
   JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[3], st));
@@ -746,7 +752,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
   e->parity = in->step & 1;
   if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL) e->bucket_ready = false;
-  e->acc = e->acc2 + 16 * e->parity;
+  e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
@@ -758,7 +764,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
     JCK_TRY(d_head(e, D, B, 0.f, 1, -1, -1, s));
     JCK_TRY(d_backward(e, D, e->xhat, B, false, true, in->drop_mask[2], s, nullptr));
-    JCK_TRY(jck_gp_norm(e->prec, D.gx, B, HW, e->acc, 6, D.norms, s));
+    JCK_TRY(jck_gp_norm(e->prec, D.gx, B, HW, e->acc, 6, e->acc_ld, D.norms, s));
     return JCK_OK;
   };
   switch (phase) {
@@ -769,7 +775,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         // head buffers serve all three; the penalty group goes last and leaves them as its double backward (PHASE_D_GP)
         // expects them.
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
         JCK_TRY(prep_real(e, in, B, st));
@@ -785,7 +791,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           void* g4 = (unsigned char*)S.g[3] + (size_t)g * B * FEAT * e->esz;
           JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
           JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
-                               pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, st));
+                               pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, e->acc_ld, st));
           JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
         }
         JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
@@ -794,7 +800,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       if (!cg && e->batched == 4) {                   // as 3, but D(real)'s forward runs beside G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
         JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
@@ -813,7 +819,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       if (!cg && e->batched == 3) {                   // [real | fake | penalty] as one 3B pass after G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
@@ -830,7 +836,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_D_FAKE: {
       if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
         if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw (or real_u8)");
-        HIPCHK(hipMemsetAsync(e->acc, 0, 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                   // D.zero_grad()  :155
         if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
       }
@@ -927,7 +933,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           t.l[i].nbt = (long long*)(e->dnbt + i);
           t.l[i].C = cs;
         }
-        t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
+        t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.acc_ld = e->acc_ld; t.B = B; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
         hipLaunchKernelGGL(step_tail_kernel, dim3(2, 5), dim3(256), 0, st, t);
         HIPCHK(hipGetLastError());
       }
@@ -969,7 +975,7 @@ extern "C" const void* jck_engine_tensor(const jck_engine* e, const char* name, 
   const long long img = (long long)e->B * 64 * 64 * 4;
   struct { const char* n; const void* p; long long c; } tab[] = {
       {"fake", e->fake, img}, {"fake_raw", e->fake_raw, img}, {"real_noisy", e->real_noisy, img}, {"xhat", e->xhat, img},
-      {"d_gx", e->d_gx, img}, {"prob", e->prob, e->B}, {"ds", e->ds, e->B}, {"norms", e->norms, e->B}, {"acc", e->acc, 16},
+      {"d_gx", e->d_gx, img}, {"prob", e->prob, e->B}, {"ds", e->ds, e->B}, {"norms", e->norms, e->B}, {"acc", e->acc, (long long)8 * e->acc_ld},
       {"d_y1", e->d_y[0], (long long)e->B * 32 * 32 * 64}, {"d_a4", e->d_a[3], (long long)e->B * 8192},
       {"g_y1", e->g_y[0], (long long)e->B * 8192}, {"g_a4", e->g_a[3], (long long)e->B * 32 * 32 * 64}};
   for (auto& t : tab)

@@ -2,7 +2,8 @@
 // (statistics finalise, normalise+activation, backward reduce/apply), D head (4x4 valid conv to one
 // logit + sigmoid + BCE with the -100 log clamp + gradient), tanh backward, gradient-penalty norm,
 // Adam, weight packing.  Everything is 16-byte vectorised along the NHWC channel axis; per-channel
-// reductions use registers -> LDS atomics -> one global atomic per channel per workgroup.
+// reductions use registers -> LDS -> per-workgroup partial rows summed in a fixed order (no float atomics anywhere:
+// two runs of a step give bitwise identical gradients and scalars).
 #pragma once
 #include "common.hpp"
 
@@ -165,10 +166,12 @@ __global__ void tanh_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y
   }
 }
 
-// gradient penalty: sum_n (||g[n]||_2 - 1)^2 -> scal[slot]      one workgroup per image
+// gradient penalty: (||g[n]||_2 - 1)^2 -> scal[slot][n]      one workgroup per image
+// scal: per-image accumulator table [slots][scal_ld] - image n writes scal[slot*scal_ld + n] (plain store; the step tail
+// sums the rows in a fixed order, so the logged scalars are bitwise reproducible)
 template <typename T>
 __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, int per_image4, float* __restrict__ scal,
-                                                      int slot, float* __restrict__ norms) {
+                                                      int slot, int scal_ld, float* __restrict__ norms) {
   __shared__ float sm[4];
   const T* p = g + (long long)blockIdx.x * per_image4 * 4;
   float s = 0.f;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, i
   if (threadIdx.x == 0) {
     const float nr = sqrtf(s);
     if (norms) norms[blockIdx.x] = nr;
-    atomicAdd(scal + slot, (nr - 1.f) * (nr - 1.f));
+    if (scal && slot >= 0) scal[(long long)slot * scal_ld + blockIdx.x] = (nr - 1.f) * (nr - 1.f);
   }
 }
 
@@ -268,7 +271,10 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
 
 // stage 1: partial[blk][0..C) = sum g_z,  partial[blk][C..2C) = sum g_z * xhat over this workgroup's rows,
 // g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics.
-#define BN_BWD_MAX_BLOCKS 256
+// HBM-bound: every thread keeps BN_BWD_UNR rows (2 x 16-byte loads each) in flight and the grid is sized for ~8 workgroups
+// per CU (>= 64 KB in flight per CU; with one workgroup per CU and 2 loads per thread the kernel ran at 2.4 TB/s).
+#define BN_BWD_MAX_BLOCKS 1024
+#define BN_BWD_UNR 4
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
@@ -286,7 +292,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     sc[k] = aux[c + k]; sh[k] = aux[C + c + k]; mu[k] = aux[2 * C + c + k]; is[k] = aux[3 * C + c + k];
     s1[k] = 0.f; s2[k] = 0.f;
   }
-  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
+  // rows of this thread: blockIdx.x*rstep + r0 + j*stride; the summation order per (thread, channel) is fixed by the
+  // launch geometry alone, so the result is bitwise reproducible
+  const long long stride = (long long)gridDim.x * rstep;
+  long long r = (long long)blockIdx.x * rstep + r0;
+  for (; r + (BN_BWD_UNR - 1) * stride < rows; r += BN_BWD_UNR * stride) {
+    Raw8<T> rg[BN_BWD_UNR], ry[BN_BWD_UNR];
+#pragma unroll
+    for (int j = 0; j < BN_BWD_UNR; ++j) { ldraw(ga + (r + j * stride) * C + c, rg[j]); ldraw(y + (r + j * stride) * C + c, ry[j]); }
+#pragma unroll
+    for (int j = 0; j < BN_BWD_UNR; ++j) {
+      float vg[8], vy[8];
+      unraw(rg[j], vg); unraw(ry[j], vy);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = vy[k] * sc[k] + sh[k];
+        const float gz = z > 0.f ? vg[k] : slope * vg[k];
+        s1[k] += gz;
+        s2[k] += gz * ((vy[k] - mu[k]) * is[k]);
+      }
+    }
+  }
+  for (; r < rows; r += stride) {
     float vg[8], vy[8];
     ld8(ga + r * C + c, vg);
     ld8(y + r * C + c, vy);
@@ -303,49 +330,51 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float t = 0.f;
-    for (int r = 0; r < rstep; ++r) t += lsum[r * 2 * C + i];
+    for (int rr = 0; rr < rstep; ++rr) t += lsum[rr * 2 * C + i];
     partial[(long long)blockIdx.x * 2 * C + i] = t;
   }
 }
 
-// stage 2: sums[0..2C) = sum over workgroups; dgamma += s2, dbeta += s1 (when given).  One workgroup per 4 channels.
+// stage 2: sums[g][0..2C) = sum over workgroups for every group g; dgamma += sum_{g < grad_groups} s2, dbeta likewise (when
+// given) - the groups are walked in order inside the workgroup, so the gradient does not depend on any arrival order.
+// One workgroup per 4 channels.
 static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                                                 long long group_stride = 0, int grad_groups = 1,
+                                                                 long long group_stride = 0, int groups = 1, int grad_groups = 1,
                                                                  long long partial_group_stride = -1) {
   __shared__ float sh[4][8];
   const int c0 = blockIdx.x * 4;
-  // grouped: blockIdx.y = group; only groups < grad_groups contribute to dgamma / dbeta (float atomics: with <= 2 adders
-  // on a zeroed gradient the sum does not depend on their order)
-  partial += (long long)blockIdx.y * (partial_group_stride >= 0 ? partial_group_stride : group_stride);
-  sums += (long long)blockIdx.y * group_stride;
-  const bool atomic = gridDim.y > 1;
-  if ((int)blockIdx.y >= grad_groups) { dgamma = nullptr; dbeta = nullptr; }
-  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  for (int k = threadIdx.x; k < nblk; k += 256) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(partial + (long long)k * 2 * C + c0);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(partial + (long long)k * 2 * C + C + c0);
+  const long long pgs = partial_group_stride >= 0 ? partial_group_stride : group_stride;
+  float dg = 0.f, db = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float* pp = partial + (long long)g * pgs;
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nblk; k += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + c0);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + C + c0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i] += a[i]; q[i] += b[i]; }
+      for (int i = 0; i < 4; ++i) { s[i] += a[i]; q[i] += b[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] = wave_sum(s[i]); q[i] = wave_sum(q[i]); }
+    __syncthreads();                                        // the previous group's sh[] has been read
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sh[threadIdx.x >> 6][i] = s[i]; sh[threadIdx.x >> 6][4 + i] = q[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int i = threadIdx.x, c = c0 + i;
+      const float s1 = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], s2 = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
+      sums[(long long)g * group_stride + c] = s1;
+      sums[(long long)g * group_stride + C + c] = s2;
+      if (g < grad_groups) { dg += s2; db += s1; }
+    }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { s[i] = wave_sum(s[i]); q[i] = wave_sum(q[i]); }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { sh[threadIdx.x >> 6][i] = s[i]; sh[threadIdx.x >> 6][4 + i] = q[i]; }
-  }
-  __syncthreads();
-  if (threadIdx.x >= 4) return;
-  const int i = threadIdx.x, c = c0 + i;
-  const float s1 = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], s2 = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
-  sums[c] = s1;
-  sums[C + c] = s2;
-  if (atomic) {
-    if (dgamma) atomicAdd(dgamma + c, s2);
-    if (dbeta) atomicAdd(dbeta + c, s1);
-  } else {
-    if (dgamma) dgamma[c] += s2;
-    if (dbeta) dbeta[c] += s1;
+  if (threadIdx.x < 4) {
+    const int c = c0 + threadIdx.x;
+    if (dgamma) dgamma[c] += dg;
+    if (dbeta) dbeta[c] += db;
   }
 }
 
@@ -382,7 +411,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4, const float* __restrict__ w, int K,
                                                        const float* __restrict__ bias, float target, int mode, float invB,
                                                        float* __restrict__ prob, float* __restrict__ ds,
-                                                       float* __restrict__ scal, int slot_loss, int slot_p) {
+                                                       float* __restrict__ scal, int slot_loss, int slot_p, int scal_ld) {
   __shared__ float sm[4];
   const T* x = a4 + (long long)blockIdx.x * K;
   float s = 0.f;
@@ -404,11 +433,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4,
       const float loss = -(target * lp + (1.f - target) * lq);
       const float dp = (p - target) / fmaxf(pq, 1e-12f) * invB;
       ds[blockIdx.x] = dp * pq;
-      if (slot_loss >= 0) atomicAdd(scal + slot_loss, loss);
+      if (slot_loss >= 0) scal[(long long)slot_loss * scal_ld + blockIdx.x] = loss;
     } else {
       ds[blockIdx.x] = pq;
     }
-    if (slot_p >= 0) atomicAdd(scal + slot_p, p);
+    if (slot_p >= 0) scal[(long long)slot_p * scal_ld + blockIdx.x] = p;
   }
 }
 
@@ -427,11 +456,12 @@ __global__ void head_dgrad_kernel(const float* __restrict__ ds, const float* __r
   }
 }
 
-// dw[k] += sum_n ds[n] * a4[n][k]       (packed (h,w,c) order; dw pre-zeroed or accumulating)
-// grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup, images strided over lanes and gridDim.y
+// part[y][k] = sum over this workgroup's images of ds[n] * a4[n][k]       (packed (h,w,c) order)
+// grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup, images strided over lanes and gridDim.y; the NS
+// partial rows are summed in order by head_part_reduce_kernel (no float atomics: bitwise reproducible)
 template <typename T>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ ds, const T* __restrict__ a4, int B, int K,
-                                                         float* __restrict__ dw) {
+                                                         float* __restrict__ part) {
   __shared__ float red[4][64][9];
   const int u = threadIdx.x & 63, ln = threadIdx.x >> 6;
   const int k = (blockIdx.x * 64 + u) * 8;
@@ -448,14 +478,28 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   for (int j = 0; j < 8; ++j) red[ln][u][j] = s[j];
   __syncthreads();
   if (ln == 0 && k < K) {
+    float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(dw + k + j, red[0][u][j] + red[1][u][j] + red[2][u][j] + red[3][u][j]);
+    for (int j = 0; j < 8; ++j) o[j] = (red[0][u][j] + red[1][u][j]) + (red[2][u][j] + red[3][u][j]);
+    st8(part + (long long)blockIdx.y * K + k, o);
   }
 }
 
-// D.conv5 backward in one launch: g_a4[n][k] = ds[n] * w[k] and grad(conv5.weight)[c][t] += sum_n ds[n] * a4[n][t*C + c]
-// (k = t*C + c is the packed (h,w,c) order; the sum goes straight into the PyTorch-layout gradient with float atomics, so
-// there is no scratch vector to zero and no unpack pass).  grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup.
+// out (+)= sum_y part[y][k], y in order.  C == 0: out[k] (packed order, `accumulate` selects = / +=);  C > 0: the PyTorch
+// layout of a [1][C][4][4] conv weight gradient, out[c*16 + t] += sum_y part[y][t*C + c]
+static __global__ void head_part_reduce_kernel(const float* __restrict__ part, int NS, int K, int C, float* __restrict__ out,
+                                               int accumulate) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int y = 0; y < NS; ++y) s += part[(long long)y * K + k];
+  if (C > 0) { const int t = k / C, c = k % C; out[c * 16 + t] += s; }
+  else out[k] = accumulate ? out[k] + s : s;
+}
+
+// D.conv5 backward in one launch: g_a4[n][k] = ds[n] * w[k] and the partial weight-gradient rows
+// part[y][k] = sum_{n of workgroup row y} ds[n] * a4[n][k]  (k = t*C + c is the packed (h,w,c) order); head_part_reduce_kernel
+// sums the rows in order into the PyTorch-layout gradient.  grid (K/8/64, NS): 64 column units x 4 image lanes per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __restrict__ ds, const float* __restrict__ w,
                                                              const T* __restrict__ a4, int B, int K, int C,
@@ -489,10 +533,10 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
   for (int j = 0; j < 8; ++j) red[ln][u][j] = s[j];
   __syncthreads();
   if (ln == 0 && k < K) {
-    const int t = k / C, c = k % C;                      // 8 consecutive k share the tap (C % 8 == 0)
+    float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      atomicAdd(grad + (long long)(c + j) * 16 + t, red[0][u][j] + red[1][u][j] + red[2][u][j] + red[3][u][j]);
+    for (int j = 0; j < 8; ++j) o[j] = (red[0][u][j] + red[1][u][j]) + (red[2][u][j] + red[3][u][j]);
+    st8(grad + (long long)blockIdx.y * K + k, o);          // `grad` is the partial buffer [NS][K] here
   }
 }
 
@@ -689,21 +733,32 @@ __global__ void pad_rows_kernel(const float* __restrict__ in, int B, int Ci, int
   }
 }
 
-// acc: 0 loss_real 1 loss_fake 2 loss_g 3 sum p(real) 4 sum p(fake) 5 sum p(g phase) 6 sum (||g||-1)^2
+// acc rows: 0 loss_real 1 loss_fake 2 loss_g 3 p(real) 4 p(fake) 5 p(g phase) 6 (||g||-1)^2, one entry per image
 // out: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake      (train/dcgan_trainer.py:179,192-193)
 // End of a step in ONE launch: the deferred BatchNorm running-stat records of D's four layers (blockIdx.y = layer, same
 // recurrence as sequential momentum updates) and the logged scalars (blockIdx.y = 4).
 struct TailLayer { const float* rec; float* rm; float* rv; long long* nbt; int C; };
-struct TailJobs { TailLayer l[4]; int npass; float momentum; const float* acc; float invB, lambda_gp; float* out; };
-static __global__ void step_tail_kernel(const TailJobs t) {
+// acc is the per-image table [7][acc_ld] (head_fwd / gp_norm write one entry per image): each row is summed here in a fixed
+// order (thread-strided partial sums, wavefront shuffles, 4 wave totals), so the logged scalars are bitwise reproducible.
+struct TailJobs { TailLayer l[4]; int npass; float momentum; const float* acc; int acc_ld, B; float invB, lambda_gp; float* out; };
+static __global__ __launch_bounds__(256) void step_tail_kernel(const TailJobs t) {
   if (blockIdx.y == 4) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      const float lr = t.acc[0] * t.invB, lf = t.acc[1] * t.invB, gp = t.acc[6] * t.invB;
+    if (blockIdx.x != 0) return;
+    __shared__ float sm[4];
+    float tot[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      float s = 0.f;
+      for (int n = threadIdx.x; n < t.B; n += 256) s += t.acc[(long long)q * t.acc_ld + n];
+      tot[q] = block_sum256(s, sm);
+    }
+    if (threadIdx.x == 0) {
+      const float lr = tot[0] * t.invB, lf = tot[1] * t.invB, gp = tot[6] * t.invB;
       t.out[0] = (lr + lf) + t.lambda_gp * gp;
-      t.out[1] = t.acc[2] * t.invB;
-      t.out[2] = t.acc[3] * t.invB;
-      t.out[3] = t.acc[4] * t.invB;
-      t.out[4] = t.acc[5] * t.invB;
+      t.out[1] = tot[2] * t.invB;
+      t.out[2] = tot[3] * t.invB;
+      t.out[3] = tot[4] * t.invB;
+      t.out[4] = tot[5] * t.invB;
       t.out[5] = gp;
       t.out[6] = lr;
       t.out[7] = lf;
@@ -889,23 +944,20 @@ __global__ void gp_grad_kernel(const T* __restrict__ g, const float* __restrict_
 
 // second-order head terms of the penalty (see tests/test_gp_double_backward_math.py):
 //   uds[n] = <ughd[n,:], w2>;  rs[n] = uds * (1-2p) * p(1-p);  dw2[j] += sum_n ds[n] * ughd[n][j]     (ds = p(1-p))
+// (the dw2 sum is formed afterwards by head_wgrad_kernel + head_part_reduce_kernel from pq[n] = ds[n]: no atomics)
 template <typename T>
 __global__ __launch_bounds__(256) void gp_head2_kernel(const T* __restrict__ ughd, const float* __restrict__ w2,
                                                        const float* __restrict__ prob, int B, int K, float* __restrict__ rs,
-                                                       float* __restrict__ dw2) {
+                                                       float* __restrict__ pq_out) {
   __shared__ float sm[4];
   const int n = blockIdx.x;
   float s = 0.f;
-  for (int j = threadIdx.x; j < K; j += 256) {
-    const float v = ldf(ughd + (long long)n * K + j);
-    s += v * w2[j];
-    const float p = prob[n];
-    atomicAdd(dw2 + j, p * (1.f - p) * v);
-  }
+  for (int j = threadIdx.x; j < K; j += 256) s += ldf(ughd + (long long)n * K + j) * w2[j];
   s = block_sum256(s, sm);
   if (threadIdx.x == 0) {
     const float p = prob[n], pq = p * (1.f - p);
     rs[n] = s * (1.f - 2.f * p) * pq;
+    pq_out[n] = pq;
   }
 }
 

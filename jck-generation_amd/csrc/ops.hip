@@ -552,6 +552,13 @@ extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float s
 }
 
 extern "C" size_t jck_bn_bwd_ws_floats(int C) { return (size_t)(2 + 2 * BN_BWD_MAX_BLOCKS) * C; }
+// workgroups of the backward reduction: BN_BWD_UNR rows per thread and pass, at least two passes per thread, ~2048 workgroups
+// (8 per CU) over all groups - the kernel is HBM-bound and needs >= 64 KB of loads in flight per CU
+static int bn_bwd_blocks(long long rows, int rstep, int groups) {
+  const long long want = (rows + (long long)rstep * BN_BWD_UNR * 2 - 1) / ((long long)rstep * BN_BWD_UNR * 2);
+  const long long cap = std::min<long long>(BN_BWD_MAX_BLOCKS, std::max(1, 2048 / std::max(1, groups)));
+  return (int)std::max<long long>(1, std::min(want, cap));
+}
 
 extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
                               void* g_y, float* dgamma, float* dbeta, long long rows, int C, void* stream) {
@@ -559,7 +566,7 @@ extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const fl
   const int rstep = 256 / (C / 8);
   if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C too large");
   // stage 1: per-workgroup partial sums -> sums[2C + blk*2C ..];  stage 2: reduce to sums[0..2C) (+ dgamma/dbeta)
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  const int blocks = bn_bwd_blocks(rows, rstep, 1);
   float* partial = sums + 2 * C;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C));
@@ -602,14 +609,14 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
   const long long rows = rows_per_group;
   const int rstep = 256 / (C / 8);
   if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd_grouped: C too large");
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  const int blocks = bn_bwd_blocks(rows, rstep, groups);
   const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
   float* partial = sums + 2 * C;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C,
-                     gstride, grad_groups);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C,
+                     gstride, groups, grad_groups);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
@@ -625,8 +632,8 @@ extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const
                                  int C, int groups, int grad_groups, void* stream) {
   if (!is_pow2(C) || C < 8 || groups < 1 || slots_per_group < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_finish: bad shape");
   const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, slots, slots_per_group, sums, dgamma,
-                     dbeta, C, gstride, grad_groups, (long long)slots_per_group * 2 * C);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, slots, slots_per_group, sums, dgamma,
+                     dbeta, C, gstride, groups, grad_groups, (long long)slots_per_group * 2 * C);
   HIPCHK(hipGetLastError());
   const long long total8 = rows_per_group * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
@@ -683,9 +690,10 @@ extern "C" int jck_interp(int prec, const void* a, const void* b, const float* a
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
-extern "C" int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, float* norms, void* stream) {
+extern "C" int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, int scal_ld, float* norms, void* stream) {
+  if (scal && slot >= 0 && scal_ld < N) JCK_FAIL(JCK_E_ARG, "gp_norm: scal_ld < N");
   DISPATCH_T(prec, hipLaunchKernelGGL(gp_norm_kernel<T>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const T*)g, HW, scal,
-                                      slot, norms));
+                                      slot, scal_ld, norms));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -697,16 +705,21 @@ extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale,
   return JCK_OK;
 }
 extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias, int B, int K, float target, int mode,
-                            float* prob, float* ds, float* scal, int slot_loss, int slot_p, void* stream) {
+                            float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream) {
   if (K % 8) JCK_FAIL(JCK_E_ARG, "head_fwd: K % 8 != 0");
+  if ((slot_loss >= 0 || slot_p >= 0) && (!scal || scal_ld < B)) JCK_FAIL(JCK_E_ARG, "head_fwd: scalar slots need scal with scal_ld >= B");
   DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K, bias,
-                                      target, mode, 1.0f / (float)B, prob, ds, scal, slot_loss, slot_p));
+                                      target, mode, 1.0f / (float)B, prob, ds, scal, slot_loss, slot_p, scal_ld));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
+#define HEAD_NS 8          /* partial rows of jck_head_bwd */
+#define HEAD_CONV_NS 16    /* partial rows of jck_head_bwd_conv */
+extern "C" size_t jck_head_bwd_ws_floats(int K) { return (size_t)HEAD_CONV_NS * K; }
 extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const void* a4, int B, int K, void* g_a4, float* dwp,
-                            int accumulate, void* stream) {
+                            int accumulate, float* ws, void* stream) {
   if (K % 8) JCK_FAIL(JCK_E_ARG, "head_bwd: K % 8 != 0");
+  if (dwp && !ws) JCK_FAIL(JCK_E_ARG, "head_bwd: the weight gradient needs a workspace of jck_head_bwd_ws_floats(K) floats");
   if (g_a4) {
     const long long total8 = (long long)B * K / 8;
     DISPATCH_T(prec, hipLaunchKernelGGL(head_dgrad_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, ds, wp,
@@ -714,21 +727,27 @@ extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const vo
     HIPCHK(hipGetLastError());
   }
   if (dwp) {
-    if (!accumulate) HIPCHK(hipMemsetAsync(dwp, 0, (size_t)K * sizeof(float), (hipStream_t)stream));
-    DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), 8), dim3(256), 0, (hipStream_t)stream, ds,
-                                        (const T*)a4, B, K, dwp));
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_NS), dim3(256), 0, (hipStream_t)stream, ds,
+                                        (const T*)a4, B, K, ws));
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, ws, HEAD_NS, K, 0, dwp, accumulate);
     HIPCHK(hipGetLastError());
   }
   return JCK_OK;
 }
 extern "C" int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4,
-                                 float* grad, void* stream) {
+                                 float* grad, float* ws, void* stream) {
   if (C % 8) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: C % 8 != 0");
   if (!g_a4 && !grad) return JCK_OK;
+  if (grad && !ws) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: the weight gradient needs a workspace of jck_head_bwd_ws_floats(16*C) floats");
   const int K = 16 * C;
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), 16), dim3(256), 0, (hipStream_t)stream, ds, wp,
-                                      (const T*)a4, B, K, C, (T*)g_a4, grad));
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, (hipStream_t)stream, ds, wp,
+                                      (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr));
   HIPCHK(hipGetLastError());
+  if (grad) {
+    hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, ws, HEAD_CONV_NS, K, C, grad, 1);
+    HIPCHK(hipGetLastError());
+  }
   return JCK_OK;
 }
 extern "C" int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, void* stream) {
@@ -883,10 +902,19 @@ extern "C" int jck_gp_grad(int prec, const void* g, const float* norms, float co
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
+// ws: float[B + jck_head_bwd_ws_floats(K)] (pq[n] = p(1-p), then the partial rows of the dw2 sum)
 extern "C" int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2,
-                            void* stream) {
+                            float* ws, void* stream) {
+  if (K % 8 || !ws) JCK_FAIL(JCK_E_ARG, "gp_head2: K % 8 != 0 or no workspace");
   DISPATCH_T(prec, hipLaunchKernelGGL(gp_head2_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)ughd, w2, prob, B, K,
-                                      rs, dw2));
+                                      rs, ws));
+  HIPCHK(hipGetLastError());
+  // dw2[j] += sum_n pq[n] * ughd[n][j]
+  float* part = ws + (B + 63) / 64 * 64;
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_NS), dim3(256), 0, (hipStream_t)stream, ws,
+                                      (const T*)ughd, B, K, part));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, part, HEAD_NS, K, 0, dw2, 1);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -899,7 +927,7 @@ extern "C" int jck_bn2_vchain(int prec, const void* v, const void* y, const void
                               void* stream) {
   if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn2_vchain: C must be a power of two in [8, 2048]");
   const int rstep = 256 / (C / 8);
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  const int blocks = bn_bwd_blocks(rows, rstep, 1);
   float* partial = ws + 4 * C;
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 3 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)v, (const T*)y, (const T*)gy, aux, slope, partial, rows, C));
@@ -922,7 +950,7 @@ extern "C" int jck_bn2_reverse(int prec, const void* ua, const void* y, const vo
                                int C, void* stream) {
   if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn2_reverse: C must be a power of two in [8, 2048]");
   const int rstep = 256 / (C / 8);
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
+  const int blocks = bn_bwd_blocks(rows, rstep, 1);
   float* partial = ws + 4 * C;
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 4 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)ua, (const T*)y, (const T*)xdir, aux, slope, partial, rows, C));

@@ -227,7 +227,7 @@ class _HeadSigmoid(Function):
         lib.jck_pack_head(_f32(w), c, wp, cur_stream())
         prob = torch.empty(n, dtype=torch.float32, device=dev)
         dsig = torch.empty(n, dtype=torch.float32, device=dev)          # p(1-p)
-        lib.jck_head_fwd(prec, a4, wp, None, n, 16 * c, 0.0, 1, prob, dsig, None, -1, -1, cur_stream())
+        lib.jck_head_fwd(prec, a4, wp, None, n, 16 * c, 0.0, 1, prob, dsig, None, -1, -1, 0, cur_stream())
         ctx.save_for_backward(a4, wp, dsig)
         ctx.meta = (prec, c)
         return prob.view(n, 1, 1, 1)
@@ -242,7 +242,8 @@ class _HeadSigmoid(Function):
         ga = torch.empty_like(a4) if ctx.needs_input_grad[0] else None
         gw = None
         dwp = torch.empty(16 * c, dtype=torch.float32, device=a4.device) if ctx.needs_input_grad[1] else None
-        lib.jck_head_bwd(prec, ds, wp, a4, n, 16 * c, ga, dwp, 0, cur_stream())
+        hws = torch.empty(lib.jck_head_bwd_ws_floats(16 * c), dtype=torch.float32, device=a4.device) if dwp is not None else None
+        lib.jck_head_bwd(prec, ds, wp, a4, n, 16 * c, ga, dwp, 0, hws, cur_stream())
         if dwp is not None:
             gw = torch.empty(1, c, 4, 4, dtype=torch.float32, device=a4.device)
             lib.jck_head_unpack_grad(dwp, c, gw, 0, cur_stream())
@@ -315,7 +316,7 @@ class _CganHead(Function):
         prob = torch.empty(B, dtype=torch.float32, device=dev)
         dsig = torch.empty(B, dtype=torch.float32, device=dev)
         w2f, b2f = _f32(w2).view(-1), _f32(b2)
-        lib.jck_head_fwd(prec, hd, w2f, b2f, B, L1_OUT, 0.0, 1, prob, dsig, None, -1, -1, st)
+        lib.jck_head_fwd(prec, hd, w2f, b2f, B, L1_OUT, 0.0, 1, prob, dsig, None, -1, -1, 0, st)
         ctx.save_for_backward(a4, lab, mask, cbuf, pre_e, hd, dsig, w1, w2f)
         ctx.prec = prec
         return prob.view(B, 1)
@@ -331,7 +332,8 @@ class _CganHead(Function):
         ds = (gp.reshape(B).to(torch.float32) * dsig).contiguous()
         ghd = torch.empty(B, L1_OUT, dtype=dt, device=dev)
         gw2 = torch.zeros(L1_OUT, **f32)
-        lib.jck_head_bwd(prec, ds, w2f, hd, B, L1_OUT, ghd, gw2, 1, st)
+        hws = torch.empty(lib.jck_head_bwd_ws_floats(L1_OUT), **f32)
+        lib.jck_head_bwd(prec, ds, w2f, hd, B, L1_OUT, ghd, gw2, 1, hws, st)
         gb2 = torch.zeros(1, **f32)
         lib.jck_sum_vec(ds, B, gb2, st)
         gh = torch.empty_like(ghd)

@@ -155,10 +155,11 @@ def bce(prob, target: float):
     return F.binary_cross_entropy(prob, torch.full_like(prob, target))
 
 
-def gradient_penalty(d_state, real, fake, alpha, labels=None, drop_mask=None, create_graph=True):
-    """train/dcgan_trainer.py:110-127."""
-    inter = (alpha * real + ((1 - alpha) * fake)).requires_grad_(True)
-    di = discriminator(d_state, inter, labels, drop_mask)
+def gradient_penalty(d_state, real, fake, alpha, labels=None, drop_mask=None, create_graph=True, disc=None, store=None):
+    """train/dcgan_trainer.py:110-127.  disc / store: the bf16-storage emulation's net and rounding (oracle/bf16_emu.py)."""
+    inter = alpha * real + ((1 - alpha) * fake)
+    inter = (store(inter) if store is not None else inter).requires_grad_(True)
+    di = (disc or discriminator)(d_state, inter, labels, drop_mask)
     grads = torch.autograd.grad(di, inter, torch.ones_like(di), create_graph=create_graph, retain_graph=True)[0]
     grads = grads.view(grads.size(0), -1)
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
@@ -197,8 +198,17 @@ class GanOracle:
     the reference's order (n1, z, n2, [dropout masks inside each D call], alpha).
     """
 
-    def __init__(self, family="dcgan", lr=2e-4, seed: Optional[int] = 12345, skip_dead_wgrad=False):
+    def __init__(self, family="dcgan", lr=2e-4, seed: Optional[int] = 12345, skip_dead_wgrad=False, emulate_bf16=False):
+        """emulate_bf16: round to bf16 wherever the HIP fast path stores a tensor in bf16 (oracle/bf16_emu.py; DCGAN only) -
+        the envelope for the fast path's distance from this fp32 restatement.  Default off = the pinned oracle."""
         assert family in ("dcgan", "cgan")
+        assert not (emulate_bf16 and family != "dcgan"), "the bf16 emulation covers DCGAN only"
+        self.emu = emulate_bf16
+        if emulate_bf16:
+            from . import bf16_emu
+            self._gen, self._disc, self._store = bf16_emu.generator_bf16, bf16_emu.discriminator_bf16, bf16_emu.store
+        else:
+            self._gen, self._disc, self._store = generator, discriminator, None
         if seed is not None:
             torch.manual_seed(seed)
         self.family = family
@@ -219,7 +229,7 @@ class GanOracle:
     def sample(self, z, labels=None):
         """train/dcgan_trainer.py:199-200: no_grad, train-mode BN (running stats DO move)."""
         with torch.no_grad():
-            return generator(self.g, z, labels)
+            return self._gen(self.g, z, labels)
 
     def step(self, real, labels=None, noise=None):
         ctx = self.phase_d(real, labels, noise)
@@ -242,20 +252,24 @@ class GanOracle:
 
         n1 = nz["n1"] if "n1" in nz else torch.randn(real.size())
         real = NOISE_KEEP * real + NOISE_MIX * n1
-        out_real = discriminator(self.d, real, labels, mask("m1")).view(-1)
+        if self.emu:
+            real = self._store(real)
+        out_real = self._disc(self.d, real, labels, mask("m1")).view(-1)
         e_real = bce(out_real, LABEL_REAL)
         z = nz["z"] if "z" in nz else torch.randn(B, 100, 1, 1)
-        fake_raw = generator(self.g, z, labels)
+        fake_raw = self._gen(self.g, z, labels)
         n2 = nz["n2"] if "n2" in nz else torch.randn(fake_raw.size())
         fake = NOISE_KEEP * fake_raw + NOISE_MIX * n2
-        out_fake = discriminator(self.d, fake.detach(), labels, mask("m2")).view(-1)
+        if self.emu:
+            fake = self._store(fake)
+        out_fake = self._disc(self.d, fake.detach(), labels, mask("m2")).view(-1)
         e_fake = bce(out_fake, LABEL_FAKE)
         alpha = nz["alpha"] if "alpha" in nz else torch.rand(B, 1, 1, 1)
         if fam == "dcgan":
             # train/dcgan_trainer.py:164,175: two separate backward calls; the penalty (178) is never
             # back-propagated - it only enters the logged error_d (179) and moves D's BN statistics.
             dg = torch.autograd.grad(e_real + e_fake, dpl, retain_graph=False)
-            gp = gradient_penalty(self.d, real, fake, alpha).detach()
+            gp = gradient_penalty(self.d, real, fake, alpha, create_graph=not self.emu, disc=self._disc, store=self._store).detach()
         else:
             # train/cgan_trainer.py:200-203: one backward over real + fake + 10*GP (double backward).
             gp = gradient_penalty(self.d, real.detach(), fake.detach(), alpha, labels, mask("m3"))
@@ -273,7 +287,7 @@ class GanOracle:
     def phase_g(self, ctx):
         gnames = list(self.gp_params)
         gpl = [self.gp_params[k] for k in gnames]
-        out_g = discriminator(self.d, ctx["fake"], ctx["labels"], ctx["m4"]).view(-1)
+        out_g = self._disc(self.d, ctx["fake"], ctx["labels"], ctx["m4"]).view(-1)
         e_g = bce(out_g, LABEL_REAL)
         gg = torch.autograd.grad(e_g, gpl)
         self.g_grads = dict(zip(gnames, gg))

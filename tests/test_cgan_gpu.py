@@ -32,8 +32,9 @@ def _cmp(views, refs, tol_l2, what):
     assert not bad, "\\n".join(bad)
 
 
-@pytest.mark.parametrize("prec,B,tol,gtol", [("f32", 8, 1e-3, 2e-2), ("f32", 32, 1e-3, 5e-3), ("bf16", 32, 5e-2, 3e-1)])
+@pytest.mark.parametrize("prec,B,tol,gtol", [("f32", 8, 1e-3, 2e-2), ("f32", 32, 1e-3, 5e-3)])
 def test_cgan_step_parity(prec, B, tol, gtol):
+    """(the bf16 path: tests/test_bf16_envelope.py, per tensor within 2x the measured error at B = 8 / 64 / 256)"""
     from hipgan.engine import CganEngine
     from oracle.gan_oracle import GanOracle
     from util import synth_images, synth_onehot
@@ -72,7 +73,7 @@ def test_cgan_state_layout_matches_reference_keys():
     assert gs["conv1.weight"].shape == (200, 512, 4, 4)
 
 
-@pytest.mark.parametrize("prec,tol,gtol", [("f32", 1e-3, 3e-2), ("bf16", 5e-2, 4e-1)])
+@pytest.mark.parametrize("prec,tol,gtol", [("f32", 1e-3, 3e-2)])
 def test_cgan_full_size_step_batch256(prec, tol, gtol):
     """BASELINE.json configs[3] at its full size (batch 256, 10-class one-hot labels in the 100-wide encoding): one step against
     the oracle - production tile shapes, split-K Linear(8392,256), wave-specialised kernels, the double backward at scale."""

@@ -7,9 +7,9 @@ Tolerances (relative):
       LeakyReLU/ReLU derivative is discontinuous at 0, so a pre-activation within rounding distance of 0 can take the other
       branch than on the CPU and change a handful of gradient elements by 0.8*g - an effect the reference shows against
       itself once its own summation order changes (tests/golden/selfdiv.json).
-  JCK_PREC_BF16 (fast path): 3e-2 on losses per step (bf16 storage of activations and gradients; SURVEY A.2 measured
-      3.4e-3 for bf16 conv operands alone), trajectories compared statistically against the reference's own
-      8-thread-vs-1-thread divergence (tests/golden/selfdiv.json)."""
+  JCK_PREC_BF16 (fast path): 3e-2 on losses per step here; gradients, per tensor, within 2x the error MEASURED on a MI355X
+      (tests/golden/bf16_error_table.json) and inside the envelope of a bf16-storage emulation of the oracle - see
+      tests/test_bf16_envelope.py, which also holds the free-running trajectory and the run-to-run determinism."""
 import pytest
 import torch
 
@@ -108,9 +108,7 @@ def test_step_parity_bf16(B):
         for k in ("loss_d", "loss_g", "loss_real", "loss_fake"):
             assert _rel(got[k], ref[k]) < 3e-2, (s, k, got[k], ref[k])
         assert _rel(got["gp"], ref["gp"]) < 6e-2, (s, got["gp"], ref["gp"])
-    ref, got, dgr, ggr = out[-1]
-    _cmp_tensors(eng.named_views("d", "grads"), dgr, 6e-1, "d_grads", 2.5e-1)
-    _cmp_tensors(eng.named_views("g", "grads"), ggr, 6e-1, "g_grads", 2.5e-1)
+    # gradients: tests/test_bf16_envelope.py (per tensor, <= 2x the measured error)
 
 
 def test_free_running_golden_f32():
@@ -180,37 +178,6 @@ def test_sample_matches_oracle():
     assert int(eng.named_views("g")["norm1.num_batches_tracked"]) == 2
 
 
-def test_bf16_trajectory_statistics():
-    """30 free-running bf16 steps at B=64 against the oracle.  A GAN trajectory is chaotic: the reference diverges from ITSELF
-    by 2.9 % in loss_d over steps 10..29 when only its thread count changes (a 1e-7 perturbation, tests/golden/selfdiv.json);
-    bf16 storage perturbs every step by ~1e-3, and float atomics make two runs of this path differ too.  Asserted: the first
-    steps track the oracle step by step, the later ones stay in the same regime - bounded pointwise divergence and the same
-    mean loss level - and nothing blows up."""
-    from hipgan.engine import DcganEngine
-    from oracle.gan_oracle import GanOracle
-    from util import load_golden, synth_images
-    sd = load_golden("selfdiv")
-    B, steps = 64, 30
-    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
-    eng = DcganEngine(batch=B, prec="bf16")
-    eng.load_state(orc.g, orc.d)
-    imgs = synth_images(B * 4)
-    rd, ld_ref, ld_got = [], [], []
-    for s in range(steps):
-        real, nz = imgs[(s % 4) * B:(s % 4 + 1) * B], _noise(B, 500 + s)
-        ref = orc.step(real, None, nz)
-        got = eng.step(real.cuda(), {k: v.cuda() for k, v in nz.items()}, lr=2e-4)
-        rd.append(_rel(got["loss_d"], ref["loss_d"]))
-        ld_ref.append(ref["loss_d"])
-        ld_got.append(got["loss_d"])
-        assert got["loss_d"] == got["loss_d"] and got["loss_g"] == got["loss_g"]     # no NaN
-    floor = sum(sd["rel_d"][10:30]) / 20
-    assert max(rd[:5]) < 3e-2, rd[:5]                                   # step-by-step while the trajectories are still close
-    assert sum(rd[10:30]) / 20 < max(12 * floor, 0.35), (rd, floor)     # bounded divergence later on
-    m_ref, m_got = sum(ld_ref[10:30]) / 20, sum(ld_got[10:30]) / 20
-    assert abs(m_got - m_ref) < 0.15 * abs(m_ref), (m_got, m_ref)       # same loss level
-
-
 @pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 3e-2)])
 def test_config0_mnist_shaped_batch64(prec, tol):
     """BASELINE.json configs[0] (the reference's own CPU-runnable case): batch 64, MNIST-shaped input; per-step losses of the
@@ -235,8 +202,16 @@ def test_full_size_step_batch256(prec, tol):
     assert int(eng.named_views("d")["norm1.num_batches_tracked"]) == 4 and int(eng.named_views("g")["norm1.num_batches_tracked"]) == 1
     # D's gradients come from identical weights.  G's come through the D that Adam has just stepped: an element of D whose
     # gradient was within rounding of 0 moved the other way (2*lr), which at batch 256 shows as ~1e-2 in G's gradients.
-    _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3 if prec == "f32" else 1.2e-1)
-    _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2 if prec == "f32" else 2e-1)
+    if prec == "f32":
+        _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3)
+        _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2)
+    else:       # per tensor, 2x the error measured on a MI355X (tests/golden/bf16_error_table.json)
+        from test_bf16_envelope import limit
+        for tag, refs in (("d", dgr), ("g", ggr)):
+            views = eng.named_views(tag, "grads")
+            for k, r in refs.items():
+                l2 = ((views[k].detach().float().cpu().view(r.shape) - r).norm() / (r.norm() + 1e-30)).item()
+                assert l2 <= limit("dcgan", 256, f"{tag}_grads", k), (tag, k, l2)
 
 
 @pytest.mark.parametrize("env", [{"JCK_BATCHED": "0"}, {"JCK_BATCHED": "2"}, {"JCK_BATCHED": "4"}, {"JCK_OVERLAP": "0"},
