@@ -277,6 +277,9 @@ int jck_engine_sample(jck_engine*, const float* z, const int64_t* labels /* fami
 /* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */
 const void* jck_engine_tensor(const jck_engine*, const char* name, long long* numel);
 
+/* Kernel-selection knob (same names as the JCK_<KEY> environment presets, lower case: "igemm_256", "wgrad_gt", ...): lets
+ * one process A/B two variants on one device and lets a test force a variant at a small shape.  Unknown key -> JCK_E_ARG. */
+int jck_tune(const char* key, int value);
 /* per-launch HIP-event timing of the MFMA kernels (bench.py roofline leg).  enable(1) ... run ... collect():
  * per kernel variant: launches, total milliseconds, total algorithmic FLOPs.  Returns the number of rows. */
 int jck_prof_enable(int on);

@@ -270,11 +270,13 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
 }
 
 // stage 1: partial[blk][0..C) = sum g_z,  partial[blk][C..2C) = sum g_z * xhat over this workgroup's rows,
-// g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics.
-// HBM-bound: every thread keeps BN_BWD_UNR rows (2 x 16-byte loads each) in flight and the grid is sized for ~8 workgroups
-// per CU (>= 64 KB in flight per CU; with one workgroup per CU and 2 loads per thread the kernel ran at 2.4 TB/s).
-#define BN_BWD_MAX_BLOCKS 1024
-#define BN_BWD_UNR 4
+// g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics:
+// the summation order per (thread, channel) is fixed by the launch geometry alone, so the result is bitwise reproducible.
+// Geometry (measured in the step, round 2): <= 256 workgroups per group and one row per thread and pass.  A variant with
+// 1024 workgroups and 4 rows in flight per thread (8x the bytes in flight) was SLOWER in the step (29.3 vs 22.1 us average):
+// the kernel runs beside the weight-gradient product of the previous layer on the second stream and both are bound by the
+// same memory system, so more loads in flight here only take bandwidth from there.
+#define BN_BWD_MAX_BLOCKS 256
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
@@ -292,28 +294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     sc[k] = aux[c + k]; sh[k] = aux[C + c + k]; mu[k] = aux[2 * C + c + k]; is[k] = aux[3 * C + c + k];
     s1[k] = 0.f; s2[k] = 0.f;
   }
-  // rows of this thread: blockIdx.x*rstep + r0 + j*stride; the summation order per (thread, channel) is fixed by the
-  // launch geometry alone, so the result is bitwise reproducible
-  const long long stride = (long long)gridDim.x * rstep;
-  long long r = (long long)blockIdx.x * rstep + r0;
-  for (; r + (BN_BWD_UNR - 1) * stride < rows; r += BN_BWD_UNR * stride) {
-    Raw8<T> rg[BN_BWD_UNR], ry[BN_BWD_UNR];
-#pragma unroll
-    for (int j = 0; j < BN_BWD_UNR; ++j) { ldraw(ga + (r + j * stride) * C + c, rg[j]); ldraw(y + (r + j * stride) * C + c, ry[j]); }
-#pragma unroll
-    for (int j = 0; j < BN_BWD_UNR; ++j) {
-      float vg[8], vy[8];
-      unraw(rg[j], vg); unraw(ry[j], vy);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float z = vy[k] * sc[k] + sh[k];
-        const float gz = z > 0.f ? vg[k] : slope * vg[k];
-        s1[k] += gz;
-        s2[k] += gz * ((vy[k] - mu[k]) * is[k]);
-      }
-    }
-  }
-  for (; r < rows; r += stride) {
+  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
     float vg[8], vy[8];
     ld8(ga + r * C + c, vg);
     ld8(y + r * C + c, vy);

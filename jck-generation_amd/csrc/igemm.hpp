@@ -64,10 +64,10 @@ struct IgemmParams {
 
 #define IG_BK 64
 
-template <class P, int BCH, int BPIX> struct IgemmCfg {
+template <class P, int BCH, int BPIX, int NW = 4> struct IgemmCfg {      // NW: waves that own accumulators (4, or 8 consumers)
   static constexpr bool F32 = P::IS_F32;
   static constexpr int WCH = (BCH >= 64) ? 2 : 1;
-  static constexpr int WPIX = 4 / WCH;
+  static constexpr int WPIX = NW / WCH;
   static constexpr int FM = BCH / WCH / 16;
   static constexpr int FN = BPIX / WPIX / 16;
   static constexpr int WPASS = (BCH + 31) / 32;
@@ -399,23 +399,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // ------------------------------------------------------------------------------------------------------------------
 static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
 
-// WS (wave-specialised, 512 threads, NSTG = 3): waves 4-7 only issue the LDS-DMA (two stages ahead), waves 0-3 only read
+// WS (wave-specialised, NSTG = 3): the last 4 waves only issue the LDS-DMA (two stages ahead), the first NCW waves only read
 // fragments and feed the MFMA - see wgrad_dma_kernel in wgrad.hpp for the measurement behind it.  Used when the launch has
 // about one workgroup per CU, where a 4-wave workgroup would serialise DMA issue and MFMA in every wave.
-template <int BCH, int BPIX, int NSTG, bool BNB = false, bool WS = false>
-__global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmParams p) {
+// NCW = 8 (768 threads) with a 128 x 256 tile: the weight tile is filled once for twice the pixels - 85 instead of 64 FLOP
+// per filled byte (the kernels are bound by the LDS fill rate).
+template <int BCH, int BPIX, int NSTG, bool BNB = false, bool WS = false, int NCW = 4>
+__global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(const IgemmParams p) {
   static_assert(!WS || NSTG == 3, "wave specialisation uses 3 LDS stages");
+  static_assert(NCW == 4 || (WS && NCW == 8), "8 consumer waves exist in the wave-specialised form only");
   typedef PrecBf16 P;
-  typedef IgemmCfg<P, BCH, BPIX> C;
+  typedef IgemmCfg<P, BCH, BPIX, NCW> C;
   constexpr int FM = C::FM, FN = C::FN, LD = IG_BK;                 // unpadded 128-byte rows
   constexpr int STG_BYTES = (BCH + BPIX) * LD * 2;
   constexpr int NLD = (BCH + BPIX) / 32;                            // DMA wave-instructions per stage and wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* lds = smem_raw;                                    // the ONLY shared object (hipcc wait-insertion trap)
 
-  const int tid = threadIdx.x & 255, lane = tid & 63;                // position inside the role (loader / consumer)
+  const bool loader = WS && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= NCW;
+  const int tid = loader ? (int)threadIdx.x - NCW * 64 : (int)threadIdx.x, lane = tid & 63;   // position inside the role
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = WS && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
   const int nwg = gridDim.x;
   int wgid;
   {
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmPa
   const int m0 = bidx * BPIX, ch0 = bidy * BCH;
   const int Cc = 1 << p.logC;
 
-  const int lrow = tid >> 3, unit = tid & 7;
+  const int lrow = (tid & 255) >> 3, unit = tid & 7;                 // fill geometry of the 4 issuing waves
   const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;      // swizzle on the source side
   unsigned rowoff[C::APASS];
   int riy[C::APASS], rix[C::APASS];
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmPa
   // k-steps past the end re-load the last tile into a stage nobody reads: no predicate, no branch, exact vmcnt arithmetic
   auto issue = [&](int kc, int stage) {
     const int kbase = min(kc, nk - 1) * IG_BK;
-    unsigned char* sb = lds + stage * STG_BYTES + wave * (8 * LD * 2);           // this wave's 8 rows of each 32-row pass
+    unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);     // this wave's 8 rows of each 32-row pass
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
       const unsigned char* src = wb + (wrowoff[ps] + (unsigned)kbase * 2u + src_chunk);
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmPa
     }
   };
 
-  const int wch = (C::WCH == 2) ? (wave >> 1) : 0;
-  const int wpix = (C::WCH == 2) ? (wave & 1) : wave;
+  const int wch = (C::WCH == 2) ? (wave / C::WPIX) : 0;
+  const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
   f32x4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -513,7 +516,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void igemm_dma_kernel(const IgemmPa
       for (int k = 0; k < nk; ++k) {
         if constexpr (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage k has landed (this wave's pieces)
         else if constexpr (NLD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else static_assert(NLD == 8 || NLD == 6, "add the vmcnt literal");
+        else if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else static_assert(NLD == 8 || NLD == 6 || NLD == 12, "add the vmcnt literal");
         __builtin_amdgcn_s_barrier();                                 // consumers may read stage k; stage k-1 is free
         issue(k + 2, slot);                                           // past the end: re-loads the last tile, never read
         slot = slot == 2 ? 0 : slot + 1;

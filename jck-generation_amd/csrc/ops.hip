@@ -3,6 +3,7 @@
 #include "thin.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 static thread_local std::string g_err;
@@ -13,6 +14,32 @@ extern "C" int jck_pad_rows(int c) { return c <= 16 ? 16 : (c <= 64 ? 64 : (c + 
 extern "C" int jck_pad_chan(int c) { return c == 3 ? 4 : c; }
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel-selection knobs: defaults are the measured-best choices; each can be preset with an environment variable of the
+// same name (JCK_<KEY>) or changed at run time with jck_tune("<key>", value) - which is what lets one process A/B two
+// variants on the same device and lets a test force a variant at a small shape.
+// ---------------------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int g_igemm_dma = env_int("JCK_IGEMM_DMA", 1);        // LDS-DMA gather-GEMM for bf16 tiles
+static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised 128x64 tiles when < 512 tiles of 128x128
+static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
+static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
+static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
+static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
+static int g_wgrad_small_wgs = env_int("JCK_WGRAD_SMALL_WGS", 512);
+static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
+static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
+static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
+extern "C" int jck_tune(const char* key, int value) {
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256},
+                                              {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
+                                              {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
+                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}};
+  for (auto& t : tab)
+    if (key && !strcmp(t.k, key)) { *t.p = value; return JCK_OK; }
+  JCK_FAIL(JCK_E_ARG, std::string("jck_tune: unknown key ") + (key ? key : "(null)"));
+}
 
 #define DISPATCH_T(prec, CALL)                                  \
   do {                                                          \
@@ -34,7 +61,8 @@ const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "
                                   "igemm<bf16,16,256>",  "igemm<f32,128,128>", "igemm<f32,128,64>",      "igemm<f32,64,128,img>",
                                   "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
                                   "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
-                                  "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>"};
+                                  "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>",
+                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>"};
 struct ProfScope {
   ProfRec r; bool on; hipStream_t st;
   ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
@@ -103,17 +131,17 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
   return JCK_OK;
 }
 
-template <int BCH, int BPIX, int NSTG, bool WS = false>
+template <int BCH, int BPIX, int NSTG, bool WS = false, int NCW = 4>
 static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
-  constexpr int variant = BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
+  constexpr int variant = BPIX == 256 ? 20 : BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
   ProfScope prof(variant, p.flops, st);
-  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true, WS> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS>;
+  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true, WS, NCW> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true, WS>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true, WS, NCW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false, WS>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
@@ -122,9 +150,9 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
   q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
   if (q.stats) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
-    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX>::WPIX);
+    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
   }
-  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(WS ? 512 : 256), LDSB, st, q);
+  hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(WS ? (NCW + 4) * 64 : 256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -135,12 +163,19 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   // which hide each other's load latency): 128x128 tiles while that still gives >= 512 workgroups, else 128x64.
   // Measured on MI355X at B=256 (tests/_micro.py, us): down2 36.2 -> 29.7, down3 43.0 -> 30.3, down4 65.8 -> 40.3,
   // up2 47.2 -> 30.8, up3 34.5 -> 28.8; 3-4 stages at one workgroup per CU are slower.  JCK_IGEMM_DMA=0 disables.
-  static const int use_dma = getenv("JCK_IGEMM_DMA") ? atoi(getenv("JCK_IGEMM_DMA")) : 1;
+  const int use_dma = g_igemm_dma;
   if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && p.ksplit <= 1 && !p.rows_are_phases) {
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
     // wave-specialised variant for the launches that would run 128x64 tiles (< 512 tiles of 128x128: one or two workgroups
     // per CU); JCK_IGEMM_WS=0 disables.  128x128 WS (one workgroup per CU) and WS for the 64-channel tile measured slower.
-    static const int ws_mode = getenv("JCK_IGEMM_WS") ? atoi(getenv("JCK_IGEMM_WS")) : 1;
+    const int ws_mode = g_igemm_ws;
+    // 128 x 256 tiles (8 consumer + 4 loader waves, one workgroup per CU) when that still gives about one tile per CU and a
+    // tile cannot straddle two BatchNorm groups: groups are multiples of 8 images, so 8 * OH*OW must be a multiple of 256.
+    // JCK_IGEMM_256 = minimum number of such tiles (0 disables).
+    const int min256 = g_igemm_256;
+    const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
+    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && p.logOHW >= 5 && p.M % 256 == 0)
+      return launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
     if (ws_mode) return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
     return launch_igemm_dma<128, 64, 2>(p, nch_pad, phases, st, slots);
@@ -195,7 +230,7 @@ extern "C" size_t jck_stats_floats(long long pixels, int C, int nyrep) {
 extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)elems * (prec == JCK_PREC_F32 ? 4 : 2); }
 
 // image-side layers on the streaming kernels of thin.hpp (bf16, 64 channels on the wide side, row length % 16 == 0)
-static const int g_use_thin = getenv("JCK_THIN") ? atoi(getenv("JCK_THIN")) : 1;
+#define g_use_thin g_thin
 #define IMG_GPW 8
 static int launch_img_down(const void* x, const void* w, void* out, float* stats, int* slots, int N, int Hb, int Wb, double flops,
                            hipStream_t st, const void* bn_y = nullptr, const float* bn_aux = nullptr, float bn_slope = 0.f,
@@ -343,17 +378,18 @@ extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, flo
 // ---------------------------------------------------------------------------------------------------------
 struct WgradPlan { int BG, BS, gx, gy, Z, mchunk, CsRows, ncols; size_t ws; };
 
-static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs) {
+// wide: 256-column gathered tile of the LDS-DMA kernel (bf16, Cs % 128 == 0, ncols % 256 == 0); JCK_WGRAD_GT=1 disables
+static bool wgrad_wide_shape(int ncols, int Cs) { return g_wgrad_gt == 2 && ncols % 256 == 0 && Cs % 128 == 0; }
+static WgradPlan plan_wgrad(long long Mtot, int ncols, int Cs, bool wide = false) {
   WgradPlan pl;
   pl.ncols = ncols;
-  pl.BG = (ncols % 128 == 0) ? 128 : 64;
+  pl.BG = wide ? 256 : (ncols % 128 == 0) ? 128 : 64;
   pl.BS = (Cs >= 128) ? 128 : 64;
   pl.gx = cdiv(ncols, pl.BG);
   pl.gy = cdiv(Cs, pl.BS);
   pl.CsRows = pl.gy * pl.BS;
   const int tiles = pl.gx * pl.gy;
-  static const int target = getenv("JCK_WGRAD_WGS") ? atoi(getenv("JCK_WGRAD_WGS")) : 256;
-  static const int target_small = getenv("JCK_WGRAD_SMALL_WGS") ? atoi(getenv("JCK_WGRAD_SMALL_WGS")) : 512;
+  const int target = g_wgrad_wgs, target_small = g_wgrad_small_wgs;
   long long Z = std::max(1, (tiles >= 4 ? target : target_small) / tiles);
   const long long maxZ = std::max(1ll, Mtot / (WG_BKP * 4));
   Z = std::min(Z, maxZ);
@@ -384,36 +420,37 @@ static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t
 // LDS-DMA weight gradient: wave-specialised (4 loader + 4 consumer waves, 3 stages = 96 KB) by default; JCK_WGRAD_WS=0 selects
 // the 4-wave, 2-stage form (48.4 vs 33.7 us at B=256 on the isolated product; 3-4 stages or 8 symmetric waves: within 7 %).
 // JCK_WGRAD_STAMP=1 (development) launches the instrumented twin read back by jck_debug_wgrad_stamps.
-template <int NSTG, bool STAMP, bool WS>
+template <int NSTG, bool STAMP, bool WS, int GT = 1>
 static int launch_wgrad_dma_t(const WgradParams& q, int grid, hipStream_t st) {
-  constexpr int LDSB = NSTG * 2 * WGD_BKP * 256;
+  constexpr int LDSB = NSTG * (GT + 1) * WGD_BKP * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, 4, STAMP, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, 4, STAMP, WS>), dim3(grid), dim3(WS ? 512 : 256), LDSB, st, q);
+  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT>), dim3(grid), dim3(WS ? (4 + 4 * GT) * 64 : 256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
 static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-  ProfScope prof(10, p.flops, st);
+  ProfScope prof(pl.BG == 256 ? 21 : 10, p.flops, st);
   WgradParams q = p;
   q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
   const int grid = pl.gx * pl.gy * pl.Z;
-  static const int stamp = getenv("JCK_WGRAD_STAMP") ? atoi(getenv("JCK_WGRAD_STAMP")) : 0;
-  static const int wsp = getenv("JCK_WGRAD_WS") ? atoi(getenv("JCK_WGRAD_WS")) : 1;
+  const int stamp = g_wgrad_stamp, wsp = g_wgrad_ws;
+  if (pl.BG == 256) return launch_wgrad_dma_t<3, false, true, 2>(q, grid, st);
   if (wsp) return stamp ? launch_wgrad_dma_t<3, true, true>(q, grid, st) : launch_wgrad_dma_t<3, false, true>(q, grid, st);
   return stamp ? launch_wgrad_dma_t<2, true, false>(q, grid, st) : launch_wgrad_dma_t<2, false, false>(q, grid, st);
 }
 
 template <class P>
 static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, hipStream_t st) {
-  static const int use_dma = getenv("JCK_WGRAD_DMA") ? atoi(getenv("JCK_WGRAD_DMA")) : 1;
-  if (use_dma && !P::IS_F32 && pl.BG == 128 && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
+  const int use_dma = g_wgrad_dma;
+  if (use_dma && !P::IS_F32 && (pl.BG == 128 || pl.BG == 256) && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
       pl.mchunk % WGD_BKP == 0 && p.logOW <= 6 &&
       ((1 << p.logOHW) <= WGD_BKP || p.H == p.sy * ((1 << p.logOHW) >> p.logOW)))     // constant 64-pixel address step (wgrad.hpp)
     return launch_wgrad_dma(p, pl, st);
+  if (pl.BG == 256) JCK_FAIL(JCK_E_ARG, "wgrad: the 256-column plan is for the LDS-DMA kernel only");
   if (pl.BG == 128 && pl.BS == 128 && nsub == 1) return launch_wgrad_t<P, 128, 128, 1>(p, pl, st);
   if (pl.BG == 128 && pl.BS == 64 && nsub == 1) return launch_wgrad_t<P, 128, 64, 1>(p, pl, st);
   if (pl.BG == 64 && pl.BS == 64 && nsub == 2) return launch_wgrad_t<P, 64, 64, 2>(p, pl, st);
@@ -445,8 +482,16 @@ static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, in
   return JCK_OK;
 }
 
+// the 256-column plan applies when the launch takes the LDS-DMA kernel (bf16, >= 64 gathered channels, 128-row S tiles)
+static bool conv_wgrad_wide(int prec, int cbp, int Cs) {
+  return g_wgrad_dma && prec == JCK_PREC_BF16 && cbp >= 64 && wgrad_wide_shape(16 * cbp, Cs);
+}
 extern "C" size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs) {
-  return plan_wgrad((long long)N * (Hb / 2) * (Wb / 2), 16 * jck_pad_chan(Cb), Cs).ws;
+  const long long M = (long long)N * (Hb / 2) * (Wb / 2);
+  const int cbp = jck_pad_chan(Cb);
+  // the larger of the two plans, whatever the knobs say right now (a workspace outlives a jck_tune call)
+  const bool wide_shape = cbp >= 64 && (16 * cbp) % 256 == 0 && Cs % 128 == 0;
+  return std::max(plan_wgrad(M, 16 * cbp, Cs).ws, wide_shape ? plan_wgrad(M, 16 * cbp, Cs, true).ws : (size_t)0);
 }
 
 extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes,
@@ -458,7 +503,7 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
   p.sside = small_side; p.big = big_side; p.Mtot = N * OH * OW; p.CsStride = Cs; p.logCb = ilog2(cbp);
   p.H = Hb; p.W = Wb; p.logOW = ilog2(OW); p.logOHW = ilog2(OH * OW); p.sy = p.sx = 2; p.ntaps = 16;
   for (int t = 0; t < 16; ++t) { p.dy[t] = (signed char)(t / 4 - 1); p.dx[t] = (signed char)(t % 4 - 1); }
-  const WgradPlan pl = plan_wgrad(p.Mtot, 16 * cbp, Cs);
+  const WgradPlan pl = plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
   p.flops = 2.0 * p.Mtot * Cs * 16.0 * Cb;
   int rc = run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
   if (rc) return rc;
@@ -552,12 +597,10 @@ extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float s
 }
 
 extern "C" size_t jck_bn_bwd_ws_floats(int C) { return (size_t)(2 + 2 * BN_BWD_MAX_BLOCKS) * C; }
-// workgroups of the backward reduction: BN_BWD_UNR rows per thread and pass, at least two passes per thread, ~2048 workgroups
-// (8 per CU) over all groups - the kernel is HBM-bound and needs >= 64 KB of loads in flight per CU
+// workgroups of the backward reduction (see bn_bwd_reduce_kernel for the measurement behind the cap)
 static int bn_bwd_blocks(long long rows, int rstep, int groups) {
-  const long long want = (rows + (long long)rstep * BN_BWD_UNR * 2 - 1) / ((long long)rstep * BN_BWD_UNR * 2);
-  const long long cap = std::min<long long>(BN_BWD_MAX_BLOCKS, std::max(1, 2048 / std::max(1, groups)));
-  return (int)std::max<long long>(1, std::min(want, cap));
+  (void)groups;
+  return (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
 }
 
 extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,

@@ -288,22 +288,28 @@ static __device__ unsigned long long g_wgd_stamps[1024 * 8 * 4];
 // one after the other in each wave's instruction stream, while waiting for data takes 2 %.  With WS waves 4-7 only issue the
 // DMA (two stages ahead) and waves 0-3 only read fragments and feed the MFMA, one loader and one consumer per SIMD, so the
 // two halves of a k-step overlap; one s_barrier per k-step hands a landed stage over and frees the stage read last.
-template <int NSTG, int NW, bool STAMP = false, bool WS = false>
-static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(const WgradParams p) {
-  static_assert(!WS || (NW == 4 && NSTG == 3), "wave specialisation: 4 loader + 4 consumer waves, 3 LDS stages");
-  constexpr int BG = 128, BS = 128, FM = 4, FN = NW == 8 ? 2 : 4;
+// GT (wave-specialised form only): gathered-side tiles of 128 columns per workgroup.  GT = 2 gives a 256 x 128 output tile:
+// 8 consumer waves (4 per gathered tile) + 4 loader waves = 768 threads, three 48 KB stages.  The S tile is filled once for
+// twice the columns, 87 instead of 64 FLOP per filled byte - the kernels are bound by the LDS fill rate (~24 B/clk/CU), so
+// bytes per FLOP is what sets their speed.
+template <int NSTG, int NW, bool STAMP = false, bool WS = false, int GT = 1>
+static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad_dma_kernel(const WgradParams p) {
+  static_assert(!WS || (NW == 4 && NSTG == 3), "wave specialisation: 4 loader + 4*GT consumer waves, 3 LDS stages");
+  static_assert(GT == 1 || (WS && !STAMP && GT == 2), "the 256-column tile exists in the wave-specialised form only");
+  constexpr int BG = 128 * GT, BS = 128, FM = 4, FN = NW == 8 ? 2 : 4;
   constexpr int NQ = 16 / NW;                                        // DMA rounds per operand tile: 4 rows per wave and round
   constexpr int SW = 128 / (NW / 2);                                 // small-side columns per wave: 64 (4 waves) or 32 (8 waves)
   constexpr int ROWB = 256;                                          // bytes per tile row (128 bf16)
   constexpr int TILE_BYTES = WGD_BKP * ROWB;                         // 16 KB per operand tile
-  constexpr int STG_BYTES = 2 * TILE_BYTES;
+  constexpr int STG_BYTES = (GT + 1) * TILE_BYTES;                   // GT gathered tiles, then the S tile
+  constexpr int NCW = WS ? 4 * GT : NW;                              // consumer waves
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* lds = smem_raw;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_raw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = WS ? (wave_raw & 3) : wave_raw;                   // index inside the role (loader / consumer)
-  const bool loader = WS && wave_raw >= 4;
+  const bool loader = WS && wave_raw >= NCW;
+  const int wave = loader ? wave_raw - NCW : wave_raw;               // index inside the role (loader / consumer)
   // XCD-aware order (workgroup id % 8 = XCD, each with its own 4 MB L2): every XCD takes a contiguous run of logical tiles,
   // column tile fastest, then row tile, then pixel chunk - the tiles of one pixel chunk read the same rows of both operands
   // (other taps / channel chunks), so a chunk's 1.5-4.5 MB working set is fetched into ONE L2 instead of all eight
@@ -323,12 +329,6 @@ static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(co
 
   // this lane's place inside a wave-instruction: 4 rows x 16 chunks
   const int r4 = lane >> 4, pc = lane & 15;
-  // the tile's first tap and (when Cb == 64) the next one
-  const int t_base = g0 >> p.logCb;
-  const int cb_base = g0 & (Cb - 1);
-  const int tA = min(t_base, p.ntaps - 1), tB = min(t_base + 1, p.ntaps - 1);
-  const int dyA = p.dy[tA], dxA = p.dx[tA], dyB = p.dy[tB], dxB = p.dx[tB];
-  const bool tvA = t_base < p.ntaps, tvB = t_base + 1 < p.ntaps;
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -341,9 +341,9 @@ static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(co
   const unsigned binc = (unsigned)((small_img ? (WGD_BKP / OHW) * p.H * p.W : (WGD_BKP / OW) * p.sy * p.W) << p.logCb) * 2u;
   const unsigned sinc = (unsigned)(WGD_BKP * p.CsStride) * 2u;
   const int doy = small_img ? 0 : WGD_BKP / OW;
-  unsigned boff[NQ], soff[NQ];
-  int oyq[NQ], mq[NQ], dyq[NQ];
-  bool bokx[NQ], sokc[NQ];
+  unsigned boff[GT][NQ], soff[NQ];
+  int oyq[NQ], mq[NQ], dyq[GT][NQ];
+  bool bokx[GT][NQ], sokc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int row = q * (4 * NW) + wave * 4 + r4;                      // 0..63 inside the tile
@@ -352,35 +352,48 @@ static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(co
     const int n = m >> p.logOHW;
     const int rem = m & (OHW - 1);
     const int oy = rem >> p.logOW, ox = rem & (OW - 1);
-    // gathered side: column g0 + lc*8 -> (tap, cb)
-    const int col = cb_base + lc * 8;
-    const bool second = col >= Cb;                                     // only when Cb == 64
-    const int dyv = second ? dyB : dyA, dxv = second ? dxB : dxA;
-    const bool tv = second ? tvB : tvA;
-    const int cb = second ? col - Cb : col;
-    const int ix = ox * p.sx + dxv;
-    boff[q] = (unsigned)(((((n * p.H + oy * p.sy + dyv) * p.W + ix) << p.logCb) + cb) * 2);
-    bokx[q] = tv && (unsigned)ix < (unsigned)p.W;
-    oyq[q] = oy; dyq[q] = dyv; mq[q] = m;
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      // gathered side: column g0 + 128*g + lc*8 -> (tap, cb); a 128-column tile spans at most two taps (Cb >= 64)
+      const int gcol0 = g0 + 128 * g;
+      const int t_base = gcol0 >> p.logCb;
+      const int col = (gcol0 & (Cb - 1)) + lc * 8;
+      const bool second = col >= Cb;                                   // only when Cb == 64
+      const int t = t_base + (second ? 1 : 0);
+      const bool tv = t < p.ntaps;
+      const int tc = min(t, p.ntaps - 1);
+      const int dyv = p.dy[tc], dxv = p.dx[tc];
+      const int cb = second ? col - Cb : col;
+      const int ix = ox * p.sx + dxv;
+      boff[g][q] = (unsigned)(((((n * p.H + oy * p.sy + dyv) * p.W + ix) << p.logCb) + cb) * 2);
+      bokx[g][q] = tv && (unsigned)ix < (unsigned)p.W;
+      dyq[g][q] = dyv;
+    }
+    oyq[q] = oy; mq[q] = m;
     soff[q] = (unsigned)((m * p.CsStride + s0 + lc * 8) * 2);
     sokc[q] = s0 + lc * 8 < p.CsStride;
   }
   auto issue = [&](int stage) {
     unsigned char* gt = lds + stage * STG_BYTES;
-    unsigned char* st = gt + TILE_BYTES;
+    unsigned char* st = gt + GT * TILE_BYTES;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool rok = mq[q] < mz1;
-      const bool ok = rok && bokx[q] && (unsigned)(oyq[q] * p.sy + dyq[q]) < (unsigned)p.H;
-      const unsigned char* gsrc = ok ? bigb + boff[q] : zp;
-      __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(gt + (q * (4 * NW) + wave * 4) * ROWB), 16, 0, 0);
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+        const bool ok = rok && bokx[g][q] && (unsigned)(oyq[q] * p.sy + dyq[g][q]) < (unsigned)p.H;
+        const unsigned char* gsrc = ok ? bigb + boff[g][q] : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)(gt + g * TILE_BYTES + (q * (4 * NW) + wave * 4) * ROWB), 16, 0, 0);
+        boff[g][q] += binc;
+      }
       const unsigned char* ssrc = (rok && sokc[q]) ? sb_ + soff[q] : zp;
       __builtin_amdgcn_global_load_lds((gptr_t)ssrc, (lptr_t)(st + (q * (4 * NW) + wave * 4) * ROWB), 16, 0, 0);
-      boff[q] += binc; soff[q] += sinc; mq[q] += WGD_BKP;
+      soff[q] += sinc; mq[q] += WGD_BKP;
       oyq[q] = (oyq[q] + doy) & (OH - 1);
     }
   };
 
+  // consumer wave -> 64 x SW part of the output tile: wg = 64-column block of the gathered side (GT*2 of them), ws = S part
   const int wg = NW == 8 ? wave >> 2 : wave >> 1, ws = NW == 8 ? wave & 3 : wave & 1;
   f32x4 acc[FM][FN];
 #pragma unroll
@@ -397,15 +410,15 @@ static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(co
     return reinterpret_cast<const bf16_t*>(tile + row * ROWB + ((chunk ^ f) << 4) + ((il & 1) << 3));
   };
   auto compute = [&](int stage) {
-    const unsigned char* gt = lds + stage * STG_BYTES;
-    const unsigned char* st = gt + TILE_BYTES;
+    const unsigned char* gt = lds + stage * STG_BYTES + (wg >> 1) * TILE_BYTES;      // this wave's gathered tile
+    const unsigned char* st = lds + stage * STG_BYTES + GT * TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < WGD_BKP / 32; ++kk) {
       const int row = kk * 32 + (lane >> 4) * 8 + (il >> 2);
       bf16x8 a[FM], b[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int c0 = wg * 64 + i * 16;
+        const int c0 = (wg & 1) * 64 + i * 16;
         a[i] = join_tr(lds_tr4(tr_addr(gt, row, c0)), lds_tr4(tr_addr(gt, row + 4, c0)));
       }
 #pragma unroll
@@ -432,7 +445,9 @@ static __global__ __launch_bounds__(WS ? 512 : NW * 64) void wgrad_dma_kernel(co
       int slot = 2;
       for (int k = 0; k < nk; ++k) {
         if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // stage k has landed (this wave's pieces)
+        // stage k has landed (this wave's pieces): (GT + 1) * NQ = 8 or 12 younger pieces may stay in flight
+        if constexpr (GT == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // consumers may read stage k; stage k-1 is free
         if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tw += t1 - t0; t0 = t1; }
         issue(slot);                                                  // stage k+2 (past the end: zero page, never read)

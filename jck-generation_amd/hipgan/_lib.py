@@ -96,6 +96,7 @@ PROTOS = {
     "jck_engine_tensor": (vp, [vp, C.c_char_p, C.POINTER(i64)]),
     "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),
     "jck_debug_wgrad_stamps": (i32, [vp, i32]),
+    "jck_tune": (i32, [C.c_char_p, i32]),
     "jck_prof_enable": (i32, [i32]),
     "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
 }

@@ -13,20 +13,26 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, world, group=None):
+    def __init__(self, world, group=None, force=False):
+        """force: issue the collectives even for world == 1 (tests: a one-rank RCCL group runs the real ProcessGroupNCCL
+        stream path, and SUM over one rank must leave every bit unchanged)."""
         self.world = world
         self.group = group
+        self.force = force
         self._comm = None
 
     def start(self, flat, early=None):
         """All-reduce (SUM) of a flat gradient arena; returns a callable that makes the current stream wait for it.
         early = (offset, wait_on): flat[offset:] is already final once `wait_on(stream_handle)` has made a stream wait for
         the engine's bucket event - that slice is reduced on a side stream at once, under the rest of the backward pass,
-        and only flat[:offset] waits for the end of the phase (JCK_DDP_BUCKETS=0: one all-reduce of the whole arena)."""
-        if self.world == 1:
+        and only flat[:offset] waits for the end of the phase.  EXPERIMENTAL, off by default (JCK_DDP_BUCKETS=1 enables):
+        the ordering of the two collectives on ProcessGroupNCCL's stream is exercised by tests/test_ddp_gpu.py through a
+        world-size-1 RCCL group only - no run on two or more devices has validated it yet (no multi-GPU node was available
+        to the build)."""
+        if self.world == 1 and not self.force:
             return None
         works = []
-        if early is not None and os.environ.get("JCK_DDP_BUCKETS", "1") != "0":
+        if early is not None and os.environ.get("JCK_DDP_BUCKETS", "0") == "1":
             off, wait_on = early
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=flat.device)

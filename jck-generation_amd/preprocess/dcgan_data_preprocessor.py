@@ -103,6 +103,11 @@ class DCGANDataPreprocessor:
             x = torch.from_numpy(np.asarray(d["data"], dtype=np.uint8).reshape(-1, 3, 32, 32))
             self._logger.debug(f"CIFAR-100 loaded from {path}: {tuple(x.shape)}")
             return x, [int(t) for t in d["fine_labels"]]
+        if synthetic_size is None and os.environ.get("JCKGAN_SYNTHETIC", "0") != "1":
+            # a training run on random pixels must be asked for: silently writing checkpoints of a model trained on noise
+            # because a path was mistyped helps nobody (the reference downloads CIFAR-100; there is no network here)
+            raise FileNotFoundError(f"no local CIFAR-100 under {CIFAR_DIR} (expected the pickle `train` of cifar-100-python); "
+                                    f"set JCKGAN_SYNTHETIC=1 to train on seeded synthetic 32x32 images instead")
         n = synthetic_size or 50000
         g = torch.Generator().manual_seed(2024)
         self._logger.warning(f"no local CIFAR-100 under {CIFAR_DIR}: using {n} seeded synthetic 32x32 images")

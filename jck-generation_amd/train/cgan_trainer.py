@@ -54,6 +54,12 @@ class CGANTrainer(DCGANTrainer):
             self.engine.mark_weights_changed()
         self._tail_engines = {}
         self.reducer = GradReducer(self.world) if self.world > 1 else None
+        # per-rank noise stream in data-parallel runs (every rank is seeded alike by main.py; see DCGANTrainer)
+        self.noise_gen = self.host_gen = None
+        if self.world > 1:
+            from change_randomseed import RANDOMSEED
+            self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
+            self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.criterion = nn.BCELoss()
@@ -158,24 +164,27 @@ class CGANTrainer(DCGANTrainer):
         self.logger.debug("train start")
         iters = 0
         for epoch in range(self.epoch):
+            if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+                loader.sampler.set_epoch(epoch)                   # host-data path: a new shuffle / shard every epoch
             for i, data in enumerate(loader):
                 real = data[0] if isinstance(data[0], DeviceBatch) else data[0].to(dev, torch.float32, non_blocking=True).contiguous()
                 labels = data[1].to(dev, torch.int64, non_blocking=True).contiguous()
                 b = real.size(0)
                 eng = self._engine_for(b)
                 if self.host_rng:       # CPU generator in the reference's order (:181,183[dropout],189,192,194,115,118,209)
-                    keep = lambda: torch.empty(b, 256).bernoulli_(0.75)
-                    noise = {"n1": torch.randn(b, 3, 64, 64)}
+                    hg = self.host_gen
+                    keep = lambda: torch.empty(b, 256).bernoulli_(0.75, generator=hg)
+                    noise = {"n1": torch.randn(b, 3, 64, 64, generator=hg)}
                     noise["m1"] = keep()
-                    noise["z"] = torch.randn(b, 100, 1, 1)
-                    noise["n2"] = torch.randn(b, 3, 64, 64)
+                    noise["z"] = torch.randn(b, 100, 1, 1, generator=hg)
+                    noise["n2"] = torch.randn(b, 3, 64, 64, generator=hg)
                     noise["m2"] = keep()
-                    noise["alpha"] = torch.rand(b, 1, 1, 1)
+                    noise["alpha"] = torch.rand(b, 1, 1, 1, generator=hg)
                     noise["m3"] = keep()
                     noise["m4"] = keep()
                     noise["labels"] = labels
                 else:
-                    noise = eng.draw_noise(labels=labels)
+                    noise = eng.draw_noise(self.noise_gen, labels=labels)
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:

@@ -126,6 +126,14 @@ class DCGANTrainer(Trainer):
             self.engine.mark_weights_changed()
         self._tail_engines = {}
         self.reducer = GradReducer(self.world) if self.world > 1 else None
+        # data parallel: main.py seeds every rank alike (identical initial weights), so the NOISE needs its own per-rank stream -
+        # otherwise every replica draws the same z / instance noise / alpha, generates the same fake batch, and the all-reduce
+        # averages N identical gradients (effective batch B instead of N*B for G and for the fake half of D)
+        self.noise_gen = self.host_gen = None
+        if self.world > 1:
+            from change_randomseed import RANDOMSEED
+            self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
+            self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
 
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
@@ -224,14 +232,18 @@ class DCGANTrainer(Trainer):
         self.logger.debug("train start")
         iters = 0
         for epoch in range(self.epoch):
+            if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+                loader.sampler.set_epoch(epoch)                   # host-data path: a new shuffle / shard every epoch
             for i, data in enumerate(loader):
                 real = data[0] if isinstance(data[0], DeviceBatch) else data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
                 eng = self._engine_for(real.size(0))
                 noise = None
                 if self.host_rng:           # reference order: train/dcgan_trainer.py:160,168,171,111
-                    b = real.size(0)
-                    noise = {"n1": torch.randn(b, 3, 64, 64), "z": torch.randn(b, 100, 1, 1), "n2": torch.randn(b, 3, 64, 64),
-                             "alpha": torch.rand(b, 1, 1, 1)}
+                    b, hg = real.size(0), self.host_gen
+                    noise = {"n1": torch.randn(b, 3, 64, 64, generator=hg), "z": torch.randn(b, 100, 1, 1, generator=hg),
+                             "n2": torch.randn(b, 3, 64, 64, generator=hg), "alpha": torch.rand(b, 1, 1, 1, generator=hg)}
+                elif self.noise_gen is not None:
+                    noise = eng.draw_noise(self.noise_gen)
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:

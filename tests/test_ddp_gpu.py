@@ -1,5 +1,9 @@
-"""Two engine replicas as two processes on ONE GPU (gloo carries the CUDA tensors; RCCL needs one device per rank and is
-exercised by bench.py on the 8-GPU node): the native step with gradient exchange reproduces the N-replica CPU oracle."""
+"""Two engine replicas as two processes on ONE GPU (gloo carries the CUDA tensors; RCCL needs one device per rank): the
+native step with gradient exchange reproduces the N-replica CPU oracle.  RCCL itself runs here through a ONE-rank "nccl"
+process group (test_rccl_world1_*): that is the real ProcessGroupNCCL stream path - the collectives are enqueued on RCCL's
+stream behind the issuing stream, the early bucket from a side stream - and SUM over one rank must leave every bit unchanged.
+No run on two or more devices has happened yet (no multi-GPU node was available to the build; the driver's SCALE run is the
+first)."""
 import os
 import sys
 
@@ -22,6 +26,7 @@ def _worker(rank, world, port, q, steps, B):
     for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["JCK_DDP_BUCKETS"] = "1"            # experimental early bucket (off by default): keep it under test
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hipgan.dist import GradReducer
     from hipgan.engine import DcganEngine
@@ -89,3 +94,105 @@ def test_two_replicas_match_ddp_oracle(B):
     for k, v in got[0][1].items():
         if v.dtype == torch.float32 and "running" not in k:
             assert torch.equal(v, got[1][1][k]), k          # replicas in lock-step
+
+
+def _trainer_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import argparse
+    import tempfile
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.chdir(tempfile.mkdtemp())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import main          # noqa: F401  (seeds every rank with RANDOMSEED, as `python main.py` does)
+    from model import DCGAN
+    from preprocess.dcgan_data_preprocessor import DCGANDataPreprocessor
+    from train.dcgan_trainer import DCGANTrainer
+    args = argparse.Namespace(epoch=1, max_learning_rate=2e-4, model_path="t", log_file=0, save_path="save", batch_size=8, num_worker=0)
+    pre = DCGANDataPreprocessor(args, synthetic_size=32)
+    pre.transform_data()
+    tr = DCGANTrainer(args, DCGAN.Generator(), DCGAN.Discriminator(), pre, prec="f32")
+    w0 = float(tr.engine.arenas["g_params"].double().sum())
+    nz = tr.engine.draw_noise(tr.noise_gen)
+    zsum, asum = float(nz["z"].double().sum()), float(nz["alpha"].double().sum())
+    tr.train()                                     # 2 iterations per rank (32 images / 2 ranks / batch 8), gradients exchanged
+    w1 = float(tr.engine.arenas["g_params"].double().sum())
+    q.put((rank, w0, zsum, asum, w1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_draws_its_own_noise_per_rank():
+    """main.py seeds every rank alike (identical initial weights); the trainer must still give every rank its own noise
+    stream, or all replicas generate the same fake batch and the all-reduce averages N identical gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0]                              # same initial weights
+    assert got[0][1] != got[1][1] and got[0][2] != got[1][2]   # different z and alpha
+    assert got[0][3] == got[1][3] and got[0][3] != got[0][0]   # replicas stay in lock-step and did move
+
+
+_RCCL1 = r"""
+import os, sys, torch, torch.distributed as dist
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+os.environ["JCK_DDP_BUCKETS"] = "1"                       # the early-bucket path is what this test is about
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from hipgan.dist import GradReducer
+from hipgan.engine import DcganEngine
+from oracle.gan_oracle import build_params
+from util import synth_images
+import bf16_error as be
+B = 16
+torch.manual_seed(12345)
+g, d = build_params("dcgan")
+imgs = synth_images(B * 3)
+def run(reduce, pipeline):
+    eng = DcganEngine(batch=B, prec="bf16", device="cuda:0")
+    eng.load_state(g, d)
+    red = GradReducer(1, force=True) if reduce else None
+    for s in range(3):
+        nz = {k: v.cuda() for k, v in be.noise_for("dcgan", B, 70 + s).items()}
+        kw = dict(reduce_d=red.start, reduce_g=red.start) if red else {}
+        eng.step_async(imgs[s * B:(s + 1) * B].cuda(), nz, 2e-4, pipeline=pipeline, **kw)
+    eng.join()
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in eng.arenas.items()}, eng.scalars()
+base, sb = run(False, False)
+for pipe in (False, True):
+    ref, sr = (base, sb) if not pipe else run(False, True)
+    got, sg = run(True, pipe)
+    assert sg == sr, (pipe, sg, sr)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (pipe, k)
+dist.destroy_process_group()
+print("RCCL1-OK")
+"""
+
+
+def test_rccl_world1_reduce_paths_leave_every_bit_unchanged(tmp_path):
+    """GradReducer.start(flat, early=...) and the full step_async(reduce_d=, reduce_g=) through a ONE-rank RCCL group, with
+    and without the cross-step pipeline: the results must equal the no-reduce step bit for bit (SUM over one rank is the
+    identity, the step has no float atomics) - which they only do if every collective is ordered behind the gradient
+    kernels it reduces and ahead of the optimiser kernels that read it."""
+    import subprocess
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL1)
+    port = str(29500 + ((os.getpid() + 13) % 2000))
+    r = subprocess.run([sys.executable, str(script), ROOT, port], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL1-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -134,3 +134,16 @@ def test_logger_and_time_format(tmp_path):
     import logging
     logging.getLogger("main").handlers.clear()
     MainLogger._instance, MainLogger._initialized = None, False
+
+
+def test_synthetic_data_must_be_asked_for(tmp_path, monkeypatch):
+    """No local CIFAR-100 and no explicit opt-in: the preprocessor refuses instead of silently training on random pixels."""
+    import argparse
+    import preprocess.dcgan_data_preprocessor as P
+    monkeypatch.setattr(P, "CIFAR_DIR", str(tmp_path / "nowhere"))
+    monkeypatch.delenv("JCKGAN_SYNTHETIC", raising=False)
+    args = argparse.Namespace(batch_size=4, num_worker=0, log_file=0, save_path=str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        P.DCGANDataPreprocessor(args)
+    monkeypatch.setenv("JCKGAN_SYNTHETIC", "1")
+    assert P.DCGANDataPreprocessor(args).images.shape[1:] == (3, 32, 32)

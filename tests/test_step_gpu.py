@@ -239,3 +239,14 @@ def test_batched_schedule_with_a_non_power_of_two_batch():
             assert _rel(got[k], ref[k]) < 1e-3, (s, k, got[k], ref[k])
     ref, got, dgr, ggr = out[-1]
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
+
+
+def test_per_pass_schedule_at_the_8gpu_tail_batch():
+    """Batch 106 = what every rank of an 8-GPU run gets as the last batch of a CIFAR epoch (6250 % 256): not a multiple of 8,
+    so the per-pass schedule with stream overlap runs, with tiles that end inside an image."""
+    orc, eng, out = _run(106, 1, "f32")
+    ref, got, dgr, ggr = out[0]
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(got[k], ref[k]) < 1e-3, (k, got[k], ref[k])
+    _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
+    _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
