@@ -7,9 +7,12 @@ reference), 64x64x3 synthetic images, batch 256 per GPU, on the MI355X-native HI
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU; data parallel = replicate, shard the batch, all-reduce D and G gradients with RCCL
-(torch.distributed "nccl") - D's all-reduce overlaps the gradient-penalty pass.  Rank 0 prints ONE JSON line.
+(torch.distributed "nccl").  Rank 0 prints ONE JSON line.
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM, including the RNG draws
-(instance noise x2, z, GP alpha), four D passes, one G pass, five backward chains, two Adam steps.
+(instance noise x2, z, GP alpha), four D passes, one G pass, five backward chains, two Adam steps.  The step is replayed
+from captured hipGraphs (one host call per step segment; JCK_GRAPH=0 launches every kernel from the host instead).
+With one GPU the same line carries `secondary.cgan`: BASELINE.json configs[3] (CGAN, 10-class labels, batch 256, the
+penalty back-propagated) measured the same way in the same process.
 """
 import argparse
 import json
@@ -39,56 +42,193 @@ def step_flops_per_image(dead_wgrad=False):
     return 2 * mac
 
 
+# profiler variant label (csrc/ops.hip PROF_NAMES) -> substring of the kernel symbol rocprofv3 reports
+_SYMBOL = {"igemm<bf16,128,256>": "igemm_dma_kernel<128, 256,", "igemm<bf16,128,128>": "igemm_dma_kernel<128, 128,",
+           "igemm<bf16,128,64>": "igemm_dma_kernel<128, 64,", "igemm<bf16,64,128>": "igemm_dma_kernel<64, 128,",
+           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>", "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2>",
+           "wgrad<bf16,64,64,img>": "wgrad_kernel<PrecBf16, 64, 64, 2>", "img_down<bf16>": "img_down_kernel", "img_up<bf16>": "img_up_kernel"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/rNN_traffic.json: rocprofv3 --pmc FETCH_SIZE
     and --pmc WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as the gfx950 guide prescribes).  rocprofv3
     cannot run inside the timed process, so the number is read back from the newest committed profile; None if absent."""
     import glob
-    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
+    pat = _SYMBOL.get(kernel)
+    if not files or not pat:
         return None
     with open(files[-1]) as f:
         tr = json.load(f)
-    m = re.match(r"(igemm|wgrad)<(bf16|f32),(\d+),(\d+)(,img)?>", kernel)
-    if not m:
-        return None
-    kind, prec, a, b, img = m.groups()
-    # the profiler's variant label -> the kernel symbol rocprofv3 reports: LDS-DMA variants first (bf16 only), then the
-    # register-staged templates
-    pats = []
-    if prec == "bf16" and not img and (kind == "igemm" or (a, b) == ("128", "128")):
-        pats.append(f"igemm_dma_kernel<{a}, {b}, " if kind == "igemm" else "wgrad_dma_kernel")
-    pats.append(f"{kind}_kernel<{'PrecBf16' if prec == 'bf16' else 'PrecF32'}, {a}, {b}, {2 if img else 1}")
-    for pat in pats:
-      for name, v in tr.items():
+    for name, v in tr.items():
         if pat in name:
-          return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
-                  "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
+            return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
+                    "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
     return None
 
 
-def cpu_baseline(batch, seconds_budget=25.0):
-    """The CPU oracle (a restatement of the reference's step, pinned to it by tests/golden) timed on the host cores."""
+def _host_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job 16
+    of its 128 hardware threads; timing the oracle on all 128 oversubscribes the share and reads 2-3x too slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return n, model
+
+
+def cpu_baseline(batch, seconds_budget=30.0):
+    """The CPU oracle (a restatement of the reference's step, pinned to it by tests/golden) timed on the host cores as
+    BASELINE.md section 3 prescribes: a thread sweep (1, half, all of the CPUs this job may use) picks the thread count, then
+    3 warm-up + up to 10 timed steps at the headline batch with it (bounded by `seconds_budget`)."""
     import torch
     from oracle.gan_oracle import GanOracle
-    torch.manual_seed(0)
-    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+    avail, model = _host_cpus()
     g = torch.Generator().manual_seed(2024)
     real = torch.rand(batch, 3, 64, 64, generator=g) * 2 - 1
-    cores = torch.get_num_threads()
-    orc.step(real)                                       # warm-up (allocator, thread pool)
+    saved = torch.get_num_threads()
+    sweep, small = {}, real[:64]
+    for n in sorted({1, max(1, avail // 2), avail}):
+        torch.set_num_threads(n)
+        torch.manual_seed(0)
+        orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+        orc.step(small)                                  # warm-up (allocator, thread pool)
+        t0 = time.time()
+        k = 0
+        while k < 3 and (k < 1 or time.time() - t0 < 4.0):
+            orc.step(small)
+            k += 1
+        sweep[n] = round(64 * k / (time.time() - t0), 1)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    torch.manual_seed(0)
+    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+    warm = 0
+    t0 = time.time()
+    while warm < 3 and (warm < 1 or time.time() - t0 < seconds_budget / 3):
+        orc.step(real)
+        warm += 1
     t0 = time.time()
     n = 0
-    while True:
+    while n < 10 and (n < 2 or time.time() - t0 < seconds_budget):
         orc.step(real)
         n += 1
-        dt = time.time() - t0
-        if dt > seconds_budget or n >= 12:
-            break
-    return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} full G+D steps at batch {batch} after 1 warm-up ({dt:.1f} s), torch fp32 CPU oracle "
+    dt = time.time() - t0
+    torch.set_num_threads(saved)
+    return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": best, "kind": "port",
+            "s_per_step": round(dt / n, 3), "cpu_model": model, "cpus_available": avail, "cpus_in_machine": os.cpu_count(),
+            "thread_sweep_images_per_sec_batch64": {str(k): v for k, v in sweep.items()},
+            "sample": f"{n} full G+D steps at batch {batch} after {warm} warm-up ({dt:.1f} s) with {best} threads (the fastest of "
+                      f"the sweep at batch 64) on {model}, {avail} CPUs available to the job; torch fp32 CPU oracle "
                       f"(oracle/gan_oracle.py), anomaly detection off"}
+
+
+def measure(a, model, world, rank, dev, dist):
+    """Warm-up, the timed region, the per-launch profile of the MFMA kernels; -> dict (rank 0 fills the roofline)."""
+    import torch
+    from hipgan import lib
+    from hipgan.dist import GradReducer
+    from hipgan.engine import CganEngine, DcganEngine, DeviceBatch
+    from model import CGAN, DCGAN
+    B = a.batch
+    cgan = model == "cgan"
+    M = CGAN if cgan else DCGAN
+    eng = (CganEngine if cgan else DcganEngine)(batch=B, prec=a.prec, device=dev)
+    torch.manual_seed(12345)                            # change_randomseed.py:1 - identical weights on every rank
+    net_g, net_d = M.Generator(), M.Discriminator()
+    net_g.apply(M.weights_init)
+    net_d.apply(M.weights_init)
+    eng.load_state(net_g.state_dict(), net_d.state_dict())
+    gen = torch.Generator(device=dev).manual_seed(2024 + rank)
+    batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    if a.input == "u8":
+        data = (torch.rand(50000, 3, 32, 32, device=dev, generator=gen) * 255).to(torch.uint8)        # CIFAR-sized
+        batches = [DeviceBatch(data, torch.randint(0, 50000, (B,), device=dev, generator=gen)) for _ in range(4)]
+    # CGAN: 10-class synthetic labels as one-hot int64 [B,100] (classes 0-9 of the reference's 100-wide encoding)
+    labels = [torch.nn.functional.one_hot(torch.randint(0, 10, (B,), device=dev, generator=gen), 100).to(torch.int64)
+              for _ in range(4)] if cgan else None
+    red = GradReducer(world) if world > 1 else None
+
+    def one_step(i):
+        # device-side RNG inside the step like the reference: noise=None draws n1 | z | n2, alpha (and the dropout masks)
+        kw = dict(reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world) if red else {}
+        eng.step_async(batches[i % 4], None, 2e-4, generator=gen, labels=labels[i % 4] if cgan else None, **kw)
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(i)
+    t_host = time.perf_counter() - t0                   # host time to enqueue the timed steps (diagnostic)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    scal = eng.scalars()
+    ms = dt / a.steps * 1e3
+    fl = step_flops_per_image() * B
+    if cgan:   # + v-chain (D forward-like + direct wgrads) and the reverse sweep (wgrad + dgrad) of the penalty, + linear1
+        fl += 2 * B * (D_FWD + D_FWD + D_FWD + (D_FWD - D_CONV1))
+    res = {"value": round(world * B * a.steps / dt, 1), "ms_per_step": round(ms, 4),
+           "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4),
+           "launch_mode": "hipGraph replay" if eng.graphs and eng._graph_cache else "eager launches",
+           "losses_last_step": {k: round(v, 5) for k, v in scal.items() if k in ("loss_d", "loss_g", "gp")},
+           "step_mfma": {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                         "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}}
+    if not a.no_roofline:
+        # every rank runs the three extra steps (they contain the gradient all-reduce); rank 0 times its launches with HIP
+        # events on the launch streams - which needs every launch to come from the host, so these steps are not replayed
+        eng.graphs = False
+        torch.cuda.synchronize()
+        if rank == 0:
+            lib.jck_prof_enable(1)
+        for i in range(3):
+            one_step(i)
+        torch.cuda.synchronize()
+    if rank == 0 and not a.no_roofline:
+        import ctypes as C
+        lib.jck_prof_enable(0)
+        cap = 32
+        names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        n = lib.jck_prof_collect(cap, names, cnt, msv, flv)
+        rows = [{"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i],
+                 "ms_per_step": msv[i] / 3, "tflops": flv[i] / (msv[i] * 1e-3) / 1e12} for i in range(n)]
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        if rows:
+            d = rows[0]
+            tr = pmc_traffic(d["kernel"])
+            res["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "traffic": (tr or {}).get("bytes_per_launch"),      # HBM bytes per launch (PMC)
+                               "traffic_detail": tr, "avg_launch_ms": round(d["avg_ms"], 5),
+                               "launches_per_step": d["launches_per_step"],
+                               "method": "HIP events around every launch on the launch stream, 3 extra (eagerly launched) steps "
+                                         "after the timed region"}
+            res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+            res["mfma_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 4)
+    del eng
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -105,6 +245,7 @@ def main():
                          "resident in HBM, Resize/ToTensor/Normalize done inside the step (the training pipeline's form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the CGAN (configs[3]) measurement of the one-GPU run")
     a = ap.parse_args()
 
     import torch
@@ -129,107 +270,30 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from hipgan.engine import CganEngine, DcganEngine
-    from hipgan.dist import GradReducer
-    from hipgan import lib
-    from model import CGAN, DCGAN
-
-    B = a.batch
     dev = torch.device("cuda", local)
+    B = a.batch
     cgan = a.model == "cgan"
-    M = CGAN if cgan else DCGAN
-    eng = (CganEngine if cgan else DcganEngine)(batch=B, prec=a.prec, device=dev)
-    torch.manual_seed(12345)                            # change_randomseed.py:1 - identical weights on every rank
-    net_g, net_d = M.Generator(), M.Discriminator()
-    net_g.apply(M.weights_init)
-    net_d.apply(M.weights_init)
-    eng.load_state(net_g.state_dict(), net_d.state_dict())
-    gen = torch.Generator(device=dev).manual_seed(2024 + rank)
-    batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
-    if a.input == "u8":
-        from hipgan.engine import DeviceBatch
-        data = (torch.rand(50000, 3, 32, 32, device=dev, generator=gen) * 255).to(torch.uint8)        # CIFAR-sized
-        batches = [DeviceBatch(data, torch.randint(0, 50000, (B,), device=dev, generator=gen)) for _ in range(4)]
-    # CGAN: 10-class synthetic labels as one-hot int64 [B,100] (classes 0-9 of the reference's 100-wide encoding)
-    labels = [torch.nn.functional.one_hot(torch.randint(0, 10, (B,), device=dev, generator=gen), 100).to(torch.int64)
-              for _ in range(4)] if cgan else None
-    red = GradReducer(world) if world > 1 else None
-
-    def one_step(i):
-        # device-side RNG, inside the step like the reference
-        noise = eng.draw_noise(gen, labels=labels[i % 4]) if cgan else eng.draw_noise(gen)
-        if red:
-            eng.step_async(batches[i % 4], noise, 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
-        else:
-            eng.step_async(batches[i % 4], noise, 2e-4)
-
-    for i in range(a.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        one_step(i)
-    t_host = time.perf_counter() - t0                   # host time to enqueue the timed steps (diagnostic)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    scal = eng.scalars()
-    ms = dt / a.steps * 1e3
-    value = world * B * a.steps / dt
-
-    out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256" if not cgan else "images/sec (G+D step) CGAN 64x64 bs256", "value": round(value, 1), "unit": "images/sec",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "ms_per_step": round(ms, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": a.prec,
+    res = measure(a, a.model, world, rank, dev, dist)
+    out = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256" if not cgan else "images/sec (G+D step) CGAN 64x64 bs256",
+           "value": res.pop("value"), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "host_enqueue_ms_per_step": res.pop("host_enqueue_ms_per_step"), "ms_per_step": res.pop("ms_per_step"),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.prec,
            "data": "synthetic" if a.input == "tensor" else "synthetic uint8 dataset in HBM, transformed in the step",
            "config": {"workload": (f"DCGAN 64x64x3 synthetic, batch {B} per GPU, full G+D step incl. GP pass, RNG and Adam "
                                    f"(BASELINE.json configs[1]{'/[2]' if world > 1 else ''})") if not cgan else
                                   (f"CGAN 64x64x3, 10-class synthetic one-hot labels, batch {B} per GPU, full step incl. the "
                                    f"back-propagated gradient penalty (BASELINE.json configs[3])"),
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                      "dead_D_wgrad_in_G_phase": "skipped (never observable: zeroed at train/dcgan_trainer.py:155)"},
-           "losses_last_step": {k: round(v, 5) for k, v in scal.items() if k in ("loss_d", "loss_g", "gp")}}
-    fl = step_flops_per_image() * B
-    if cgan:   # + v-chain (D forward-like + direct wgrads) and the reverse sweep (wgrad + dgrad) of the penalty, + linear1
-        fl += 2 * B * (D_FWD + D_FWD + D_FWD + (D_FWD - D_CONV1))
-    out["step_mfma"] = {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
-                        "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
-
-    if not a.no_roofline:
-        # every rank runs the three extra steps (they contain the gradient all-reduce); rank 0 times its launches
-        if rank == 0:
-            lib.jck_prof_enable(1)
-        for i in range(3):
-            one_step(i)
-        torch.cuda.synchronize()
-    if rank == 0 and not a.no_roofline:
-        import ctypes as C
-        lib.jck_prof_enable(0)
-        cap = 32
-        names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
-        n = lib.jck_prof_collect(cap, names, cnt, msv, flv)
-        rows = [{"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i],
-                 "ms_per_step": msv[i] / 3, "tflops": flv[i] / (msv[i] * 1e-3) / 1e12} for i in range(n)]
-        rows.sort(key=lambda r: -r["ms_per_step"])
-        if rows:
-            d = rows[0]
-            out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
-                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                               "traffic": (pmc_traffic(d["kernel"]) or {}).get("bytes_per_launch"),      # HBM bytes per launch (PMC)
-                               "traffic_detail": pmc_traffic(d["kernel"]), "avg_launch_ms": round(d["avg_ms"], 5),
-                               "launches_per_step": d["launches_per_step"],
-                               "method": "HIP events around every launch on the launch stream, 3 extra steps after the timed region"}
-            out["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
-            out["mfma_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 4)
+                      "dead_D_wgrad_in_G_phase": "skipped (never observable: zeroed at train/dcgan_trainer.py:155)"}}
+    out.update(res)
+    if world == 1 and not cgan and not a.no_secondary:
+        # BASELINE.json configs[3] in the same process and the same way, so that its throughput is a driver-run number too
+        sec = measure(a, "cgan", world, rank, dev, dist)
+        sec = {"metric": "images/sec (G+D step) CGAN 64x64 bs256", "unit": "images/sec", "dtype": a.prec,
+               "config": {"workload": f"CGAN 64x64x3, 10-class synthetic one-hot labels, batch {B}, full step incl. the "
+                                      f"back-propagated gradient penalty (BASELINE.json configs[3])"}, **sec}
+        sec.pop("kernels", None)
+        out["secondary"] = {"cgan": sec}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:

@@ -277,6 +277,17 @@ int jck_engine_sample(jck_engine*, const float* z, const int64_t* labels /* fami
 /* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */
 const void* jck_engine_tensor(const jck_engine*, const char* name, long long* numel);
 
+/* Per-step optimiser scalars into device memory (so that a captured graph of the step has no per-step kernel argument), and
+ * hipGraph capture of a sequence of jck_engine_phase calls: begin -> phases on `stream` (not the default stream) -> end
+ * returns an executable graph; launch replays it.  The jck_step_inputs pointers are baked: keep the buffers in place,
+ * refresh their contents, keep one graph per step parity, call jck_engine_set_step before every launch. */
+int jck_engine_set_step(jck_engine*, int step, float lr, void* stream);
+int jck_engine_capture_begin(jck_engine*, void* stream);
+int jck_engine_capture_end(jck_engine*, void* stream, void** graph_exec);
+int jck_engine_capture_abort(jck_engine*, void* stream);
+int jck_graph_launch(void* graph_exec, void* stream);
+void jck_graph_destroy(void* graph_exec);
+
 /* Kernel-selection knob (same names as the JCK_<KEY> environment presets, lower case: "igemm_256", "wgrad_gt", ...): lets
  * one process A/B two variants on one device and lets a test force a variant at a small shape.  Unknown key -> JCK_E_ARG. */
 int jck_tune(const char* key, int value);

@@ -138,6 +138,9 @@ struct jck_engine {
   float *acc2, *scal2;                  // acc2: [2 parities][8 rows][acc_ld] per-image scalar table (summed by the step tail)
   int acc_ld = 0;
   float *head_ws, *gp2_ws;              // partial rows of the head weight gradients (deterministic two-stage sums)
+  float* hp2;                           // [2 parities][4]: {step_size, bc2_sqrt} of the optimiser step in flight (jck_engine_set_step)
+  int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases)
+  bool capturing = false;
   float* wg_ws; size_t wg_ws_bytes;
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
@@ -213,6 +216,7 @@ struct jck_engine {
     acc_ld = (B + 63) / 64 * 64;
     acc2 = c.take<float>((size_t)2 * 8 * acc_ld); scal2 = c.take<float>(16);
     acc = acc2; scal_out = scal2;
+    hp2 = c.take<float>(8);
     head_ws = c.take<float>(jck_head_bwd_ws_floats(FEAT));
     gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
     size_t w = 0;
@@ -756,8 +760,13 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
+  // weight gradients beside the dgrad chain on a second stream: +8 % for DCGAN.  CGAN (~280 kernels per step, most of them
+  // small) measured the same with and without it (3.478 vs 3.456 ms eager) and WORSE with it when the step is replayed from a
+  // hipGraph (3.82 ms: a graph with parallel branches costs ~7 us of host time per node and runs slower; the linear graph
+  // costs 0.18 ms per replay) - so CGAN keeps everything on one stream unless JCK_CGAN_SIDE=1.
   static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
-  hipStream_t sA = (e->overlap && wgrad_side) ? e->sA : nullptr;
+  static const bool cgan_side = getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) != 0;
+  hipStream_t sA = (e->overlap && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
   const bool ov_g = e->overlap, ov_gp = e->overlap && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
@@ -887,7 +896,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
       if (e->gp_done && cg) {                         // forward and first backward ran as group 2 of the batched pass
         e->gp_done = false;
-        static const bool cg_side2 = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
+        static const bool cg_side2 = cgan_side;
         JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side2 ? sA : nullptr));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
         return JCK_OK;
@@ -900,7 +909,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
-        static const bool cg_side = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
+        static const bool cg_side = cgan_side;
         JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side ? sA : nullptr));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
       }
@@ -908,7 +917,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_D_STEP: {                                                                      // :180
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
-      JCK_TRY(jck_adam(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
+      if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));   // (eager callers)
+      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 4 * e->parity, st));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
@@ -921,7 +931,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       return JCK_OK;
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
-      JCK_TRY(jck_adam(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, in->lr, 0.5, 0.999, 1e-8, in->step, in->grad_scale, st));
+      if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+      JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 4 * e->parity, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
       {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
         TailJobs t = {};
@@ -941,6 +952,71 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
   }
   JCK_FAIL(JCK_E_ARG, "unknown phase");
+}
+
+// Per-step optimiser scalars (Adam bias corrections of step `step` at learning rate `lr`, computed on the host in double as
+// torch.optim.Adam does) -> device memory of parity step & 1.  Call once per step BEFORE its phases when the phases are
+// replayed from a captured graph (the graph bakes every kernel argument); eager callers may skip it - the optimiser phases
+// then write the scalars themselves.
+extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
+  JCK_TRY(jck_adam_set_step(e->hp2 + 4 * (step & 1), (double)lr, 0.5, 0.999, step, (hipStream_t)stream));
+  e->hp_step[step & 1] = step;
+  return JCK_OK;
+}
+
+// hipGraph capture of phases: begin -> jck_engine_phase(...) x n on the same stream -> end gives an executable graph that
+// replays exactly those launches (incl. the side-stream forks and joins, which become graph dependencies).  Everything a
+// phase reads through jck_step_inputs pointers is baked: the caller keeps those buffers at fixed addresses, refreshes
+// their contents before each launch, keeps one graph per step parity (scalar / BatchNorm-record buffers alternate) and
+// calls jck_engine_set_step first.  `stream` must not be the legacy default stream.
+extern "C" int jck_engine_capture_begin(jck_engine* e, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (!stream) JCK_FAIL(JCK_E_ARG, "cannot capture on the default stream");
+  if (jck_prof_is_on()) JCK_FAIL(JCK_E_ARG, "per-launch profiling (jck_prof_enable) records timing events: not capturable");
+  HIPCHK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  e->capturing = true;
+  return JCK_OK;
+}
+extern "C" int jck_engine_capture_end(jck_engine* e, void* stream, void** graph_exec) {
+  if (!e || !graph_exec) JCK_FAIL(JCK_E_ARG, "null argument");
+  e->capturing = false;
+  hipGraph_t g = nullptr;
+  HIPCHK(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t rc = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (rc != hipSuccess) JCK_FAIL(JCK_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(rc));
+  *graph_exec = ge;
+  return JCK_OK;
+}
+// abandon a capture after a failed phase (the stream leaves capture mode; nothing was executed)
+extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
+  if (e) e->capturing = false;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture((hipStream_t)stream, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  // side streams that joined the broken capture may be left invalidated: replace them
+  if (e && e->overlap) {
+    hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
+    for (auto pp : ss) {
+      if (*pp) (void)hipStreamDestroy(*pp);
+      *pp = nullptr;
+      HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
+    }
+    (void)hipGetLastError();
+  }
+  return JCK_OK;
+}
+extern "C" int jck_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) JCK_FAIL(JCK_E_ARG, "null graph");
+  HIPCHK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return JCK_OK;
+}
+extern "C" void jck_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
 }
 
 // Early gradient bucket of PHASE_D_LOSS (batched schedule): returns 1 and the [offset, offset + numel) range of D's gradient

@@ -524,9 +524,16 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor algorithm, amsgrad=False, weight_decay=0) over a flat arena
 // ------------------------------------------------------------------------------------------------------
+// hp (optional): device float[2] = {step_size, bc2_sqrt} of THIS step, written by adam_hp_kernel before the step is enqueued
+// - the whole-step engine passes its per-step scalars this way so that a captured hipGraph of the step carries no
+// per-step kernel argument; the values are the same host-computed floats either way.
+static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { hp[0] = step_size; hp[1] = bc2_sqrt; }
+}
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float w1 /*1-beta1*/, float beta2, float omb2 /*1-beta2*/,
-                            float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                            float eps, float step_size, float bc2_sqrt, float grad_scale, const float* __restrict__ hp = nullptr) {
+  if (hp) { step_size = hp[0]; bc2_sqrt = hp[1]; }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
     // exp_avg.lerp_(grad, 1-beta1): weight 0.5 takes ATen's "end - (end-start)*(1-w)" branch when w >= 0.5

@@ -78,6 +78,7 @@ struct ProfScope {
   }
 };
 }  // namespace
+bool jck_prof_is_on() { return g_prof_on; }
 extern "C" int jck_prof_enable(int on) {
   g_prof_on = on != 0;
   return JCK_OK;
@@ -804,7 +805,22 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
   const float step_size = (float)(lr / bc1), bc2s = (float)std::sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2s, grad_scale);
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2s, grad_scale, (const float*)nullptr);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+// the same update with {step_size, bc2_sqrt} read from device memory: jck_adam_set_step writes them (same host arithmetic)
+int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, hipStream_t st) {
+  if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
+  const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
+  hipLaunchKernelGGL(adam_hp_kernel, dim3(1), dim3(64), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
+                float grad_scale, const float* hp, hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

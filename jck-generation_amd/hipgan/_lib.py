@@ -97,6 +97,12 @@ PROTOS = {
     "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),
     "jck_debug_wgrad_stamps": (i32, [vp, i32]),
     "jck_tune": (i32, [C.c_char_p, i32]),
+    "jck_engine_set_step": (i32, [vp, i32, f32, vp]),
+    "jck_engine_capture_begin": (i32, [vp, vp]),
+    "jck_engine_capture_end": (i32, [vp, vp, C.POINTER(vp)]),
+    "jck_engine_capture_abort": (i32, [vp, vp]),
+    "jck_graph_launch": (i32, [vp, vp]),
+    "jck_graph_destroy": (None, [vp]),
     "jck_prof_enable": (i32, [i32]),
     "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
 }

@@ -39,6 +39,10 @@ def _layout(family, net):
     return out
 
 
+class _GraphUnavailable(JckError):
+    """Capture of a step segment failed before anything of the step ran: the engine falls back to eager launches."""
+
+
 class DeviceBatch:
     """A training batch as indices into a uint8 image dataset that lives in HBM ([N,3,32,32], the CIFAR pickle layout).
     The step gathers and transforms it on the device (jck_img_prep_u8: the reference's Resize(64) / ToTensor /
@@ -79,6 +83,9 @@ class DcganEngine:
         self.batch = batch
         self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
         self._packed_version = -1
+        # hipGraph replay of the step (JCK_GRAPH=0 disables): one captured graph per (segment, step parity, input kind)
+        self.graphs = os.environ.get("JCK_GRAPH", "1") != "0"
+        self._graph_cache, self._sbuf, self._st, self._eager_steps = {}, None, None, 0
         h = C.c_void_p()
         dll = load_library()
         if dll.jck_engine_create(C.byref(h), self.family, self.prec, batch) != 0:
@@ -117,6 +124,9 @@ class DcganEngine:
 
     def __del__(self):
         try:
+            for ge in getattr(self, "_graph_cache", {}).values():
+                load_library().jck_graph_destroy(ge)
+            self._graph_cache = {}
             if getattr(self, "_h", None):
                 load_library().jck_engine_destroy(self._h)
                 self._h = None
@@ -240,20 +250,30 @@ class DcganEngine:
                 si.drop_mask[i] = ptr(m, B * 256)
         return si, keep
 
-    def draw_noise(self, generator=None, labels=None):
-        """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111)."""
+    def draw_noise(self, generator=None, labels=None, out=None):
+        """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111).  out: the engine's
+        fixed-address input buffers (graph replay) - filled in place with the same draws, no extra copy."""
         B, dev = self.batch, self.device
         # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
         ni, nzz = B * 3 * 64 * 64, B * 100
-        buf = torch.randn(2 * ni + nzz, device=dev, generator=generator)
+        if out is None:
+            buf = torch.randn(2 * ni + nzz, device=dev, generator=generator)
+            alpha = torch.rand(B, 1, 1, 1, device=dev, generator=generator)
+        else:
+            buf = torch.randn(2 * ni + nzz, generator=generator, out=out["nbuf"])
+            alpha = torch.rand(B, 1, 1, 1, generator=generator, out=out["alpha"])
         nz = {"n1": buf[:ni].view(B, 3, 64, 64),
               "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
               "n2": buf[ni + nzz:].view(B, 3, 64, 64),
-              "alpha": torch.rand(B, 1, 1, 1, device=dev, generator=generator)}
+              "alpha": alpha}
         if self.family == 1:
             nz["labels"] = labels
             for i in range(4):          # nn.Dropout(0.25) keep masks of the four D passes (model/CGAN.py:105)
-                nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
+                if out is None:
+                    nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
+                else:
+                    u = torch.rand(B, 256, generator=generator, out=out["u"])
+                    nz[f"m{i + 1}"] = out[f"m{i + 1}"].copy_(u >= 0.25)
         return nz
 
     # ---- cross-step pipeline -------------------------------------------------------------------------------
@@ -265,23 +285,166 @@ class DcganEngine:
         return self._shared["g_stream"]
 
     def join(self):
-        """Makes the current stream wait for a G phase still in flight (call before reading weights, scalars, ...)."""
-        gs = self._shared["g_stream"]
-        if gs is not None:
-            torch.cuda.current_stream().wait_stream(gs)
+        """Makes the current stream wait for engine work still in flight on the engine's own streams - the G phase of the
+        cross-step pipeline, the graph-replay stream (call before reading weights, scalars, ...)."""
+        cur = torch.cuda.current_stream()
+        for key in ("g_stream", "e_stream"):
+            s_ = self._shared.get(key)
+            if s_ is not None and s_ != cur:
+                cur.wait_stream(s_)
 
-    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None):
-        """Enqueues one full step; no host sync.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
+    # ---- hipGraph replay -----------------------------------------------------------------------------------
+    # A step is ~125 (DCGAN) / ~280 (CGAN) kernel launches; replayed from a captured graph the host issues ONE call per
+    # step segment.  A captured graph bakes every kernel argument, so: the step inputs live in fixed-address buffers that are
+    # refilled in place, the Adam bias corrections go through device memory (jck_engine_set_step), and there is one graph
+    # per step parity (the scalar and BatchNorm-record buffers alternate).  All of it runs on the engine's own stream.
+    def _e_stream(self):
+        if self._shared.get("e_stream") is None:
+            self._shared["e_stream"] = torch.cuda.Stream(device=self.device)
+        return self._shared["e_stream"]
+
+    def _static(self):
+        if self._sbuf is None:
+            B, dev = self.batch, self.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            sb = {"nbuf": torch.empty(2 * B * 3 * 64 * 64 + B * 100, **f32), "alpha": torch.empty(B, 1, 1, 1, **f32),
+                  "real": torch.empty(B, 3, 64, 64, **f32), "idx": torch.empty(B, dtype=torch.int64, device=dev)}
+            if self.family == 1:
+                sb["labels"] = torch.empty(B, 100, dtype=torch.int64, device=dev)
+                sb["u"] = torch.empty(B, 256, **f32)
+                for i in range(4):
+                    sb[f"m{i + 1}"] = torch.empty(B, 256, **f32)
+            self._sbuf = sb
+        return self._sbuf
+
+    def _fill_static(self, real, noise, generator, labels):
+        """Puts this step's inputs into the fixed-address buffers (on the current = engine stream); -> (real, noise) that
+        point into them."""
+        sb, B = self._static(), self.batch
+        ni, nzz = B * 3 * 64 * 64, B * 100
+        if noise is None:
+            if self.family == 1:
+                if labels is None:
+                    raise JckError("CGAN step without a noise dict needs labels=")
+                sb["labels"].copy_(labels.to(torch.int64).view(B, 100), non_blocking=True)
+            nz = self.draw_noise(generator, labels=sb.get("labels"), out=sb)
+        else:
+            buf = sb["nbuf"]
+            buf[:ni].view(B, 3, 64, 64).copy_(noise["n1"], non_blocking=True)
+            buf[ni:ni + nzz].view(B, 100, 1, 1).copy_(noise["z"].view(B, 100, 1, 1), non_blocking=True)
+            buf[ni + nzz:].view(B, 3, 64, 64).copy_(noise["n2"], non_blocking=True)
+            sb["alpha"].copy_(noise["alpha"].view(B, 1, 1, 1), non_blocking=True)
+            nz = {"n1": buf[:ni].view(B, 3, 64, 64), "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
+                  "n2": buf[ni + nzz:].view(B, 3, 64, 64), "alpha": sb["alpha"]}
+            if self.family == 1:
+                lab = noise.get("labels")
+                if lab is None or lab.shape != (B, 100) or lab.dtype != torch.int64:
+                    raise JckError("CGAN step needs labels: int64 one-hot [B,100]")
+                nz["labels"] = sb["labels"].copy_(lab, non_blocking=True)
+                for i in range(4):
+                    m = noise.get(f"m{i + 1}")
+                    if m is None:
+                        raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
+                    nz[f"m{i + 1}"] = sb[f"m{i + 1}"].copy_(m.view(B, 256), non_blocking=True)
+        if isinstance(real, DeviceBatch):
+            if real.size(0) != B:
+                raise JckError(f"DeviceBatch must index {B} images")
+            real = DeviceBatch(real.data, sb["idx"].copy_(real.idx, non_blocking=True))
+        else:
+            if real.shape != (B, 3, 64, 64) or real.dtype != torch.float32:
+                raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
+            real = sb["real"].copy_(real, non_blocking=True)
+        return real, nz
+
+    def _step_graph(self, real, noise, lr, reduce_d, reduce_g, grad_scale, generator, labels):
+        main, est = torch.cuda.current_stream(), self._e_stream()
+        est.wait_stream(main)                                       # inputs produced on the caller's stream
+        for t in ([real] if torch.is_tensor(real) else [real.data, real.idx]) + [v for v in (noise or {}).values() if torch.is_tensor(v)]:
+            if t.is_cuda:
+                t.record_stream(est)                                # read by the copies below, on the engine stream
+        h, st = self._h, est.cuda_stream
+        with torch.cuda.stream(est):
+            gs = self._shared["g_stream"]
+            if gs is not None:
+                est.wait_stream(gs)
+            real_s, nz = self._fill_static(real, noise, generator, labels)
+            si, keep = self._inputs(real_s, nz, lr, grad_scale)
+            step = self.t + 1
+            lib.jck_engine_set_step(h, step, lr, st)
+            # a captured segment must join every side stream it forks: the penalty pass started in PHASE_D_LOSS (per-pass
+            # schedule) is joined by PHASE_D_GP, so the two always share a segment
+            if reduce_d or reduce_g:
+                segs = ([[PHASE_D_LOSS, PHASE_D_GP]], [[PHASE_D_STEP, PHASE_G_LOSS]], [[PHASE_G_STEP]])
+            else:
+                segs = ([[PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP]], [], [])
+            kind = ("u8", real.data.data_ptr()) if isinstance(real, DeviceBatch) else ("f32",)
+            handle = None
+
+            launched = []
+
+            def run(seg_id, phases):
+                key = (seg_id, step & 1, kind, float(grad_scale), tuple(phases))
+                ge = self._graph_cache.get(key)
+                if ge is None:
+                    try:
+                        lib.jck_engine_capture_begin(h, st)
+                        try:
+                            for ph in phases:
+                                lib.jck_engine_phase(h, ph, C.byref(si), st)
+                            out = C.c_void_p()
+                            lib.jck_engine_capture_end(h, st, C.byref(out))
+                        except Exception:
+                            lib.jck_engine_capture_abort(h, st)
+                            raise
+                    except JckError as e:
+                        if launched:        # part of the step already ran: no clean fallback
+                            raise
+                        raise _GraphUnavailable(str(e))
+                    ge = self._graph_cache[key] = out.value
+                lib.jck_graph_launch(ge, st)
+                launched.append(seg_id)
+
+            run(0, segs[0][0])
+            if reduce_d or reduce_g:
+                handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None    # no early bucket under replay: its event lives in the graph
+                if handle is not None:
+                    handle()
+                run(1, segs[1][0])
+                handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+                if handle is not None:
+                    handle()
+                run(2, segs[2][0])
+        self.t += 1
+        self._shared["last_step"] = self.t
+        self._shared["version"] += 1
+        self._packed_version = self._shared["version"]
+        self._keep = keep
+
+    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None, graph=None,
+                   generator=None, labels=None):
+        """Enqueues one full step; no host sync.  noise=None draws on the device (generator= / labels= as draw_noise takes
+        them).  graph (default: on, env JCK_GRAPH=0 disables; never with the pipeline or per-launch profiling): replay the
+        step from captured hipGraphs on the engine's own stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
         optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
         env JCK_PIPELINE=1 enables): run the G phase - with G's gradient all-reduce - on a second stream so that the next
         step's D(real) pass overlaps it.  On one GPU the in-step overlap already saturates the memory system and the
         pipeline measured 8 % slower; it exists for the multi-GPU case where it hides the G all-reduce."""
         if pipeline is None:
             pipeline = self.family == 0 and os.environ.get("JCK_PIPELINE", "0") == "1"
-        noise = noise if noise is not None else self.draw_noise()
         if self._packed_version != self._shared["version"]:
             self.join()
             self.repack()
+        use_graph = (self.graphs if graph is None else graph) and not pipeline and self._eager_steps >= 1
+        if use_graph:
+            try:
+                return self._step_graph(real, noise, lr, reduce_d, reduce_g, grad_scale, generator, labels)
+            except _GraphUnavailable as e:
+                import warnings
+                warnings.warn(f"hipGraph replay disabled for this engine ({e}); running the step eagerly")
+                self.graphs = False
+                torch.cuda.current_stream().wait_stream(self._e_stream())
+        self._eager_steps += 1
+        noise = noise if noise is not None else self.draw_noise(generator, labels=labels)
         si, keep = self._inputs(real, noise, lr, grad_scale)
         main = torch.cuda.current_stream()
         st = main.cuda_stream
@@ -340,11 +503,12 @@ class DcganEngine:
     def record_scalars(self, dst_row):
         """Copies the step scalars (device float[8]) into `dst_row` on the stream that produced them - no host sync and no
         stall of the next step's D pass."""
-        gs = self._shared["g_stream"]
+        gs = self._shared["g_stream"] or self._shared.get("e_stream")
         src = self.scalars_view(joined=False)
         if gs is None:
             dst_row.copy_(src, non_blocking=True)
         else:
+            gs.wait_stream(torch.cuda.current_stream())          # dst_row may have been produced on the caller's stream
             with torch.cuda.stream(gs):
                 dst_row.copy_(src, non_blocking=True)
 

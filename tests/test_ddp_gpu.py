@@ -66,7 +66,7 @@ def test_two_replicas_match_ddp_oracle(B):
         p.start()
     got = {}
     for _ in range(world):
-        r, out, gs, ds = q.get(timeout=600)
+        r, out, gs, ds = q.get(timeout=240)
         got[r] = (out, {k: torch.from_numpy(v) for k, v in gs.items()}, {k: torch.from_numpy(v) for k, v in ds.items()})
     for p in procs:
         p.join(120)
@@ -134,7 +134,7 @@ def test_two_rank_trainer_draws_its_own_noise_per_rank():
         p.start()
     got = {}
     for _ in range(world):
-        r = q.get(timeout=600)
+        r = q.get(timeout=240)
         got[r[0]] = r[1:]
     for p in procs:
         p.join(120)
