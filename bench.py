@@ -30,6 +30,18 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: den
 D_FWD, D_CONV1, G_FWD, G_CONV1 = 103_817_216, 3_145_728, 104_628_224, 819_200
 
 
+def step_flops_per_image_128():
+    """The same step on the 128x128 plan (one more stride-2 stage, 1024 channels at the 4x4 end): D forward
+    = conv1 3->64 @64x64 + 64->128 @32x32 + ... + 512->1024 @4x4 + the 16384-wide head; G the mirror image."""
+    d = [(64 * 64, 64, 48), (32 * 32, 128, 1024), (16 * 16, 256, 2048), (8 * 8, 512, 4096), (4 * 4, 1024, 8192)]
+    d_fwd = sum(px * co * k for px, co, k in d) + 16 * 1024
+    d_c1 = d[0][0] * d[0][1] * d[0][2]
+    g_c1 = 100 * 16 * 1024
+    g_fwd = g_c1 + sum(px * co * k for px, co, k in d[1:]) + d_c1          # ConvT layers mirror D's convs
+    mac = 4 * d_fwd + g_fwd + 2 * (d_fwd + (d_fwd - d_c1)) + d_fwd + d_fwd + g_fwd + (g_fwd - g_c1)
+    return 2 * mac
+
+
 def step_flops_per_image(dead_wgrad=False):
     """FLOPs of the work the engine performs per image and step (2 FLOP per MAC)."""
     mac = 4 * D_FWD + G_FWD                              # forward passes
@@ -144,14 +156,15 @@ def measure(a, model, world, rank, dev, dist):
     B = a.batch
     cgan = model == "cgan"
     M = CGAN if cgan else DCGAN
-    eng = (CganEngine if cgan else DcganEngine)(batch=B, prec=a.prec, device=dev)
+    S = a.size if not cgan else 64
+    eng = (CganEngine if cgan else DcganEngine)(batch=B, prec=a.prec, device=dev, **({"image_size": S} if S != 64 else {}))
     torch.manual_seed(12345)                            # change_randomseed.py:1 - identical weights on every rank
-    net_g, net_d = M.Generator(), M.Discriminator()
+    net_g, net_d = (M.Generator(S), M.Discriminator(S)) if S != 64 else (M.Generator(), M.Discriminator())
     net_g.apply(M.weights_init)
     net_d.apply(M.weights_init)
     eng.load_state(net_g.state_dict(), net_d.state_dict())
     gen = torch.Generator(device=dev).manual_seed(2024 + rank)
-    batches = [torch.rand(B, 3, 64, 64, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
+    batches = [torch.rand(B, 3, S, S, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
     if a.input == "u8":
         data = (torch.rand(50000, 3, 32, 32, device=dev, generator=gen) * 255).to(torch.uint8)        # CIFAR-sized
         batches = [DeviceBatch(data, torch.randint(0, 50000, (B,), device=dev, generator=gen)) for _ in range(4)]
@@ -187,6 +200,8 @@ def measure(a, model, world, rank, dev, dist):
     scal = eng.scalars()
     ms = dt / a.steps * 1e3
     fl = step_flops_per_image() * B
+    if S == 128:
+        fl = step_flops_per_image_128() * B
     if cgan:   # + v-chain (D forward-like + direct wgrads) and the reverse sweep (wgrad + dgrad) of the penalty, + linear1
         fl += 2 * B * (D_FWD + D_FWD + D_FWD + (D_FWD - D_CONV1))
     res = {"value": round(world * B * a.steps / dt, 1), "ms_per_step": round(ms, 4),
@@ -238,6 +253,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--prec", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--size", type=int, default=64, choices=[64, 128],
+                    help="64 = the reference's nets (headline); 128 = BASELINE.json configs[4]'s topology (use --batch 128)")
     ap.add_argument("--model", default="dcgan", choices=["dcgan", "cgan"],
                     help="dcgan = the headline config (BASELINE.json configs[1]); cgan = configs[3] (label-concat path, 10 classes)")
     ap.add_argument("--input", default="tensor", choices=["tensor", "u8"],
@@ -286,7 +303,11 @@ def main():
                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                       "dead_D_wgrad_in_G_phase": "skipped (never observable: zeroed at train/dcgan_trainer.py:155)"}}
     out.update(res)
-    if world == 1 and not cgan and not a.no_secondary:
+    if a.size == 128:
+        out["metric"] = "images/sec (G+D step) DCGAN 128x128"
+        out["config"]["workload"] = (f"DCGAN 128x128x3 synthetic (one more stride-2 stage, 1024 channels at 4x4), batch {B} per GPU, "
+                                     f"full G+D step (BASELINE.json configs[4] without the Inception/FID evaluation)")
+    if world == 1 and not cgan and not a.no_secondary and a.size == 64:
         # BASELINE.json configs[3] in the same process and the same way, so that its throughput is a driver-run number too
         sec = measure(a, "cgan", world, rank, dev, dist)
         sec = {"metric": "images/sec (G+D step) CGAN 64x64 bs256", "unit": "images/sec", "dtype": a.prec,

@@ -215,6 +215,15 @@ int jck_adam(float* p, const float* g, float* m, float* v, long long n, double l
 typedef struct jck_engine jck_engine;
 /* family 0 = DCGAN, 1 = CGAN.  Layout queries let the host build flat parameter arenas with the reference's state-dict order. */
 int jck_engine_create(jck_engine** out, int family, int prec, int batch);
+/* image_size 64 = the reference's nets (model/DCGAN.py:10-27,42-59); 128 = one more stride-2 stage at the deep end (D 3-64-128-
+ * 256-512-1024-1, G 100-1024-...-64-3; DCGAN only) for BASELINE.json configs[4] - no reference behaviour exists for it. */
+int jck_engine_create_sized(jck_engine** out, int family, int prec, int batch, int image_size);
+int jck_engine_image_size(const jck_engine*);
+/* layout queries of a created engine (its own image size); same meaning as the family-keyed ones below */
+int jck_engine_num_tensors_of(const jck_engine*, int net);
+int jck_engine_tensor_info_of(const jck_engine*, int net, int idx, char* name, int name_cap, int* kind, long long* offset,
+                              long long* numel, int* shape4);
+long long jck_engine_arena_numel_of(const jck_engine*, int net, int which);
 void jck_engine_destroy(jck_engine*);
 int jck_engine_num_tensors(int family, int net /*0=G,1=D*/);
 /* kind: 0 = parameter, 1 = running_mean, 2 = running_var ; name buffer gets the state-dict key */

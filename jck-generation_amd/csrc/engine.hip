@@ -7,6 +7,7 @@
 
 #include "ops_internal.hpp"
 #define JCK_BATCHED_DEFAULT 3
+#define TT (e->T)        /* the engine's channel plan; `e` is the engine in every function below (this inside its members) */
 
 namespace {
 
@@ -35,39 +36,60 @@ void add_bn(NetLayout& L, const char* wn, const char* bn, const char* rm, const 
   L.n_bn += (c + ALIGN_F - 1) / ALIGN_F * ALIGN_F;
 }
 
-// channel plan (model/DCGAN.py:10-26, :42-58)
-const int D_CS[4] = {64, 128, 256, 512}, D_CB[4] = {3, 64, 128, 256}, D_HB[4] = {64, 32, 16, 8};
-const int G_CS[4] = {512, 256, 128, 64}, G_CB[4] = {256, 128, 64, 3}, G_HS[4] = {4, 8, 16, 32};   // conv2..conv5
-const int G_C1 = 512;
-const int N_CLASS = 100, EMB = 200, L1_OUT = 256, FEAT = 8192, L1_K = FEAT + EMB, L1_KPAD = 8448, L1_KSPLIT = 12;   // model/CGAN.py:83,104
+// Channel plan.  S = 64 is the reference's topology (model/DCGAN.py:10-26, :42-58): NS = 4 stride-2 stages, 512 channels at
+// the 4x4 end.  S = 128 (BASELINE.json configs[4]; no reference behaviour exists - SURVEY section 8d) adds ONE stage at the
+// deep end, the usual way a DCGAN is grown: D 3 -> 64 -> 128 -> 256 -> 512 -> 1024 -> 1, G 100 -> 1024 -> ... -> 64 -> 3,
+// so every layer keeps >= 64 channels on its wide side and the image-side layers stay 3 <-> 64.
+#define JCK_MAX_STAGES 5
+struct Topo {
+  int S, NS, HW;                       // image size, stride-2 stages, S*S
+  int D_CS[JCK_MAX_STAGES], D_CB[JCK_MAX_STAGES], D_HB[JCK_MAX_STAGES];
+  int G_CS[JCK_MAX_STAGES], G_CB[JCK_MAX_STAGES], G_HS[JCK_MAX_STAGES];     // G.conv2 .. G.conv(NS+1)
+  int G_C1, FEAT;                      // channels at the 4x4 end; D's flattened top features 16*G_C1
+};
+Topo make_topo(int S) {
+  Topo T = {};
+  T.S = S; T.NS = S == 128 ? 5 : 4; T.HW = S * S;
+  T.G_C1 = 64 << (T.NS - 1);
+  T.FEAT = 16 * T.G_C1;
+  for (int i = 0; i < T.NS; ++i) {
+    T.D_CS[i] = 64 << i; T.D_CB[i] = i == 0 ? 3 : 32 << i; T.D_HB[i] = S >> i;
+    T.G_CS[i] = T.G_C1 >> i; T.G_CB[i] = i == T.NS - 1 ? 3 : T.G_C1 >> (i + 1); T.G_HS[i] = 4 << i;
+  }
+  return T;
+}
+const int N_CLASS = 100, EMB = 200, L1_OUT = 256, L1_FEAT = 8192, L1_K = L1_FEAT + EMB, L1_KPAD = 8448, L1_KSPLIT = 12;   // model/CGAN.py:83,104
 inline int z_dim(int family) { return family == 1 ? 200 : 100; }      // model/CGAN.py:132: ConvTranspose2d(200, 512)
 inline int z_pad(int family) { return family == 1 ? 256 : 128; }
 
-NetLayout make_layout(int family, int net) {
+static const char* const CWN[6] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight", "conv6.weight"};
+static const char* const NWN[5] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight", "norm5.weight"};
+static const char* const NBN[5] = {"norm1.bias", "norm2.bias", "norm3.bias", "norm4.bias", "norm5.bias"};
+static const char* const RMN[5] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean", "norm5.running_mean"};
+static const char* const RVN[5] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var", "norm5.running_var"};
+
+NetLayout make_layout(int family, int net, int S = 64) {
   NetLayout L;
-  static const char* CW[5] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight"};
-  static const char* NW[4] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight"};
-  static const char* NB[4] = {"norm1.bias", "norm2.bias", "norm3.bias", "norm4.bias"};
-  static const char* RM[4] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean"};
-  static const char* RV[4] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var"};
+  const Topo T = make_topo(S);
+  const char* const* CW = CWN; const char* const* NW = NWN; const char* const* NB = NBN; const char* const* RM = RMN; const char* const* RV = RVN;
   if (net == 0) {
-    add_param(L, CW[0], z_dim(family), G_C1, 4, 4);
-    add_bn(L, NW[0], NB[0], RM[0], RV[0], G_C1);
-    for (int i = 0; i < 4; ++i) {
-      add_param(L, CW[i + 1], G_CS[i], G_CB[i], 4, 4);
-      if (i < 3) add_bn(L, NW[i + 1], NB[i + 1], RM[i + 1], RV[i + 1], G_CB[i]);
+    add_param(L, CW[0], z_dim(family), T.G_C1, 4, 4);
+    add_bn(L, NW[0], NB[0], RM[0], RV[0], T.G_C1);
+    for (int i = 0; i < T.NS; ++i) {
+      add_param(L, CW[i + 1], T.G_CS[i], T.G_CB[i], 4, 4);
+      if (i < T.NS - 1) add_bn(L, NW[i + 1], NB[i + 1], RM[i + 1], RV[i + 1], T.G_CB[i]);
     }
   } else {
     if (family == 1) {                                  // model/CGAN.py:83: registered first
       add_param(L, "label_embedding.weight", EMB, N_CLASS, 1, 1);
       add_param(L, "label_embedding.bias", EMB, 1, 1, 1);
     }
-    for (int i = 0; i < 4; ++i) {
-      add_param(L, CW[i], D_CS[i], D_CB[i], 4, 4);
-      add_bn(L, NW[i], NB[i], RM[i], RV[i], D_CS[i]);
+    for (int i = 0; i < T.NS; ++i) {
+      add_param(L, CW[i], T.D_CS[i], T.D_CB[i], 4, 4);
+      add_bn(L, NW[i], NB[i], RM[i], RV[i], T.D_CS[i]);
     }
     if (family == 0) {
-      add_param(L, CW[4], 1, 512, 4, 4);
+      add_param(L, CW[T.NS], 1, T.G_C1, 4, 4);
     } else {                                            // model/CGAN.py:104,106
       add_param(L, "linear1.weight", L1_OUT, L1_K, 1, 1);
       add_param(L, "linear1.bias", L1_OUT, 1, 1, 1);
@@ -99,6 +121,7 @@ struct BnBuf { float *stats, *sums, *aux; int slots; };
 
 struct jck_engine {
   int family, prec, B;
+  Topo T;
   size_t esz;
   NetLayout LG, LD;
   size_t ws_bytes = 0;
@@ -108,32 +131,32 @@ struct jck_engine {
   float *dp = nullptr, *dg = nullptr, *dm = nullptr, *dv = nullptr, *dbn = nullptr;
   int64_t *gnbt = nullptr, *dnbt = nullptr;
   // packed weights
-  void *d_down[4], *d_up[4];
+  void *d_down[JCK_MAX_STAGES], *d_up[JCK_MAX_STAGES];
   float *d_head_wp, *d_head_dwp;
-  void *g1_w, *g_up[4], *g_down[4];
+  void *g1_w, *g_up[JCK_MAX_STAGES], *g_down[JCK_MAX_STAGES];
   // activations: three B-image D sets for the per-pass schedules (each pass that may run concurrently has its own)
-  struct DSet { void *y[4], *a[4], *g[4], *gx; BnBuf bn[4]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
+  struct DSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES], *gx; BnBuf bn[JCK_MAX_STAGES]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
   void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
   void*& d_gx = dset[0].gx;
   BnBuf* d_bn = dset[0].bn;
   float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
   // batched D passes (DCGAN): up to 3 batches that share D's weights go through ONE launch per layer, BatchNorm grouped
-  struct BSet { void *y[4], *a[4], *g[4]; float *stats[4], *aux[4], *sums[4]; float *prob, *ds; } bset;
+  struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds; } bset;
   int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
   bool gp_done = false;
-  float* d_rs[4];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
+  float* d_rs[JCK_MAX_STAGES];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[4] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr, evBucket = nullptr;
+  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr, evBucket = nullptr;
   bool bucket_ready = false;            // evBucket was recorded in this step's PHASE_D_LOSS (gradients of conv4.weight .. conv5.weight final)
   bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
-  void *g_z, *g_y[4], *g_a[4], *g_gr[4], *fake_raw, *fake, *g_raw;
+  void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
   unsigned char* zero_d; size_t zero_d_bytes;      // stats + sums of D's 4 layers
   unsigned char* zero_g; size_t zero_g_bytes;
-  BnBuf g_bn[4];
+  BnBuf g_bn[JCK_MAX_STAGES];
   float *acc, *scal_out;                // current-parity views into acc2 / scal2
   float *acc2, *scal2;                  // acc2: [2 parities][8 rows][acc_ld] per-image scalar table (summed by the step tail)
   int acc_ld = 0;
@@ -147,42 +170,42 @@ struct jck_engine {
   void *cbuf, *cbuf2;                 // [B][8448] concat(flatten(a4), e) ; [u4 | 0]
   void *h_pre, *h_drop, *g_h, *g_hd, *gh_b1, *ughd, *gc;    // [B][256] x6, [B][8448]
   float *pre_e, *l1_slab, *gw1p, *rs, *prob_gp;
-  void *d_v[4], *d_xdir[4], *d_u0;
-  float* bn2_ws[4]; float* bn2_ws_rev;
+  void *d_v[JCK_MAX_STAGES], *d_xdir[JCK_MAX_STAGES], *d_u0;
+  float* bn2_ws[JCK_MAX_STAGES]; float* bn2_ws_rev;
   const int64_t* cur_labels = nullptr;
 
   void carve(unsigned char* base) {
+    jck_engine* e = this;
     Carver c; c.base = base;
-    const size_t e = esz;
-    auto bytes = [&](size_t n) { return n * e; };
-    for (int i = 0; i < 4; ++i) {
-      d_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(D_CS[i]) * 16 * jck_pad_chan(D_CB[i])));
-      d_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(D_CB[i]) * 4 * D_CS[i]));
+    auto bytes = [&](size_t n) { return n * esz; };
+    for (int i = 0; i < TT.NS; ++i) {
+      d_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(TT.D_CS[i]) * 16 * jck_pad_chan(TT.D_CB[i])));
+      d_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(TT.D_CB[i]) * 4 * TT.D_CS[i]));
     }
-    d_head_wp = c.take<float>(8192); d_head_dwp = c.take<float>(8192);
-    g1_w = c.take<unsigned char>(bytes((size_t)16 * G_C1 * z_pad(family)));
-    for (int i = 0; i < 4; ++i) {
-      g_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(G_CB[i]) * 4 * G_CS[i]));
-      g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(G_CS[i]) * 16 * jck_pad_chan(G_CB[i])));
+    d_head_wp = c.take<float>(TT.FEAT); d_head_dwp = c.take<float>(TT.FEAT);
+    g1_w = c.take<unsigned char>(bytes((size_t)16 * TT.G_C1 * z_pad(family)));
+    for (int i = 0; i < TT.NS; ++i) {
+      g_up[i] = c.take<unsigned char>(bytes((size_t)4 * jck_pad_rows(TT.G_CB[i]) * 4 * TT.G_CS[i]));
+      g_down[i] = c.take<unsigned char>(bytes((size_t)jck_pad_rows(TT.G_CS[i]) * 16 * jck_pad_chan(TT.G_CB[i])));
     }
-    const size_t img = (size_t)B * 64 * 64 * 4;
+    const size_t img = (size_t)B * TT.HW * 4;
     for (int sI = 0; sI < 3; ++sI) {
       DSet& D = dset[sI];
-      for (int i = 0; i < 4; ++i) {
-        const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+      for (int i = 0; i < TT.NS; ++i) {
+        const size_t n = (size_t)B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2) * TT.D_CS[i];
         D.y[i] = c.take<unsigned char>(bytes(n)); D.a[i] = c.take<unsigned char>(bytes(n)); D.g[i] = c.take<unsigned char>(bytes(n));
-        D.bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(D_CS[i]));
-        D.bn[i].aux = c.take<float>(4 * D_CS[i]);
-        D.bn[i].stats = c.take<float>(jck_stats_floats((long long)B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
+        D.bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(TT.D_CS[i]));
+        D.bn[i].aux = c.take<float>(4 * TT.D_CS[i]);
+        D.bn[i].stats = c.take<float>(jck_stats_floats((long long)B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2), TT.D_CS[i], 1));
       }
       D.gx = c.take<unsigned char>(bytes(img));
       D.prob = c.take<float>(B); D.ds = c.take<float>(B); D.norms = c.take<float>(B);
     }
-    for (int i = 0; i < 4; ++i) d_rs[i] = c.take<float>(2 * 4 * 2 * D_CS[i]);
+    for (int i = 0; i < TT.NS; ++i) d_rs[i] = c.take<float>(2 * 4 * 2 * TT.D_CS[i]);
     g_z = c.take<unsigned char>(bytes((size_t)B * z_pad(family)));
     // G layer i (0..3): output of conv(i+1) = [B, h, h, C] with (h, C) = (4,512), (8,256), (16,128), (32,64)
-    for (int i = 0; i < 4; ++i) {
-      const int h = 4 << i, C = 512 >> i;
+    for (int i = 0; i < TT.NS; ++i) {
+      const int h = 4 << i, C = TT.G_C1 >> i;
       const size_t n = (size_t)B * h * h * C;
       g_y[i] = c.take<unsigned char>(bytes(n)); g_a[i] = c.take<unsigned char>(bytes(n)); g_gr[i] = c.take<unsigned char>(bytes(n));
     }
@@ -190,12 +213,12 @@ struct jck_engine {
     // real_noisy | fake | xhat are consecutive (img bytes % 256 == 0): the batched D pass reads them as one 3B-image tensor
     real_noisy = c.take<unsigned char>(bytes(img)); fake = c.take<unsigned char>(bytes(img)); xhat = c.take<unsigned char>(bytes(img));
     if (batched) {
-      for (int i = 0; i < 4; ++i) {
-        const size_t n = (size_t)3 * B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+      for (int i = 0; i < TT.NS; ++i) {
+        const size_t n = (size_t)3 * B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2) * TT.D_CS[i];
         bset.y[i] = c.take<unsigned char>(bytes(n)); bset.a[i] = c.take<unsigned char>(bytes(n)); bset.g[i] = c.take<unsigned char>(bytes(n));
-        bset.sums[i] = c.take<float>(3 * jck_bn_bwd_ws_floats(D_CS[i]));
-        bset.aux[i] = c.take<float>(3 * 4 * D_CS[i]);
-        bset.stats[i] = c.take<float>(jck_stats_floats((long long)3 * B * (D_HB[i] / 2) * (D_HB[i] / 2), D_CS[i], 1));
+        bset.sums[i] = c.take<float>(3 * jck_bn_bwd_ws_floats(TT.D_CS[i]));
+        bset.aux[i] = c.take<float>(3 * 4 * TT.D_CS[i]);
+        bset.stats[i] = c.take<float>(jck_stats_floats((long long)3 * B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2), TT.D_CS[i], 1));
       }
       bset.prob = c.take<float>(3 * B); bset.ds = c.take<float>(3 * B);
     }
@@ -205,10 +228,10 @@ struct jck_engine {
       zero_d = nullptr; zero_d_bytes = 0;
       start = c.off;
       zero_g = base ? base + start : nullptr;
-      for (int i = 0; i < 4; ++i) g_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(512 >> i));
+      for (int i = 0; i < TT.NS; ++i) g_bn[i].sums = c.take<float>(jck_bn_bwd_ws_floats(TT.G_C1 >> i));
       zero_g_bytes = c.off - start;
-      for (int i = 0; i < 4; ++i) {
-        const int C = 512 >> i, h = 4 << i;
+      for (int i = 0; i < TT.NS; ++i) {
+        const int C = TT.G_C1 >> i, h = 4 << i;
         g_bn[i].aux = c.take<float>(4 * C);
         g_bn[i].stats = c.take<float>(jck_stats_floats((long long)B * h * h, C, i == 0 ? 16 : 1));
       }
@@ -217,15 +240,15 @@ struct jck_engine {
     acc2 = c.take<float>((size_t)2 * 8 * acc_ld); scal2 = c.take<float>(16);
     acc = acc2; scal_out = scal2;
     hp2 = c.take<float>(8);
-    head_ws = c.take<float>(jck_head_bwd_ws_floats(FEAT));
+    head_ws = c.take<float>(jck_head_bwd_ws_floats(TT.FEAT));
     gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
     size_t w = 0;
-    for (int i = 0; i < 4; ++i) {
-      w = std::max(w, jck_conv_wgrad_ws_bytes(B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
-      w = std::max(w, jck_conv_wgrad_ws_bytes(2 * B, D_HB[i], D_HB[i], D_CB[i], D_CS[i]));
-      w = std::max(w, jck_conv_wgrad_ws_bytes(B, G_HS[i] * 2, G_HS[i] * 2, G_CB[i], G_CS[i]));
+    for (int i = 0; i < TT.NS; ++i) {
+      w = std::max(w, jck_conv_wgrad_ws_bytes(B, TT.D_HB[i], TT.D_HB[i], TT.D_CB[i], TT.D_CS[i]));
+      w = std::max(w, jck_conv_wgrad_ws_bytes(2 * B, TT.D_HB[i], TT.D_HB[i], TT.D_CB[i], TT.D_CS[i]));
+      w = std::max(w, jck_conv_wgrad_ws_bytes(B, TT.G_HS[i] * 2, TT.G_HS[i] * 2, TT.G_CB[i], TT.G_CS[i]));
     }
-    w = std::max(w, jck_g1_wgrad_ws_bytes(B, z_pad(family), G_C1));
+    w = std::max(w, jck_g1_wgrad_ws_bytes(B, z_pad(family), TT.G_C1));
     if (family == 1) w = std::max(w, jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT));
     wg_ws_bytes = w;
     wg_ws = c.take<float>(w / 4);
@@ -238,10 +261,10 @@ struct jck_engine {
       gc = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
       pre_e = c.take<float>((size_t)B * EMB); l1_slab = c.take<float>((size_t)L1_KSPLIT * B * L1_OUT);
       gw1p = c.take<float>((size_t)L1_OUT * L1_KPAD); rs = c.take<float>(B); prob_gp = c.take<float>(B);
-      for (int i = 0; i < 4; ++i) {
-        const size_t n = (size_t)B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i];
+      for (int i = 0; i < TT.NS; ++i) {
+        const size_t n = (size_t)B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2) * TT.D_CS[i];
         d_v[i] = c.take<unsigned char>(bytes(n)); d_xdir[i] = c.take<unsigned char>(bytes(n));
-        bn2_ws[i] = c.take<float>(jck_bn2_ws_floats(D_CS[i]));
+        bn2_ws[i] = c.take<float>(jck_bn2_ws_floats(TT.D_CS[i]));
       }
       bn2_ws_rev = c.take<float>(jck_bn2_ws_floats(512));
       d_u0 = c.take<unsigned char>(bytes(img));
@@ -252,20 +275,22 @@ struct jck_engine {
   float* P(const NetLayout& L, float* arena, const char* name) const { return arena + find(L, name)->offset; }
 };
 
-static const char* NAMES_CW[5] = {"conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight"};
-static const char* NAMES_NW[4] = {"norm1.weight", "norm2.weight", "norm3.weight", "norm4.weight"};
-static const char* NAMES_NB[4] = {"norm1.bias", "norm2.bias", "norm3.bias", "norm4.bias"};
-static const char* NAMES_RM[4] = {"norm1.running_mean", "norm2.running_mean", "norm3.running_mean", "norm4.running_mean"};
-static const char* NAMES_RV[4] = {"norm1.running_var", "norm2.running_var", "norm3.running_var", "norm4.running_var"};
 
 extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int batch) {
+  return jck_engine_create_sized(out, family, prec, batch, 64);
+}
+// image_size 64 = the reference's topology; 128 = one more stride-2 stage (DCGAN only; BASELINE.json configs[4])
+extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, int batch, int image_size) {
   if (!out) JCK_FAIL(JCK_E_ARG, "null out");
+  if (image_size != 64 && image_size != 128) JCK_FAIL(JCK_E_ARG, "image_size must be 64 or 128");
+  if (image_size != 64 && family != 0) JCK_FAIL(JCK_E_ARG, "the 128x128 topology exists for DCGAN only (CGAN's Linear(8392,256) fixes 64x64)");
   if (family != 0 && family != 1) JCK_FAIL(JCK_E_ARG, "family must be 0 (DCGAN) or 1 (CGAN)");
   if (prec != JCK_PREC_BF16 && prec != JCK_PREC_F32) JCK_FAIL(JCK_E_ARG, "bad prec");
   if (batch < 1 || batch > 8192) JCK_FAIL(JCK_E_ARG, "batch must be in [1, 8192]");
   jck_engine* e = new jck_engine();
   e->family = family; e->prec = prec; e->B = batch; e->esz = prec == JCK_PREC_BF16 ? 2 : 4;
-  e->LG = make_layout(family, 0); e->LD = make_layout(family, 1);
+  e->T = make_topo(image_size);
+  e->LG = make_layout(family, 0, image_size); e->LD = make_layout(family, 1, image_size);
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
   // batched D passes need whole tiles per group: 16*B rows at the last layer, tiles of up to 128 rows
   e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
@@ -278,7 +303,8 @@ extern "C" int jck_engine_create(jck_engine** out, int family, int prec, int bat
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
-    hipEvent_t* ev[10] = {&e->evW[0], &e->evW[1], &e->evW[2], &e->evW[3], &e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
+    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
   }
   *out = e;
@@ -289,7 +315,8 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[10] = {e->evW[0], e->evW[1], e->evW[2], e->evW[3], e->evWdone, e->ev0, e->evF, e->evReal, e->evGP, e->evBucket};
+    hipEvent_t ev[6 + JCK_MAX_STAGES] = {e->evWdone, e->ev0, e->evF, e->evReal, e->evGP, e->evBucket};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = e->evW[i];
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -304,13 +331,34 @@ extern "C" int jck_engine_tensor_info(int family, int net, int idx, char* name, 
   if (kind) *kind = t.kind;
   if (offset) *offset = t.offset;
   if (numel) *numel = t.numel;
-  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  if (shape4) for (int q_ = 0; q_ < 4; ++q_) shape4[q_] = t.shape[q_];
   return JCK_OK;
 }
 extern "C" long long jck_engine_arena_numel(int family, int net, int which) {
   NetLayout L = make_layout(family, net);
   return which == 0 ? L.n_params : L.n_bn;
 }
+// the same three queries for a created engine (its own image size)
+extern "C" int jck_engine_num_tensors_of(const jck_engine* e, int net) { return e ? (int)(net == 0 ? e->LG : e->LD).t.size() : 0; }
+extern "C" int jck_engine_tensor_info_of(const jck_engine* e, int net, int idx, char* name, int name_cap, int* kind, long long* offset,
+                                         long long* numel, int* shape4) {
+  if (!e) JCK_FAIL(JCK_E_ARG, "null engine");
+  const NetLayout& L = net == 0 ? e->LG : e->LD;
+  if (idx < 0 || idx >= (int)L.t.size()) JCK_FAIL(JCK_E_ARG, "index out of range");
+  const TensorInfo& t = L.t[idx];
+  if (name && name_cap > 0) { strncpy(name, t.name, name_cap - 1); name[name_cap - 1] = 0; }
+  if (kind) *kind = t.kind;
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (shape4) for (int q_ = 0; q_ < 4; ++q_) shape4[q_] = t.shape[q_];
+  return JCK_OK;
+}
+extern "C" long long jck_engine_arena_numel_of(const jck_engine* e, int net, int which) {
+  if (!e) return 0;
+  const NetLayout& L = net == 0 ? e->LG : e->LD;
+  return which == 0 ? L.n_params : L.n_bn;
+}
+extern "C" int jck_engine_image_size(const jck_engine* e) { return e ? e->T.S : 0; }
 extern "C" size_t jck_engine_workspace_bytes(const jck_engine* e) { return e ? e->ws_bytes : 0; }
 
 extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, float* g_params, float* g_grads, float* g_m,
@@ -352,18 +400,18 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
     else add(1, w, wp, (long long)Cs * Cb, Cs, Cb, jck_pad_rows(Cb));
   };
   if (net == 1) {
-    for (int i = 0; i < 4; ++i) {
-      const float* w = e->P(e->LD, e->dp, NAMES_CW[i]);
-      add_down(w, D_CS[i], D_CB[i], e->d_down[i]);
-      add_up(w, D_CS[i], D_CB[i], e->d_up[i]);
+    for (int i = 0; i < TT.NS; ++i) {
+      const float* w = e->P(e->LD, e->dp, CWN[i]);
+      add_down(w, TT.D_CS[i], TT.D_CB[i], e->d_down[i]);
+      add_up(w, TT.D_CS[i], TT.D_CB[i], e->d_up[i]);
     }
-    if (e->family == 0) add(4, e->P(e->LD, e->dp, NAMES_CW[4]), e->d_head_wp, 512, 512, 0, 0);
+    if (e->family == 0) add(4, e->P(e->LD, e->dp, CWN[TT.NS]), e->d_head_wp, TT.G_C1, TT.G_C1, 0, 0);
   } else {
-    add(3, e->P(e->LG, e->gp, NAMES_CW[0]), e->g1_w, (long long)z_dim(e->family) * G_C1, z_dim(e->family), G_C1, z_pad(e->family));
-    for (int i = 0; i < 4; ++i) {
-      const float* w = e->P(e->LG, e->gp, NAMES_CW[i + 1]);
-      add_up(w, G_CS[i], G_CB[i], e->g_up[i]);
-      add_down(w, G_CS[i], G_CB[i], e->g_down[i]);
+    add(3, e->P(e->LG, e->gp, CWN[0]), e->g1_w, (long long)z_dim(e->family) * TT.G_C1, z_dim(e->family), TT.G_C1, z_pad(e->family));
+    for (int i = 0; i < TT.NS; ++i) {
+      const float* w = e->P(e->LG, e->gp, CWN[i + 1]);
+      add_up(w, TT.G_CS[i], TT.G_CB[i], e->g_up[i]);
+      add_down(w, TT.G_CS[i], TT.G_CB[i], e->g_down[i]);
     }
   }
   jobs.first_chunk[n] = chunk;
@@ -392,12 +440,12 @@ typedef jck_engine::DSet DSet;
 // which keeps the result bitwise independent of how the passes overlap on streams.
 static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st) {
   const void* in = x_in;
-  for (int i = 0; i < 4; ++i) {
-    const int hb = D_HB[i], cs = D_CS[i];
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, D_CB[i], cs, st));
+  for (int i = 0; i < TT.NS; ++i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i];
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, st));
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
-                       e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]), (float*)nullptr, (float*)nullptr,
+                       e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
     JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
@@ -411,9 +459,9 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 // label embedding, Linear(8392,256), Dropout.  Leaves cbuf, pre_e, h_pre, h_drop for the matching d_head_backward.
 static int cg_head_forward(jck_engine* e, const void* a4, int B, const float* drop_mask, hipStream_t st) {
   if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
-  JCK_TRY(jck_concat_rows(e->prec, a4, FEAT, e->cbuf, L1_KPAD, B, st));
+  JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, B, st));
   JCK_TRY(jck_label_embed_fwd(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
-                              e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, FEAT, e->pre_e, st));
+                              e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, TT.FEAT, e->pre_e, st));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   return jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
                            e->h_drop, B, L1_OUT, st);
@@ -421,14 +469,14 @@ static int cg_head_forward(jck_engine* e, const void* a4, int B, const float* dr
 
 static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
   JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st));
-  if (e->family == 1) return cg_head_forward(e, e->d_a[3], B, drop_mask, st);
+  if (e->family == 1) return cg_head_forward(e, e->d_a[TT.NS - 1], B, drop_mask, st);
   return JCK_OK;
 }
 
 // sigmoid head + loss (mode 0) or + d(sum p)/dlogit (mode 1); fills e->prob / e->ds
 static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
   if (e->family == 0)
-    return jck_head_fwd(e->prec, D.a[3], e->d_head_wp, nullptr, B, FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
+    return jck_head_fwd(e->prec, D.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
   return jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, target,
                       mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
 }
@@ -436,7 +484,7 @@ static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slo
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
 static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
   if (e->family == 0)
-    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[3], B, 512, ga4_out, want_wgrad ? e->P(e->LD, e->dg, NAMES_CW[4]) : nullptr,
+    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, ga4_out, want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr,
                              e->head_ws, st);
   // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds
   JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), e->h_drop, B, L1_OUT, e->g_hd,
@@ -448,9 +496,9 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
     JCK_TRY(jck_colsum(e->prec, e->g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
   }
   JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
-  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, FEAT, ga4_out, B, st));
+  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, TT.FEAT, ga4_out, B, st));
   if (want_wgrad)
-    JCK_TRY(jck_label_embed_bwd(e->prec, e->gc, L1_KPAD, FEAT, e->pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
+    JCK_TRY(jck_label_embed_bwd(e->prec, e->gc, L1_KPAD, TT.FEAT, e->pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
                                 e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), st));
   return JCK_OK;
 }
@@ -459,14 +507,14 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
 // (both only READ gy_i and the saved activations); the main stream waits for them before returning.
 static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
                       hipStream_t st, hipStream_t side, bool join = true) {
-  JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[3], st));
+  JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[TT.NS - 1], st));
   const bool par = want_wgrad && side != nullptr;
-  for (int i = 3; i >= 0; --i) {
-    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+  for (int i = TT.NS - 1; i >= 0; --i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    float* dgam = want_wgrad ? e->P(e->LD, e->dg, NAMES_NW[i]) : nullptr;
-    float* dbet = want_wgrad ? e->P(e->LD, e->dg, NAMES_NB[i]) : nullptr;
-    if (i < 3 && e->fuse_bnbwd)      // the dgrad launch below (previous iteration) already left sum g_z, sum g_z*xhat in the slots
+    float* dgam = want_wgrad ? e->P(e->LD, e->dg, NWN[i]) : nullptr;
+    float* dbet = want_wgrad ? e->P(e->LD, e->dg, NBN[i]) : nullptr;
+    if (i < TT.NS - 1 && e->fuse_bnbwd)      // the dgrad launch below (previous iteration) already left sum g_z, sum g_z*xhat in the slots
       JCK_TRY(jck_bn_bwd_finish(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].stats, D.bn[i].slots, D.bn[i].sums, D.g[i], dgam,
                                 dbet, rows, cs, 1, 1, st));
     else
@@ -475,7 +523,7 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     if (want_wgrad) {
       hipStream_t ws = st;
       if (par) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
-      JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, ws));
+      JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, ws));
     }
     if (i > 0 && e->fuse_bnbwd)
       JCK_TRY(jck_conv_up_bnbwd(e->prec, D.g[i], e->d_up[i], D.g[i - 1], D.bn[i - 1].stats, &D.bn[i - 1].slots, B, hb / 2, hb / 2, cs, cb,
@@ -502,15 +550,15 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   const void* in = x_in;
-  for (int i = 0; i < 4; ++i) {
-    const int hb = D_HB[i], cs = D_CS[i];
+  for (int i = 0; i < TT.NS; ++i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // statistic slots of group g0 start at the g0/3 point of the buffer (sized for 3B pixels at one slot per 32 pixels)
     float* stats = S.stats[i] + (size_t)g0 * (jck_stats_floats((long long)3 * B * (hb / 2) * (hb / 2), cs, 1) / 3 / (2 * cs)) * (2 * cs);
     int slots = 0;
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, D_CB[i], cs, st));
+    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
-    JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NAMES_NW[i]), e->P(e->LD, e->dp, NAMES_NB[i]),
+    JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
     JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
                                    at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
@@ -527,21 +575,21 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
-  int bslots[4] = {0, 0, 0, 0};
-  for (int i = 3; i >= 0; --i) {
-    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+  int bslots[JCK_MAX_STAGES] = {0, 0, 0, 0, 0};
+  for (int i = TT.NS - 1; i >= 0; --i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    if (i < 3 && e->fuse_bnbwd)
+    if (i < TT.NS - 1 && e->fuse_bnbwd)
       JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
-                                e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+                                e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
     else
-      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NAMES_NW[i]),
-                                     e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, G, gw, st));
+      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NWN[i]),
+                                     e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
-    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, gw * B, hb, hb, cb, cs, ws));
-    if (i == 3 && e->family == 0 && G == 3) {
+    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
+    if (i == TT.NS - 1 && e->family == 0 && G == 3) {
       // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
       // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
       // (jck_engine_grad_bucket)
@@ -558,7 +606,7 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
       JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)(G - 1) * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
   // the penalty's norm does not need the weight gradients: it runs while the side stream finishes the last of them
-  if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, 64 * 64, e->acc, 6, e->acc_ld, e->norms, st));
+  if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, TT.HW, e->acc, 6, e->acc_ld, e->norms, st));
   if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
@@ -577,12 +625,12 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   if (!forward_done) JCK_TRY(d_batched_forward(e, x_in, B, 0, G, pass0, st));
   for (int g = 0; g < G; ++g) {
     const bool pen = g == G - 1;
-    JCK_TRY(jck_head_fwd(e->prec, at(S.a[3], (size_t)g * B * FEAT), e->d_head_wp, nullptr, B, FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
+    JCK_TRY(jck_head_fwd(e->prec, at(S.a[TT.NS - 1], (size_t)g * B * TT.FEAT), e->d_head_wp, nullptr, B, TT.FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
                          S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], e->acc_ld, st));
   }
-  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[3], gw * B, 512, S.g[3], e->P(e->LD, e->dg, NAMES_CW[4]), e->head_ws, st));
-  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[3], (size_t)gw * B * FEAT), B, 512,
-                            at(S.g[3], (size_t)gw * B * FEAT), nullptr, nullptr, st));
+  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]), e->head_ws, st));
+  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[TT.NS - 1], (size_t)gw * B * TT.FEAT), B, TT.G_C1,
+                            at(S.g[TT.NS - 1], (size_t)gw * B * TT.FEAT), nullptr, nullptr, st));
   JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true));
   return JCK_OK;
 }
@@ -596,21 +644,21 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
 // (which overwrites the v_i the v-chain products read and runs the Linear weight gradient on the main stream) and at the end.
 // where the penalty pass left its forward / first-backward tensors: activation set 0 (per-pass schedule) or the last group
 // of the batched set
-struct GpSrc { const void *y[4], *a[4], *g[4]; const float *aux[4], *sums[4], *prob; };
+struct GpSrc { const void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; const float *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES], *prob; };
 static GpSrc gp_src_dset0(jck_engine* e) {
   GpSrc r;
-  for (int i = 0; i < 4; ++i) { r.y[i] = e->d_y[i]; r.a[i] = e->d_a[i]; r.g[i] = e->d_g[i]; r.aux[i] = e->d_bn[i].aux; r.sums[i] = e->d_bn[i].sums; }
+  for (int i = 0; i < TT.NS; ++i) { r.y[i] = e->d_y[i]; r.a[i] = e->d_a[i]; r.g[i] = e->d_g[i]; r.aux[i] = e->d_bn[i].aux; r.sums[i] = e->d_bn[i].sums; }
   r.prob = e->prob;
   return r;
 }
 static GpSrc gp_src_group(jck_engine* e, int g, int B) {
   GpSrc r;
   auto& S = e->bset;
-  for (int i = 0; i < 4; ++i) {
-    const size_t off = (size_t)g * B * (D_HB[i] / 2) * (D_HB[i] / 2) * D_CS[i] * e->esz;
+  for (int i = 0; i < TT.NS; ++i) {
+    const size_t off = (size_t)g * B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2) * TT.D_CS[i] * e->esz;
     r.y[i] = (const unsigned char*)S.y[i] + off; r.a[i] = (const unsigned char*)S.a[i] + off; r.g[i] = (const unsigned char*)S.g[i] + off;
-    r.aux[i] = S.aux[i] + (size_t)g * 4 * D_CS[i];
-    r.sums[i] = S.sums[i] + (size_t)g * jck_bn_bwd_ws_floats(D_CS[i]);
+    r.aux[i] = S.aux[i] + (size_t)g * 4 * TT.D_CS[i];
+    r.sums[i] = S.sums[i] + (size_t)g * jck_bn_bwd_ws_floats(TT.D_CS[i]);
   }
   r.prob = S.prob + (size_t)g * B;
   return r;
@@ -632,21 +680,21 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   };
   HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->prob_gp, P.prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
-  JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, 64 * 64, e->d_u0, st));
+  JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, TT.HW, e->d_u0, st));
   // ---- v-chain: adjoint of the first backward, swept forward through D
   const void* u = e->d_u0;
-  for (int i = 0; i < 4; ++i) {
-    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+  for (int i = 0; i < TT.NS; ++i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // g_{a_{i-1}} = convT(gy_i; W_i):  dW_i += wgrad(gy_i, u_{i-1}),  v_i = conv(u_{i-1}; W_i)
-    JCK_TRY(jck_conv_wgrad(e->prec, P.g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
+    JCK_TRY(jck_conv_wgrad(e->prec, P.g[i], u, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, fork(i)));
     JCK_TRY(jck_conv_down(e->prec, u, e->d_down[i], e->d_v[i], nullptr, nullptr, B, hb, hb, cb, cs, st));
-    JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], P.y[i], P.g[i], P.aux[i], P.sums[i], e->P(e->LD, e->dp, NAMES_NW[i]),
-                           LRELU, e->bn2_ws[i], e->d_v[i], e->d_xdir[i], e->P(e->LD, e->dg, NAMES_NW[i]), rows, cs, st));
+    JCK_TRY(jck_bn2_vchain(e->prec, e->d_v[i], P.y[i], P.g[i], P.aux[i], P.sums[i], e->P(e->LD, e->dp, NWN[i]),
+                           LRELU, e->bn2_ws[i], e->d_v[i], e->d_xdir[i], e->P(e->LD, e->dg, NWN[i]), rows, cs, st));
     u = e->d_v[i];
   }
   // head: gc[:, :8192] = gh W1 -> adj(gh) = [u4 | 0] W1^T, dW1 += gh^T [u4 | 0]; gh = gh' * m/(1-p); gh' = ds w2; ds = p(1-p)
-  JCK_TRY(jck_concat_rows(e->prec, e->d_v[3], FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
+  JCK_TRY(jck_concat_rows(e->prec, e->d_v[TT.NS - 1], TT.FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
   JCK_TRY(jck_linear_wgrad(e->prec, e->gh_b1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
@@ -654,14 +702,14 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
                        e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
   join();
-  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[3], st));
-  for (int i = 3; i >= 0; --i) {
-    const int hb = D_HB[i], cs = D_CS[i], cb = D_CB[i];
+  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st));
+  for (int i = TT.NS - 1; i >= 0; --i) {
+    const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], P.y[i], e->d_xdir[i], P.aux[i], e->P(e->LD, e->dp, NAMES_NW[i]), e->bn2_ws[i],
-                            LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NAMES_NW[i]), e->P(e->LD, e->dg, NAMES_NB[i]), rows, cs, st));
+    JCK_TRY(jck_bn2_reverse(e->prec, e->d_v[i], P.y[i], e->d_xdir[i], P.aux[i], e->P(e->LD, e->dp, NWN[i]), e->bn2_ws[i],
+                            LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, st));
     const void* big = i == 0 ? xhat : P.a[i - 1];
-    JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, NAMES_CW[i]), 1, B, hb, hb, cb, cs, fork(i)));
+    JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, fork(i)));
     if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, e->d_v[i], e->d_up[i], e->d_v[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
@@ -684,50 +732,50 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
     if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, 100, zp, e->g_z, st); else launch_pad_rows<float>(z, B, 100, zp, e->g_z, st);
     HIPCHK(hipGetLastError());
   }
-  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, zp, G_C1, st));
-  for (int i = 0; i < 4; ++i) {
-    const int h = 4 << i, C = 512 >> i;
+  JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, zp, TT.G_C1, st));
+  for (int i = 0; i < TT.NS; ++i) {
+    const int h = 4 << i, C = TT.G_C1 >> i;
     const long long rows = (long long)B * h * h;
-    JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NAMES_NW[i]), e->P(e->LG, e->gp, NAMES_NB[i]),
-                            e->gbn + find(e->LG, NAMES_RM[i])->offset, e->gbn + find(e->LG, NAMES_RV[i])->offset,
+    JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]),
+                            e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset,
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
     JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
-    if (i < 3)
-      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, 0, B, h, h, G_CS[i], G_CB[i], st));
-    else
-      JCK_TRY(jck_conv_up(e->prec, e->g_a[3], e->g_up[3], e->fake_raw, nullptr, nullptr, 1, B, 32, 32, 64, 3, st));
+    if (i < TT.NS - 1)
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, 0, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
+    else                                             // last ConvTranspose + tanh -> the image
+      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
   }
   return JCK_OK;
 }
 
 // g_fake = gradient w.r.t. the noisy fake image (NHWC4); fills G's grads arena (accumulating)
 static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side) {
-  JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * 64 * 64 * 4, st));
+  JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st));
   const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
-  for (int i = 3; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = G_CS[i]), big side has G_CB[i] channels
-    const int hs = G_HS[i], cs = G_CS[i], cb = G_CB[i];
+  for (int i = TT.NS - 1; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = TT.G_CS[i]), big side has TT.G_CB[i] channels
+    const int hs = TT.G_HS[i], cs = TT.G_CS[i], cb = TT.G_CB[i];
     hipStream_t ws = st;
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
-    JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[i + 1]), 1, B,
+    JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
     const long long rows = (long long)B * hs * hs;
     if (e->fuse_bnbwd) {
       JCK_TRY(jck_conv_down_bnbwd(e->prec, gbig, e->g_down[i], e->g_gr[i], e->g_bn[i].stats, &e->g_bn[i].slots, B, 2 * hs, 2 * hs, cb, cs,
                                   e->g_y[i], e->g_bn[i].aux, 0.f, 0, st));
       JCK_TRY(jck_bn_bwd_finish(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].stats, e->g_bn[i].slots, e->g_bn[i].sums,
-                                e->g_gr[i], e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, 1, 1, st));
+                                e->g_gr[i], e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, st));
     } else {
       JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
       JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
-                             e->P(e->LG, e->gg, NAMES_NW[i]), e->P(e->LG, e->gg, NAMES_NB[i]), rows, cs, st));
+                             e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, st));
     }
     gbig = e->g_gr[i];
   }
   // the split-K workspace belongs to the side stream: G.conv1's weight gradient goes there too
   hipStream_t ws1 = st;
   if (side) { HIPCHK(hipEventRecord(e->evW[0], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[0], 0)); ws1 = side; }
-  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, NAMES_CW[0]), 1, B, z_dim(e->family),
-                       z_pad(e->family), G_C1, ws1));
+  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[0]), 1, B, z_dim(e->family),
+                       z_pad(e->family), TT.G_C1, ws1));
   if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
@@ -735,8 +783,11 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
 // the real batch -> NHWC4 with instance noise (:160): from an fp32 NCHW tensor, or gathered from the device-resident uint8
 // dataset with the input transform applied on the fly
 static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_t st) {
-  if (in->real_u8) return jck_img_prep_u8(e->prec, in->real_u8, in->real_idx, in->noise_real, 0.9f, 0.1f, e->real_noisy, nullptr, B, 32, 32, st);
-  return jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, 64 * 64, st);
+  if (in->real_u8) {
+    if (TT.S != 64) JCK_FAIL(JCK_E_ARG, "the device-resident uint8 pipeline is the reference's Resize(64) of 32x32 images: 64x64 engines only");
+    return jck_img_prep_u8(e->prec, in->real_u8, in->real_idx, in->noise_real, 0.9f, 0.1f, e->real_noisy, nullptr, B, 32, 32, st);
+  }
+  return jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, TT.HW, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -745,7 +796,7 @@ static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_
 extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in, void* stream) {
   if (!e || !e->bound || !in) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
   hipStream_t st = (hipStream_t)stream;
-  const int B = e->B, HW = 64 * 64;
+  const int B = e->B, HW = TT.HW;
   const bool cg = e->family == 1;
   if (cg) {
     if (!in->labels) JCK_FAIL(JCK_E_ARG, "CGAN phases need labels");
@@ -796,8 +847,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         const float tg[2] = {0.9f, 0.1f};
         for (int g = 0; g < 3; ++g) {
           const bool pen = g == 2;
-          void* a4 = (unsigned char*)S.a[3] + (size_t)g * B * FEAT * e->esz;
-          void* g4 = (unsigned char*)S.g[3] + (size_t)g * B * FEAT * e->esz;
+          void* a4 = (unsigned char*)S.a[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;
+          void* g4 = (unsigned char*)S.g[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;
           JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
           JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
                                pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, e->acc_ld, st));
@@ -936,16 +987,16 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       JCK_TRY(jck_engine_repack(e, 0, st));
       {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
         TailJobs t = {};
-        for (int i = 0; i < 4; ++i) {
-          const int cs = D_CS[i];
+        for (int i = 0; i < TT.NS; ++i) {
+          const int cs = TT.D_CS[i];
           t.l[i].rec = e->d_rs[i] + (size_t)e->parity * 4 * 2 * cs;
-          t.l[i].rm = e->dbn + find(e->LD, NAMES_RM[i])->offset;
-          t.l[i].rv = e->dbn + find(e->LD, NAMES_RV[i])->offset;
+          t.l[i].rm = e->dbn + find(e->LD, RMN[i])->offset;
+          t.l[i].rv = e->dbn + find(e->LD, RVN[i])->offset;
           t.l[i].nbt = (long long*)(e->dnbt + i);
           t.l[i].C = cs;
         }
-        t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.acc_ld = e->acc_ld; t.B = B; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
-        hipLaunchKernelGGL(step_tail_kernel, dim3(2, 5), dim3(256), 0, st, t);
+        t.nl = TT.NS; t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.acc_ld = e->acc_ld; t.B = B; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
+        hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(TT.G_C1, 256), TT.NS + 1), dim3(256), 0, st, t);
         HIPCHK(hipGetLastError());
       }
       return JCK_OK;
@@ -1025,7 +1076,7 @@ extern "C" void jck_graph_destroy(void* graph_exec) {
 extern "C" int jck_engine_grad_bucket(jck_engine* e, int net, void* stream, long long* offset, long long* numel) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (net != 1 || !e->bucket_ready || !e->evBucket) return 0;
-  const long long off = find(e->LD, NAMES_CW[3])->offset;
+  const long long off = find(e->LD, CWN[TT.NS - 1])->offset;
   if (offset) *offset = off;
   if (numel) *numel = (long long)e->LD.n_params - off;
   if (stream) {
@@ -1043,17 +1094,17 @@ extern "C" int jck_engine_sample(jck_engine* e, const float* z, const int64_t* l
   if (n < 1 || n > e->B) JCK_FAIL(JCK_E_ARG, "sample: n must be in [1, batch]");
   hipStream_t st = (hipStream_t)stream;
   JCK_TRY(g_forward(e, z, labels, n, st));
-  return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, 64 * 64, st);
+  return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, TT.HW, st);
 }
 
 extern "C" const void* jck_engine_tensor(const jck_engine* e, const char* name, long long* numel) {
   if (!e || !e->bound || !name) return nullptr;
-  const long long img = (long long)e->B * 64 * 64 * 4;
+  const long long img = (long long)e->B * TT.HW * 4;
   struct { const char* n; const void* p; long long c; } tab[] = {
       {"fake", e->fake, img}, {"fake_raw", e->fake_raw, img}, {"real_noisy", e->real_noisy, img}, {"xhat", e->xhat, img},
       {"d_gx", e->d_gx, img}, {"prob", e->prob, e->B}, {"ds", e->ds, e->B}, {"norms", e->norms, e->B}, {"acc", e->acc, (long long)8 * e->acc_ld},
-      {"d_y1", e->d_y[0], (long long)e->B * 32 * 32 * 64}, {"d_a4", e->d_a[3], (long long)e->B * 8192},
-      {"g_y1", e->g_y[0], (long long)e->B * 8192}, {"g_a4", e->g_a[3], (long long)e->B * 32 * 32 * 64}};
+      {"d_y1", e->d_y[0], (long long)e->B * (TT.S / 2) * (TT.S / 2) * 64}, {"d_a4", e->d_a[TT.NS - 1], (long long)e->B * TT.FEAT},
+      {"g_y1", e->g_y[0], (long long)e->B * TT.FEAT}, {"g_a4", e->g_a[TT.NS - 1], (long long)e->B * (TT.S / 2) * (TT.S / 2) * 64}};
   for (auto& t : tab)
     if (!strcmp(t.n, name)) { if (numel) *numel = t.c; return t.p; }
   return nullptr;

@@ -724,13 +724,13 @@ __global__ void pad_rows_kernel(const float* __restrict__ in, int B, int Ci, int
 // acc rows: 0 loss_real 1 loss_fake 2 loss_g 3 p(real) 4 p(fake) 5 p(g phase) 6 (||g||-1)^2, one entry per image
 // out: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake      (train/dcgan_trainer.py:179,192-193)
 // End of a step in ONE launch: the deferred BatchNorm running-stat records of D's four layers (blockIdx.y = layer, same
-// recurrence as sequential momentum updates) and the logged scalars (blockIdx.y = 4).
+// recurrence as sequential momentum updates) and the logged scalars (blockIdx.y = number of layers).
 struct TailLayer { const float* rec; float* rm; float* rv; long long* nbt; int C; };
 // acc is the per-image table [7][acc_ld] (head_fwd / gp_norm write one entry per image): each row is summed here in a fixed
 // order (thread-strided partial sums, wavefront shuffles, 4 wave totals), so the logged scalars are bitwise reproducible.
-struct TailJobs { TailLayer l[4]; int npass; float momentum; const float* acc; int acc_ld, B; float invB, lambda_gp; float* out; };
+struct TailJobs { TailLayer l[5]; int nl; int npass; float momentum; const float* acc; int acc_ld, B; float invB, lambda_gp; float* out; };
 static __global__ __launch_bounds__(256) void step_tail_kernel(const TailJobs t) {
-  if (blockIdx.y == 4) {
+  if ((int)blockIdx.y == t.nl) {
     if (blockIdx.x != 0) return;
     __shared__ float sm[4];
     float tot[7];

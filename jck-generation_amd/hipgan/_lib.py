@@ -80,6 +80,12 @@ PROTOS = {
     "jck_head_bwd_conv": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     "jck_adam": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, i32, f32, vp]),
     "jck_engine_create": (i32, [C.POINTER(vp), i32, i32, i32]),
+    "jck_engine_create_sized": (i32, [C.POINTER(vp), i32, i32, i32, i32]),
+    "jck_engine_image_size": (i32, [vp]),
+    "jck_engine_num_tensors_of": (i32, [vp, i32]),
+    "jck_engine_tensor_info_of": (i32, [vp, i32, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64),
+                                        C.POINTER(i32)]),
+    "jck_engine_arena_numel_of": (i64, [vp, i32, i32]),
     "jck_engine_destroy": (None, [vp]),
     "jck_engine_num_tensors": (i32, [i32, i32]),
     "jck_engine_tensor_info": (i32, [i32, i32, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64),

@@ -17,14 +17,15 @@ _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PRE
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
 
-def _layout(family, net):
+def _layout(handle, net):
+    """[(state-dict key, kind, arena offset, numel, shape)] of a created engine's network (its own image size)."""
     dll = load_library()
     out = []
-    for i in range(dll.jck_engine_num_tensors(family, net)):
+    for i in range(dll.jck_engine_num_tensors_of(handle, net)):
         name = C.create_string_buffer(64)
         kind, off, numel = C.c_int(), C.c_longlong(), C.c_longlong()
         shape = (C.c_int * 4)()
-        rc = dll.jck_engine_tensor_info(family, net, i, name, 64, C.byref(kind), C.byref(off), C.byref(numel), shape)
+        rc = dll.jck_engine_tensor_info_of(handle, net, i, name, 64, C.byref(kind), C.byref(off), C.byref(numel), shape)
         if rc != 0:
             raise JckError(dll.jck_last_error().decode())
         shp = list(shape)
@@ -70,9 +71,10 @@ class DcganEngine:
 
     family = 0
 
-    def __init__(self, batch, prec="bf16", device="cuda:0", share=None):
+    def __init__(self, batch, prec="bf16", device="cuda:0", share=None, image_size=64):
         """share: another DcganEngine whose arenas (weights, gradients, Adam moments, BN statistics) this one binds
-        too - used for the ragged last batch of an epoch, which needs its own workspace geometry but the same state."""
+        too - used for the ragged last batch of an epoch, which needs its own workspace geometry but the same state.
+        image_size: 64 = the reference's nets; 128 = one more stride-2 stage (DCGAN only, BASELINE.json configs[4])."""
         if not torch.cuda.is_available():
             raise JckError("DcganEngine needs a GPU: the HIP path has no CPU fallback")
         self.device = torch.device(device) if share is None else share.device
@@ -81,6 +83,7 @@ class DcganEngine:
         torch.cuda.set_device(self.device)
         self.prec = _PREC[prec] if share is None else share.prec
         self.batch = batch
+        self.size = image_size if share is None else share.size
         self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
         self._packed_version = -1
         # hipGraph replay of the step (JCK_GRAPH=0 disables): one captured graph per (segment, step parity, input kind)
@@ -88,7 +91,7 @@ class DcganEngine:
         self._graph_cache, self._sbuf, self._st, self._eager_steps = {}, None, None, 0
         h = C.c_void_p()
         dll = load_library()
-        if dll.jck_engine_create(C.byref(h), self.family, self.prec, batch) != 0:
+        if dll.jck_engine_create_sized(C.byref(h), self.family, self.prec, batch, self.size) != 0:
             raise JckError(dll.jck_last_error().decode())
         self._h = h
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -96,17 +99,17 @@ class DcganEngine:
         for net, tag in ((0, "g"), (1, "d")):
             if share is not None:
                 break
-            n, nb = dll.jck_engine_arena_numel(self.family, net, 0), dll.jck_engine_arena_numel(self.family, net, 1)
+            n, nb = dll.jck_engine_arena_numel_of(h, net, 0), dll.jck_engine_arena_numel_of(h, net, 1)
             for what in ("params", "grads", "m", "v"):
                 self.arenas[f"{tag}_{what}"] = torch.zeros(n, **f32)
             self.arenas[f"{tag}_bn"] = torch.zeros(nb, **f32)
-            self.arenas[f"{tag}_nbt"] = torch.zeros(4, dtype=torch.int64, device=self.device)
+            self.arenas[f"{tag}_nbt"] = torch.zeros(8, dtype=torch.int64, device=self.device)
         self.ws_bytes = dll.jck_engine_workspace_bytes(h)
         self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
         a = self.arenas
         lib.jck_engine_bind(h, self.workspace, self.ws_bytes, a["g_params"], a["g_grads"], a["g_m"], a["g_v"], a["g_bn"],
                             a["g_nbt"], a["d_params"], a["d_grads"], a["d_m"], a["d_v"], a["d_bn"], a["d_nbt"])
-        self.layout = {"g": _layout(self.family, 0), "d": _layout(self.family, 1)}
+        self.layout = {"g": _layout(h, 0), "d": _layout(h, 1)}
         # BN running_var starts at 1 (nn.BatchNorm2d)
         for tag in ("g", "d"):
             for name, kind, off, numel, shp in self.layout[tag]:
@@ -170,7 +173,7 @@ class DcganEngine:
         """reference state_dict order: per layer weight, [bias, running_mean, running_var, num_batches_tracked]."""
         v = self.named_views(tag)
         keys = [k for k in ("label_embedding.weight", "label_embedding.bias") if k in v]
-        for i in range(1, 6):
+        for i in range(1, 8):
             if f"conv{i}.weight" in v:
                 keys.append(f"conv{i}.weight")
             if f"norm{i}.weight" in v:
@@ -210,7 +213,7 @@ class DcganEngine:
 
     # ---- the step ---------------------------------------------------------------------------------------
     def _inputs(self, real, noise, lr, grad_scale):
-        B = self.batch
+        B, S = self.batch, self.size
         si = StepInputs()
         keep = []
         if isinstance(real, DeviceBatch):           # indices into a uint8 dataset resident in HBM: the step transforms them itself
@@ -219,8 +222,8 @@ class DcganEngine:
             keep += [real.data, real.idx]
             si.real_u8, si.real_idx = real.data.data_ptr(), real.idx.data_ptr()
             real = None
-        elif real is not None and (real.shape != (B, 3, 64, 64) or real.dtype != torch.float32):
-            raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
+        elif real is not None and (real.shape != (B, 3, S, S) or real.dtype != torch.float32):
+            raise JckError(f"real must be float32 [{B},3,{S},{S}], got {tuple(real.shape)} {real.dtype}")
 
         def ptr(t, shape):
             if t is None:
@@ -230,10 +233,10 @@ class DcganEngine:
                 raise JckError(f"noise tensor has {t.numel()} elements, expected {shape}")
             keep.append(t)
             return t.data_ptr()
-        si.real_nchw = ptr(real, B * 3 * 64 * 64)
-        si.noise_real = ptr(noise.get("n1"), B * 3 * 64 * 64)
+        si.real_nchw = ptr(real, B * 3 * S * S)
+        si.noise_real = ptr(noise.get("n1"), B * 3 * S * S)
         si.z = ptr(noise.get("z"), B * 100)
-        si.noise_fake = ptr(noise.get("n2"), B * 3 * 64 * 64)
+        si.noise_fake = ptr(noise.get("n2"), B * 3 * S * S)
         si.alpha = ptr(noise.get("alpha"), B)
         si.lr, si.grad_scale, si.step = lr, grad_scale, self.t + 1
         if self.family == 1:
@@ -253,18 +256,18 @@ class DcganEngine:
     def draw_noise(self, generator=None, labels=None, out=None):
         """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111).  out: the engine's
         fixed-address input buffers (graph replay) - filled in place with the same draws, no extra copy."""
-        B, dev = self.batch, self.device
+        B, dev, S = self.batch, self.device, self.size
         # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
-        ni, nzz = B * 3 * 64 * 64, B * 100
+        ni, nzz = B * 3 * S * S, B * 100
         if out is None:
             buf = torch.randn(2 * ni + nzz, device=dev, generator=generator)
             alpha = torch.rand(B, 1, 1, 1, device=dev, generator=generator)
         else:
             buf = torch.randn(2 * ni + nzz, generator=generator, out=out["nbuf"])
             alpha = torch.rand(B, 1, 1, 1, generator=generator, out=out["alpha"])
-        nz = {"n1": buf[:ni].view(B, 3, 64, 64),
+        nz = {"n1": buf[:ni].view(B, 3, S, S),
               "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
-              "n2": buf[ni + nzz:].view(B, 3, 64, 64),
+              "n2": buf[ni + nzz:].view(B, 3, S, S),
               "alpha": alpha}
         if self.family == 1:
             nz["labels"] = labels
@@ -305,10 +308,10 @@ class DcganEngine:
 
     def _static(self):
         if self._sbuf is None:
-            B, dev = self.batch, self.device
+            B, dev, S = self.batch, self.device, self.size
             f32 = dict(dtype=torch.float32, device=dev)
-            sb = {"nbuf": torch.empty(2 * B * 3 * 64 * 64 + B * 100, **f32), "alpha": torch.empty(B, 1, 1, 1, **f32),
-                  "real": torch.empty(B, 3, 64, 64, **f32), "idx": torch.empty(B, dtype=torch.int64, device=dev)}
+            sb = {"nbuf": torch.empty(2 * B * 3 * S * S + B * 100, **f32), "alpha": torch.empty(B, 1, 1, 1, **f32),
+                  "real": torch.empty(B, 3, S, S, **f32), "idx": torch.empty(B, dtype=torch.int64, device=dev)}
             if self.family == 1:
                 sb["labels"] = torch.empty(B, 100, dtype=torch.int64, device=dev)
                 sb["u"] = torch.empty(B, 256, **f32)
@@ -320,8 +323,8 @@ class DcganEngine:
     def _fill_static(self, real, noise, generator, labels):
         """Puts this step's inputs into the fixed-address buffers (on the current = engine stream); -> (real, noise) that
         point into them."""
-        sb, B = self._static(), self.batch
-        ni, nzz = B * 3 * 64 * 64, B * 100
+        sb, B, S = self._static(), self.batch, self.size
+        ni, nzz = B * 3 * S * S, B * 100
         if noise is None:
             if self.family == 1:
                 if labels is None:
@@ -330,12 +333,12 @@ class DcganEngine:
             nz = self.draw_noise(generator, labels=sb.get("labels"), out=sb)
         else:
             buf = sb["nbuf"]
-            buf[:ni].view(B, 3, 64, 64).copy_(noise["n1"], non_blocking=True)
+            buf[:ni].view(B, 3, S, S).copy_(noise["n1"], non_blocking=True)
             buf[ni:ni + nzz].view(B, 100, 1, 1).copy_(noise["z"].view(B, 100, 1, 1), non_blocking=True)
-            buf[ni + nzz:].view(B, 3, 64, 64).copy_(noise["n2"], non_blocking=True)
+            buf[ni + nzz:].view(B, 3, S, S).copy_(noise["n2"], non_blocking=True)
             sb["alpha"].copy_(noise["alpha"].view(B, 1, 1, 1), non_blocking=True)
-            nz = {"n1": buf[:ni].view(B, 3, 64, 64), "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
-                  "n2": buf[ni + nzz:].view(B, 3, 64, 64), "alpha": sb["alpha"]}
+            nz = {"n1": buf[:ni].view(B, 3, S, S), "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
+                  "n2": buf[ni + nzz:].view(B, 3, S, S), "alpha": sb["alpha"]}
             if self.family == 1:
                 lab = noise.get("labels")
                 if lab is None or lab.shape != (B, 100) or lab.dtype != torch.int64:
@@ -351,8 +354,8 @@ class DcganEngine:
                 raise JckError(f"DeviceBatch must index {B} images")
             real = DeviceBatch(real.data, sb["idx"].copy_(real.idx, non_blocking=True))
         else:
-            if real.shape != (B, 3, 64, 64) or real.dtype != torch.float32:
-                raise JckError(f"real must be float32 [{B},3,64,64], got {tuple(real.shape)} {real.dtype}")
+            if real.shape != (B, 3, S, S) or real.dtype != torch.float32:
+                raise JckError(f"real must be float32 [{B},3,{S},{S}], got {tuple(real.shape)} {real.dtype}")
             real = sb["real"].copy_(real, non_blocking=True)
         return real, nz
 
@@ -542,10 +545,11 @@ class DcganEngine:
         if n > self.batch:
             raise JckError(f"sample: {n} latent vectors exceed this engine's batch {self.batch}; bind an engine with batch >= n "
                            f"(DcganEngine(batch=n, share=engine))")
+
         self.join()
         if self._packed_version != self._shared["version"]:
             self.repack()
-        out = torch.empty(n, 3, 64, 64, dtype=torch.float32, device=self.device)
+        out = torch.empty(n, 3, self.size, self.size, dtype=torch.float32, device=self.device)
         zc = z.to(self.device, torch.float32).contiguous().view(-1, 100)
         lab = None
         if self.family == 1:

@@ -250,22 +250,70 @@ class _HeadSigmoid(Function):
         return ga, gw, None
 
 
+def _stage_eval(conv, norm, x, kind, slope, prec):
+    """module.eval(): normalise with the RUNNING statistics and leave the buffers alone (nn.BatchNorm2d semantics).  The
+    reference never puts G / D in eval mode; this exists so that a checkpoint loaded for inference with
+    .eval() behaves like the torch modules it is interchangeable with.  Inference only (no autograd through it)."""
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        raise JckError("eval-mode BatchNorm is provided for inference only: wrap the call in torch.no_grad() (training runs "
+                       "with batch statistics, as the reference always does)")
+    dev, st, w = x.device, cur_stream(), conv.weight
+    x = x.contiguous()
+    if kind == "down":
+        n, hb, wb, _ = x.shape
+        cs, cb = w.shape[0], w.shape[1]
+        y = torch.empty(n, hb // 2, wb // 2, cs, dtype=_DT[prec], device=dev)
+        lib.jck_conv_down(prec, x, _pack("down", w, prec), y, None, None, n, hb, wb, cb, cs, st)
+        rows, c = n * (hb // 2) * (wb // 2), cs
+    elif kind == "up":
+        n, hs, ws_, cs = x.shape
+        cb = w.shape[1]
+        y = torch.empty(n, 2 * hs, 2 * ws_, cb, dtype=_DT[prec], device=dev)
+        lib.jck_conv_up(prec, x, _pack("up", w, prec), y, None, None, 0, n, hs, ws_, cs, cb, st)
+        rows, c = n * 4 * hs * ws_, cb
+    else:
+        n, cip = x.shape
+        c = w.shape[1]
+        y = torch.empty(n, 4, 4, c, dtype=_DT[prec], device=dev)
+        lib.jck_g1_fwd(prec, x, _pack("g1", w, prec, cip), y, None, None, n, cip, c, st)
+        rows = n * 16
+    invstd = torch.rsqrt(norm.running_var.float() + norm.eps)
+    sc = norm.weight.detach().float() * invstd
+    aux = torch.cat([sc, norm.bias.detach().float() - norm.running_mean.float() * sc, norm.running_mean.float(), invstd]).contiguous()
+    a = torch.empty_like(y)
+    lib.jck_bn_act_fwd(prec, y, aux, slope, a, rows, c, st)
+    return a
+
+
 def _stage(mod, i, x, kind, slope, prec):
     conv, norm = getattr(mod, f"conv{i}"), getattr(mod, f"norm{i}")
+    if not mod.training:
+        return _stage_eval(conv, norm, x, kind, slope, prec)
     return _ConvBnAct.apply(x, conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var,
                             norm.num_batches_tracked, kind, slope, prec)
 
 
+def _n_stages(mod):
+    """BatchNorm stages of a DCGAN module: 4 (the reference's 64x64 nets) or 5 (the 128x128 plan)."""
+    n = 0
+    while hasattr(mod, f"norm{n + 1}"):
+        n += 1
+    return n
+
+
 def dcgan_discriminator(mod, x, prec="bf16"):
-    """model/DCGAN.py:29-35 on the HIP path.  x: NCHW fp32 [B,3,64,64] on the GPU -> [B,1,1,1] fp32."""
+    """model/DCGAN.py:29-35 on the HIP path.  x: NCHW fp32 [B,3,S,S] on the GPU -> [B,1,1,1] fp32 (S = 64, or 128 for a
+    module built with image_size=128)."""
     _need_cuda(x, "Discriminator.forward")
-    if x.dim() != 4 or x.shape[1:] != (3, 64, 64):
-        raise JckError(f"Discriminator expects [B,3,64,64], got {tuple(x.shape)}")
+    n = _n_stages(mod)
+    size = 4 << n
+    if x.dim() != 4 or x.shape[1:] != (3, size, size):
+        raise JckError(f"Discriminator expects [B,3,{size},{size}], got {tuple(x.shape)}")
     p = _PREC[prec]
     h = _ToNHWC.apply(x, p)
-    for i in (1, 2, 3, 4):
+    for i in range(1, n + 1):
         h = _stage(mod, i, h, "down", 0.2, p)
-    return _HeadSigmoid.apply(h, mod.conv5.weight, p)
+    return _HeadSigmoid.apply(h, getattr(mod, f"conv{n + 1}").weight, p)
 
 
 def dcgan_generator(mod, z, prec="bf16"):
@@ -278,10 +326,11 @@ def dcgan_generator(mod, z, prec="bf16"):
     cip = 128 if ci <= 128 else 256
     zp = torch.zeros(b, cip, dtype=_DT[p], device=z.device)
     zp[:, :ci] = z.reshape(b, ci).to(_DT[p])
+    n = _n_stages(mod)
     h = _stage(mod, 1, zp, "g1", 0.0, p)
-    for i in (2, 3, 4):
+    for i in range(2, n + 1):
         h = _stage(mod, i, h, "up", 0.0, p)
-    img = _UpTanh.apply(h, mod.conv5.weight, p)
+    img = _UpTanh.apply(h, getattr(mod, f"conv{n + 1}").weight, p)
     return _ToNCHW.apply(img, p)
 
 

@@ -118,7 +118,8 @@ class DCGANTrainer(Trainer):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world, self.rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
         self.batch_size = int(getattr(args, "batch_size", 128))
-        self.engine = DcganEngine(batch=self.batch_size, prec=self.prec, device=self.device)
+        self.engine = DcganEngine(batch=self.batch_size, prec=self.prec, device=self.device,
+                                  image_size=getattr(self.model_g, "image_size", 64))     # 128: the configs[4] topology
         self.engine.adopt_modules(self.model_g, self.model_d)
         if self.world > 1:
             for key in ("g_params", "d_params", "g_bn", "d_bn"):

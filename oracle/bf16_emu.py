@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from .gan_oracle import BN_EPS, BN_MOMENTUM, LRELU
+from .gan_oracle import BN_EPS, BN_MOMENTUM, LRELU, _n_norm
 
 
 def bf(x: torch.Tensor) -> torch.Tensor:
@@ -127,20 +127,22 @@ def store(x):
 
 def generator_bf16(p, z, labels=None):
     assert labels is None, "bf16 emulation covers DCGAN only"
+    n = _n_norm(p)
     h = F.conv_transpose2d(bf(z), _RndW.apply(p["conv1.weight"]), None, 1, 0)
     h = _bn_act(p, "norm1", h, 0.0)
-    for i in (2, 3, 4):
+    for i in range(2, n + 1):
         h = F.conv_transpose2d(h, _RndW.apply(p[f"conv{i}.weight"]), None, 2, 1)
         h = _bn_act(p, f"norm{i}", h, 0.0)
-    return _TanhStore.apply(F.conv_transpose2d(h, _RndW.apply(p["conv5.weight"]), None, 2, 1))
+    return _TanhStore.apply(F.conv_transpose2d(h, _RndW.apply(p[f"conv{n + 1}.weight"]), None, 2, 1))
 
 
 def discriminator_bf16(p, x, labels=None, drop_mask=None, drop_p=0.25):
     """x must already be a stored (bf16-rounded) image: callers pass store(...)."""
-    assert "conv5.weight" in p, "bf16 emulation covers DCGAN only"
+    n = _n_norm(p)
+    assert f"conv{n + 1}.weight" in p, "bf16 emulation covers DCGAN only"
     h = x
-    for i in (1, 2, 3, 4):
+    for i in range(1, n + 1):
         h = F.conv2d(h, _RndW.apply(p[f"conv{i}.weight"]), None, 2, 1)
         h = _bn_act(p, f"norm{i}", h, LRELU)
-    # head: fp32 weights on the bf16 a4; the gradient w.r.t. a4 is rounded by _BnAct.backward of layer 4
-    return torch.sigmoid(F.conv2d(h, p["conv5.weight"], None, 1, 0))
+    # head: fp32 weights on the bf16 a4; the gradient w.r.t. a4 is rounded by _BnAct.backward of the last layer
+    return torch.sigmoid(F.conv2d(h, p[f"conv{n + 1}.weight"], None, 1, 0))

@@ -41,6 +41,21 @@ D_CH = [(64, 3), (128, 64), (256, 128), (512, 256)]          # model/DCGAN.py:10
 G_CH = [(512, 256), (256, 128), (128, 64), (64, 3)]          # model/DCGAN.py:46-58
 
 
+def channel_plan(image_size=64):
+    """-> (D_CH, G_CH, channels at the 4x4 end).  64 = the reference (above).  128 = BASELINE.json configs[4]: the reference
+    has NO 128x128 behaviour (its nets are hard-wired to 3x64x64) - this restatement grows the nets by one
+    stride-2 stage at the deep end, the usual DCGAN recipe, and is PARITY UNPINNED against the reference (nothing to pin to);
+    it is pinned per operator against torch itself (tests/test_ops_gpu.py) and serves as the oracle of the HIP 128x128 path."""
+    if image_size == 64:
+        return D_CH, G_CH, 512
+    assert image_size == 128, "image_size must be 64 or 128"
+    return D_CH + [(1024, 512)], [(1024, 512)] + G_CH, 1024
+
+
+def _n_norm(p):
+    return sum(1 for k in p if k.startswith("norm") and k.endswith(".weight"))
+
+
 # ----------------------------------------------------------------------------------------------
 # parameter construction: consumes the global RNG exactly like `Generator()`, `Discriminator()`
 # followed by `.apply(weights_init)` on G then D.
@@ -53,28 +68,30 @@ def _bn_state(p: Dict[str, torch.Tensor], name: str, c: int):
     p[f"{name}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
 
 
-def _construct_g(family: str) -> Dict[str, torch.Tensor]:
+def _construct_g(family: str, image_size: int = 64) -> Dict[str, torch.Tensor]:
     zin = 100 if family == "dcgan" else 200                  # model/CGAN.py:132
     p: Dict[str, torch.Tensor] = {}
-    chans = [(zin, 512)] + [(a, b) for a, b in G_CH]
+    _, g_ch, c_top = channel_plan(image_size)
+    chans = [(zin, c_top)] + [(a, b) for a, b in g_ch]
     for i, (ci, co) in enumerate(chans, 1):
         st, pad = (1, 0) if i == 1 else (2, 1)
         p[f"conv{i}.weight"] = torch.nn.ConvTranspose2d(ci, co, 4, st, pad, bias=False).weight.detach().clone()
-        if i <= 4:
+        if i < len(chans):
             _bn_state(p, f"norm{i}", co)
     return p
 
 
-def _construct_d(family: str) -> Dict[str, torch.Tensor]:
+def _construct_d(family: str, image_size: int = 64) -> Dict[str, torch.Tensor]:
     p: Dict[str, torch.Tensor] = {}
+    d_ch, _, c_top = channel_plan(image_size)
     if family == "cgan":                                     # model/CGAN.py:83
         lin = torch.nn.Linear(100, 200)
         p["label_embedding.weight"], p["label_embedding.bias"] = lin.weight.detach().clone(), lin.bias.detach().clone()
-    for i, (cs, cb) in enumerate(D_CH, 1):
+    for i, (cs, cb) in enumerate(d_ch, 1):
         p[f"conv{i}.weight"] = torch.nn.Conv2d(cb, cs, 4, 2, 1, bias=False).weight.detach().clone()
         _bn_state(p, f"norm{i}", cs)
     if family == "dcgan":
-        p["conv5.weight"] = torch.nn.Conv2d(512, 1, 4, 1, 0, bias=False).weight.detach().clone()
+        p[f"conv{len(d_ch) + 1}.weight"] = torch.nn.Conv2d(c_top, 1, 4, 1, 0, bias=False).weight.detach().clone()
     else:                                                    # model/CGAN.py:103-106
         l1 = torch.nn.Linear(8192 + 200, 256)
         p["linear1.weight"], p["linear1.bias"] = l1.weight.detach().clone(), l1.bias.detach().clone()
@@ -99,10 +116,10 @@ def is_param(k: str) -> bool:
     return not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))
 
 
-def build_params(family: str = "dcgan"):
+def build_params(family: str = "dcgan", image_size: int = 64):
     """-> (g_state, d_state) with the reference's state-dict keys; draws from the global RNG."""
-    g = _construct_g(family)
-    d = _construct_d(family)
+    g = _construct_g(family, image_size)
+    d = _construct_d(family, image_size)
     _weights_init(g)
     _weights_init(d)
     return g, d
@@ -123,23 +140,25 @@ def generator(p, z, labels=None):
     """model/DCGAN.py:61-67, model/CGAN.py:151-162."""
     if labels is not None:
         z = torch.cat([z, labels.reshape(-1, 100, 1, 1)], 1)      # int64 one-hot promoted to float
+    n = _n_norm(p)                                             # 4 (the reference), 5 for the 128x128 plan
     h = F.conv_transpose2d(z, p["conv1.weight"], None, 1, 0)
     h = F.relu(_bn(p, "norm1", h))
-    for i in (2, 3, 4):
+    for i in range(2, n + 1):
         h = F.conv_transpose2d(h, p[f"conv{i}.weight"], None, 2, 1)
         h = F.relu(_bn(p, f"norm{i}", h))
-    return torch.tanh(F.conv_transpose2d(h, p["conv5.weight"], None, 2, 1))
+    return torch.tanh(F.conv_transpose2d(h, p[f"conv{n + 1}.weight"], None, 2, 1))
 
 
 def discriminator(p, x, labels=None, drop_mask=None, drop_p=0.25):
     """model/DCGAN.py:29-35, model/CGAN.py:109-123.  `drop_mask` (0/1, [B,256]) replaces the RNG draw
     of nn.Dropout(0.25) when given; None draws from the global generator like the reference."""
     h = x
-    for i in (1, 2, 3, 4):
+    n = _n_norm(p)
+    for i in range(1, n + 1):
         h = F.conv2d(h, p[f"conv{i}.weight"], None, 2, 1)
         h = F.leaky_relu(_bn(p, f"norm{i}", h), LRELU)
-    if "conv5.weight" in p:
-        return torch.sigmoid(F.conv2d(h, p["conv5.weight"], None, 1, 0))
+    if f"conv{n + 1}.weight" in p:
+        return torch.sigmoid(F.conv2d(h, p[f"conv{n + 1}.weight"], None, 1, 0))
     e = F.leaky_relu(F.linear(labels.float(), p["label_embedding.weight"], p["label_embedding.bias"]), LRELU)
     con = torch.cat([h.flatten(1), e], 1)
     h = F.linear(con, p["linear1.weight"], p["linear1.bias"])
@@ -198,7 +217,8 @@ class GanOracle:
     the reference's order (n1, z, n2, [dropout masks inside each D call], alpha).
     """
 
-    def __init__(self, family="dcgan", lr=2e-4, seed: Optional[int] = 12345, skip_dead_wgrad=False, emulate_bf16=False):
+    def __init__(self, family="dcgan", lr=2e-4, seed: Optional[int] = 12345, skip_dead_wgrad=False, emulate_bf16=False,
+                 image_size=64):
         """emulate_bf16: round to bf16 wherever the HIP fast path stores a tensor in bf16 (oracle/bf16_emu.py; DCGAN only) -
         the envelope for the fast path's distance from this fp32 restatement.  Default off = the pinned oracle."""
         assert family in ("dcgan", "cgan")
@@ -212,7 +232,8 @@ class GanOracle:
         if seed is not None:
             torch.manual_seed(seed)
         self.family = family
-        self.g, self.d = build_params(family)
+        assert image_size == 64 or family == "dcgan", "the 128x128 plan exists for DCGAN only"
+        self.g, self.d = build_params(family, image_size)
         self.gp_params = {k: v for k, v in self.g.items() if is_param(k)}
         self.dp_params = {k: v for k, v in self.d.items() if is_param(k)}
         self.opt_g = Adam(self.gp_params, lr)

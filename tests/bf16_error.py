@@ -18,10 +18,10 @@ import torch
 SCALARS = ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2")
 
 
-def noise_for(family, B, seed, labels=None):
+def noise_for(family, B, seed, labels=None, size=64):
     g = torch.Generator().manual_seed(seed)
-    nz = {"n1": torch.randn(B, 3, 64, 64, generator=g), "z": torch.randn(B, 100, 1, 1, generator=g),
-          "n2": torch.randn(B, 3, 64, 64, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g)}
+    nz = {"n1": torch.randn(B, 3, size, size, generator=g), "z": torch.randn(B, 100, 1, 1, generator=g),
+          "n2": torch.randn(B, 3, size, size, generator=g), "alpha": torch.rand(B, 1, 1, 1, generator=g)}
     if family == "cgan":
         nz["labels"] = labels
         for i in range(4):
@@ -66,20 +66,20 @@ def _force_engine(eng, orc):
     eng.t = orc.opt_d.t
 
 
-def measure(family, B, steps=2, lr=2e-4, with_emu=True):
+def measure(family, B, steps=2, lr=2e-4, with_emu=True, size=64):
     """-> list (one entry per teacher-forced step) of {"scalars": {k: {hip_vs_ref, ...}}, "d_grads": {...}, "g_grads": {...}}."""
     from hipgan.engine import CganEngine, DcganEngine
     from oracle.gan_oracle import GanOracle
     from util import synth_images
-    ref = GanOracle(family, lr=lr, seed=12345)
-    emu = GanOracle(family, lr=lr, seed=12345, emulate_bf16=True) if (with_emu and family == "dcgan") else None
-    eng = (CganEngine if family == "cgan" else DcganEngine)(batch=B, prec="bf16")
-    imgs = synth_images(B * steps)
+    ref = GanOracle(family, lr=lr, seed=12345, image_size=size)
+    emu = GanOracle(family, lr=lr, seed=12345, emulate_bf16=True, image_size=size) if (with_emu and family == "dcgan") else None
+    eng = (CganEngine if family == "cgan" else DcganEngine)(batch=B, prec="bf16", **({"image_size": size} if size != 64 else {}))
+    imgs = synth_images(B * steps) if size == 64 else torch.nn.functional.interpolate(synth_images(B * steps), size=size, mode="nearest")
     out = []
     for s in range(steps):
         real = imgs[s * B:(s + 1) * B]
         lab = labels_for(B, 77 + s) if family == "cgan" else None
-        nz = noise_for(family, B, 100 + s, lab)
+        nz = noise_for(family, B, 100 + s, lab, size)
         _force_engine(eng, ref)
         if emu is not None:
             _force_oracle(emu, ref)
