@@ -286,6 +286,23 @@ int jck_engine_sample(jck_engine*, const float* z, const int64_t* labels /* fami
 /* debug / parity access to internal NHWC tensors: name in {"fake","real_noisy",...}; returns device ptr or NULL */
 const void* jck_engine_tensor(const jck_engine*, const char* name, long long* numel);
 
+/* ---- evaluation branch: the metric network (reference metrics.py:46-51,80-94: torchvision inception_v3 with a
+ * Linear(2048,100) head, eval mode) as a chain of NHWC fp32 kernels; jck-generation_amd/inception.py holds the topology and
+ * the local-weights loader.  conv2d: out[n,oy,ox, out_coff + co] = act(scale[co] * sum_{kh,kw,ci} x[n, oy*SH-PH+kh, ox*SW-PW+kw, ci]
+ * * w_kc[(kh*KW + kw)*Cin + ci][co] + shift[co]) - eval-mode BatchNorm folded into scale / shift (NULL: 1 / 0), exact-fp32
+ * MFMA, the output written into a channel slice of a [.., out_cstride] tensor (Inception concatenations need no copy).
+ * pool2d mode 0: max (aten::max_pool2d, no padding value enters), mode 1: average with count_include_pad = True
+ * (F.avg_pool2d default).  mean_cov: column means and the unbiased covariance of x[N][D] in fp64 (np.mean / np.cov of
+ * metrics.py:120-126 on the device). */
+int jck_conv2d_nhwc_f32(const float* x, const float* w_kc, const float* scale, const float* shift, float* out, int N, int H, int W,
+                        int Cin, int KH, int KW, int SH, int SW, int PH, int PW, int Cout, int out_cstride, int out_coff, int relu,
+                        void* stream);
+int jck_pool2d_nhwc_f32(const float* x, float* out, int N, int H, int W, int C, int k, int stride, int pad, int mode, int out_cstride,
+                        int out_coff, void* stream);
+int jck_global_avgpool_nhwc_f32(const float* x, float* out, int N, int HW, int C, void* stream);
+int jck_nchw_to_nhwc_f32(const float* x, float* out, int N, int C, int H, int W, void* stream);
+int jck_mean_cov_f64(const float* x, double* mean, double* cov, int N, int D, void* stream);
+
 /* Per-step optimiser scalars into device memory (so that a captured graph of the step has no per-step kernel argument), and
  * hipGraph capture of a sequence of jck_engine_phase calls: begin -> phases on `stream` (not the default stream) -> end
  * returns an executable graph; launch replays it.  The jck_step_inputs pointers are baked: keep the buffers in place,

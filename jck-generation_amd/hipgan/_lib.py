@@ -103,6 +103,11 @@ PROTOS = {
     "jck_debug_tr_read": (i32, [vp, i32, vp, vp]),
     "jck_debug_wgrad_stamps": (i32, [vp, i32]),
     "jck_tune": (i32, [C.c_char_p, i32]),
+    "jck_conv2d_nhwc_f32": (i32, [vp, vp, vp, vp, vp] + [i32] * 14 + [vp]),
+    "jck_pool2d_nhwc_f32": (i32, [vp, vp] + [i32] * 10 + [vp]),
+    "jck_global_avgpool_nhwc_f32": (i32, [vp, vp, i32, i32, i32, vp]),
+    "jck_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "jck_mean_cov_f64": (i32, [vp, vp, vp, i32, i32, vp]),
     "jck_engine_set_step": (i32, [vp, i32, f32, vp]),
     "jck_engine_capture_begin": (i32, [vp, vp]),
     "jck_engine_capture_end": (i32, [vp, vp, C.POINTER(vp)]),

@@ -8,7 +8,7 @@ PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libjckgan_hip.so")
-SOURCES = ["ops.hip", "engine.hip"]
+SOURCES = ["ops.hip", "engine.hip", "infer.hip"]
 
 
 def _newest(paths):

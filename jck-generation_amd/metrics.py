@@ -2,10 +2,12 @@
 `.inception_score(loader, splits=10)`, `.fid(loader, intra_fid=False, label=0)`, `.intra_fid(tensor)`.
 
 The arithmetic is the reference's (100-d logits of a CIFAR-100 fine-tuned Inception-v3, softmax/KL per split, mean/cov +
-scipy sqrtm, 20 superclass FIDs summed and divided by 100).  The feature extractor is pluggable: by default it is built as
-the reference builds it (torchvision inception_v3 with a Linear(2048,100) head loaded from ./save/iception_v3/loss_bset.pt);
-when torchvision or the weights are missing, construction raises MetricsUnavailable and the trainer carries on without
-scores.  Fixes the reference's `.targets` defect for DCGAN (its loader has none): targets are optional."""
+scipy sqrtm, 20 superclass FIDs summed and divided by 100).  The feature extractor is pluggable; by default it is the
+reference's network (inception_v3 with a Linear(2048,100) head, weights from ./save/iception_v3/loss_bset.pt, metrics.py:
+46-51) run by the hand-written HIP chain of `inception.InceptionV3Hip` - no torchvision needed; when the weights file is
+missing, construction raises MetricsUnavailable and the trainer carries on without scores.  Feature means and covariances are
+formed in fp64 on the device (jck_mean_cov_f64) when the features live there; the matrix square root stays on the host
+(scipy), as in the reference.  Fixes the reference's `.targets` defect for DCGAN (its loader has none): targets are optional."""
 import os
 import pickle
 
@@ -27,23 +29,34 @@ class MetricsUnavailable(RuntimeError):
 
 
 def default_extractor(device, weights="./save/iception_v3/loss_bset.pt"):
-    try:
-        from torchvision import models
-    except Exception as e:
-        raise MetricsUnavailable(f"torchvision is not installed ({e})")
+    """The reference's metric network from a LOCAL weights file (torchvision key names), on the HIP kernels."""
     if not os.path.exists(weights):
-        raise MetricsUnavailable(f"fine-tuned Inception weights not found at {weights}")
-    net = models.inception_v3()
-    net.aux_logits = False
-    net.fc = torch.nn.Sequential(torch.nn.Linear(net.fc.in_features, 100))
-    net.load_state_dict(torch.load(weights, map_location="cpu"))
-    return net.to(device).eval()
+        raise MetricsUnavailable(f"fine-tuned Inception weights not found at {weights} (the reference loads them at metrics.py:51; "
+                                 f"they are not part of its repository)")
+    if not torch.cuda.is_available():
+        raise MetricsUnavailable("the metric network runs on the GPU (no CPU fallback)")
+    from inception import InceptionV3Hip
+    return InceptionV3Hip.from_file(weights, device)
+
+
+def mean_cov(x):
+    """(mean [D], covariance [D,D]) in float64 as np.mean(axis=0) / np.cov(rowvar=False) give them (metrics.py:120-126).  A
+    CUDA tensor is reduced on the device (jck_mean_cov_f64: fp64 accumulation, fixed summation order); anything else by numpy."""
+    if torch.is_tensor(x) and x.is_cuda:
+        from hipgan._lib import cur_stream, lib
+        x = x.to(torch.float32).contiguous()
+        n, d = x.shape
+        mu = torch.empty(d, dtype=torch.float64, device=x.device)
+        cov = torch.empty(d, d, dtype=torch.float64, device=x.device)
+        lib.jck_mean_cov_f64(x, mu, cov, n, d, cur_stream())
+        return mu.cpu().numpy(), cov.cpu().numpy()
+    x = x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    return np.mean(x, axis=0), np.cov(x, rowvar=False)
 
 
 def fid_from_features(real, fake):
     """Frechet distance between the Gaussians fitted to two feature matrices (reference metrics.py:120-129)."""
-    mu1, sigma1 = np.mean(real, axis=0), np.cov(real, rowvar=False)
-    mu2, sigma2 = np.mean(fake, axis=0), np.cov(fake, rowvar=False)
+    (mu1, sigma1), (mu2, sigma2) = mean_cov(real), mean_cov(fake)
     covmean = sqrtm(sigma1.dot(sigma2))
     if np.iscomplexobj(covmean):
         covmean = covmean.real
@@ -100,7 +113,7 @@ class Metrics:
             x = (x - mean) / std
         return x
 
-    def _extract(self, images, real=False, softmax=False):
+    def _extract(self, images, real=False, softmax=False, keep_on_device=False):
         feats = []
         for image in images:
             if real:
@@ -112,15 +125,29 @@ class Metrics:
                     feature = self.inception_model(image.to(self.device))
             if softmax:
                 feature = torch.nn.functional.softmax(feature.float(), dim=1)
-            feats.append(feature.detach().cpu().numpy())
-        return np.vstack(feats)
+            feats.append(feature.detach())
+        feats = torch.cat([f if torch.is_tensor(f) else torch.as_tensor(f) for f in feats])
+        return feats if (keep_on_device and feats.is_cuda) else feats.cpu().numpy()
 
     def inception_score(self, images, splits=10):
         return inception_score_from_probs(self._extract(images, softmax=True), splits)
 
+    def _real_on_device(self):
+        """the cached real features, uploaded once when a GPU is there (their mean / covariance are then formed on it)"""
+        if not torch.cuda.is_available():
+            return None
+        if getattr(self, "_real_dev", None) is None:
+            self._real_dev = torch.as_tensor(np.asarray(self.real_features, dtype=np.float32)).to(self.device)
+        return self._real_dev
+
     def fid(self, generated_images, intra_fid=False, label=0):
-        gen = self._extract(generated_images)
-        real = self.real_features[self.real_superclass_idx[label]] if intra_fid else self.real_features
+        gen = self._extract(generated_images, keep_on_device=True)
+        dev = self._real_on_device() if (torch.is_tensor(gen) and gen.is_cuda) else None
+        if intra_fid:
+            idx = self.real_superclass_idx[label]
+            real = dev[torch.as_tensor(idx, device=dev.device)] if dev is not None else self.real_features[idx]
+        else:
+            real = dev if dev is not None else self.real_features
         return fid_from_features(real, gen)
 
     def intra_fid(self, generated_images):
