@@ -1026,7 +1026,9 @@ extern "C" int jck_engine_capture_begin(jck_engine* e, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (!stream) JCK_FAIL(JCK_E_ARG, "cannot capture on the default stream");
   if (jck_prof_is_on()) JCK_FAIL(JCK_E_ARG, "per-launch profiling (jck_prof_enable) records timing events: not capturable");
-  HIPCHK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  // relaxed: a call that is "unsafe" during a capture (a free, a stream destroy from a garbage-collected object, ...) issued
+  // by this thread must not invalidate the graph being captured
+  HIPCHK(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
   e->capturing = true;
   return JCK_OK;
 }

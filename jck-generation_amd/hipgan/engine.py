@@ -40,6 +40,27 @@ def _layout(handle, net):
     return out
 
 
+# Engines are destroyed by the garbage collector, which can run at any allocation - also in the middle of a stream capture of
+# ANOTHER engine.  Destroying streams / events / graphs there (hipStreamSynchronize, hipStreamDestroy, hipGraphExecDestroy) is
+# an "unsafe call" inside a capture: it invalidates the graph being captured and the next hipGraphLaunch of it crashes.  So
+# destruction is deferred while a capture is open.
+_CAPTURES_OPEN = 0
+_DEFERRED_DESTROY = []
+
+
+def _destroy_native(graphs, handle):
+    dll = load_library()
+    for ge in graphs:
+        dll.jck_graph_destroy(ge)
+    if handle:
+        dll.jck_engine_destroy(handle)
+
+
+def _flush_deferred():
+    while _DEFERRED_DESTROY and _CAPTURES_OPEN == 0:
+        _destroy_native(*_DEFERRED_DESTROY.pop())
+
+
 class _GraphUnavailable(JckError):
     """Capture of a step segment failed before anything of the step ran: the engine falls back to eager launches."""
 
@@ -127,12 +148,12 @@ class DcganEngine:
 
     def __del__(self):
         try:
-            for ge in getattr(self, "_graph_cache", {}).values():
-                load_library().jck_graph_destroy(ge)
-            self._graph_cache = {}
-            if getattr(self, "_h", None):
-                load_library().jck_engine_destroy(self._h)
-                self._h = None
+            graphs, handle = list(getattr(self, "_graph_cache", {}).values()), getattr(self, "_h", None)
+            self._graph_cache, self._h = {}, None
+            if _CAPTURES_OPEN > 0:
+                _DEFERRED_DESTROY.append((graphs, handle))
+            else:
+                _destroy_native(graphs, handle)
         except Exception:
             pass
 
@@ -389,8 +410,10 @@ class DcganEngine:
                 key = (seg_id, step & 1, kind, float(grad_scale), tuple(phases))
                 ge = self._graph_cache.get(key)
                 if ge is None:
+                    global _CAPTURES_OPEN
                     try:
                         lib.jck_engine_capture_begin(h, st)
+                        _CAPTURES_OPEN += 1
                         try:
                             for ph in phases:
                                 lib.jck_engine_phase(h, ph, C.byref(si), st)
@@ -399,6 +422,9 @@ class DcganEngine:
                         except Exception:
                             lib.jck_engine_capture_abort(h, st)
                             raise
+                        finally:
+                            _CAPTURES_OPEN -= 1
+                            _flush_deferred()
                     except JckError as e:
                         if launched:        # part of the step already ran: no clean fallback
                             raise

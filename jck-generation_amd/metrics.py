@@ -39,19 +39,34 @@ def default_extractor(device, weights="./save/iception_v3/loss_bset.pt"):
     return InceptionV3Hip.from_file(weights, device)
 
 
+def mean_cov_device(x):
+    """(mean [D], covariance [D,D]) of a CUDA tensor as fp64 DEVICE tensors (jck_mean_cov_f64; no host sync)."""
+    from hipgan._lib import cur_stream, lib
+    x = x.to(torch.float32).contiguous()
+    n, d = x.shape
+    mu = torch.empty(d, dtype=torch.float64, device=x.device)
+    cov = torch.empty(d, d, dtype=torch.float64, device=x.device)
+    lib.jck_mean_cov_f64(x, mu, cov, n, d, cur_stream())
+    return mu, cov
+
+
 def mean_cov(x):
     """(mean [D], covariance [D,D]) in float64 as np.mean(axis=0) / np.cov(rowvar=False) give them (metrics.py:120-126).  A
-    CUDA tensor is reduced on the device (jck_mean_cov_f64: fp64 accumulation, fixed summation order); anything else by numpy."""
+    CUDA tensor is reduced on the device (fp64 accumulation, fixed summation order); anything else by numpy."""
     if torch.is_tensor(x) and x.is_cuda:
-        from hipgan._lib import cur_stream, lib
-        x = x.to(torch.float32).contiguous()
-        n, d = x.shape
-        mu = torch.empty(d, dtype=torch.float64, device=x.device)
-        cov = torch.empty(d, d, dtype=torch.float64, device=x.device)
-        lib.jck_mean_cov_f64(x, mu, cov, n, d, cur_stream())
+        mu, cov = mean_cov_device(x)
         return mu.cpu().numpy(), cov.cpu().numpy()
     x = x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
     return np.mean(x, axis=0), np.cov(x, rowvar=False)
+
+
+def fid_from_stats(mu1, sigma1, mu2, sigma2):
+    """reference metrics.py:127-129 from the two Gaussians' parameters"""
+    mu1, sigma1, mu2, sigma2 = (np.asarray(v, dtype=np.float64) for v in (mu1, sigma1, mu2, sigma2))
+    covmean = sqrtm(sigma1.dot(sigma2))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return float(np.sum((mu1 - mu2) ** 2.0) + np.trace(sigma1 + sigma2 - 2.0 * covmean))
 
 
 def fid_from_features(real, fake):
@@ -128,6 +143,73 @@ class Metrics:
             feats.append(feature.detach())
         feats = torch.cat([f if torch.is_tensor(f) else torch.as_tensor(f) for f in feats])
         return feats if (keep_on_device and feats.is_cuda) else feats.cpu().numpy()
+
+    # ---- one forward pass, every score (the evaluation branch of the trainers: the reference runs the network once per score on
+    # the same images - metrics.py:98,114 - which yields the same features each time)
+    def logits(self, images, batch=128):
+        """images: a tensor [N,3,299,299] already prepared for the network (device or host) -> logits [N,100] where the
+        extractor left them."""
+        out = []
+        for i in range(0, images.shape[0], batch):
+            chunk = images[i:i + batch]
+            if self.inception_model is None:
+                out.append(chunk)
+                continue
+            with torch.no_grad():
+                out.append(self.inception_model(chunk.to(self.device)).detach())
+        return torch.cat(out)
+
+    def fake_stats_device(self, logits, intra=False):
+        """Device part of the FID of generated logits (CUDA): {'mu', 'cov'[, 'mu_s<k>', 'cov_s<k>' per superclass]} as fp64 device
+        tensors - no host sync, so it can sit on a side stream; finish with scores_from_stats()."""
+        out = {}
+        out["mu"], out["cov"] = mean_cov_device(logits)
+        if intra:
+            for s_ in range(20):
+                idx = torch.as_tensor(self.fake_superclass_idx[s_], device=logits.device)
+                out[f"mu_s{s_}"], out[f"cov_s{s_}"] = mean_cov_device(logits[idx])
+        return out
+
+    def _real_stats(self, label=None):
+        """(mean, cov) of the cached real features (of one superclass), computed once - on the device when there is one"""
+        cache = self.__dict__.setdefault("_real_stats_cache", {})
+        if label not in cache:
+            dev = self._real_on_device()
+            if label is None:
+                cache[label] = mean_cov(dev if dev is not None else self.real_features)
+            else:
+                idx = self.real_superclass_idx[label]
+                cache[label] = mean_cov(dev[torch.as_tensor(idx, device=dev.device)] if dev is not None else self.real_features[idx])
+        return cache[label]
+
+    def scores_from_stats(self, logits, stats, splits=10, intra=False):
+        """Host part: logits (host) -> inception score; stats (host copies of fake_stats_device) -> FID[, intra-FID]."""
+        probs = torch.nn.functional.softmax(torch.as_tensor(logits).float(), dim=1).numpy()
+        is_ = inception_score_from_probs(probs, splits)
+        g = lambda v: v.numpy() if torch.is_tensor(v) else v
+        fid = fid_from_stats(*self._real_stats(), g(stats["mu"]), g(stats["cov"]))
+        if not intra:
+            return is_, fid
+        total = sum(fid_from_stats(*self._real_stats(s_), g(stats[f"mu_s{s_}"]), g(stats[f"cov_s{s_}"])) for s_ in range(20))
+        return is_, fid, total / 100
+
+    def scores_from_logits(self, logits, splits=10, intra=False):
+        """-> (inception score, FID[, intra-FID]) from the logits of the generated images; the same arithmetic as
+        inception_score() / fid() / intra_fid()."""
+        probs = torch.nn.functional.softmax(logits.float(), dim=1).cpu().numpy()
+        is_ = inception_score_from_probs(probs, splits)
+        on_dev = logits.is_cuda and self._real_on_device() is not None
+        feats = logits if on_dev else logits.detach().cpu().numpy()
+        fid = fid_from_features(self._real_on_device() if on_dev else self.real_features, feats)
+        if not intra:
+            return is_, fid
+        total = 0
+        for s_ in range(20):
+            sub = feats[torch.as_tensor(self.fake_superclass_idx[s_], device=logits.device)] if on_dev else feats[self.fake_superclass_idx[s_]]
+            idx = self.real_superclass_idx[s_]
+            real = self._real_on_device()[torch.as_tensor(idx, device=logits.device)] if on_dev else self.real_features[idx]
+            total += fid_from_features(real, sub)
+        return is_, fid, total / 100
 
     def inception_score(self, images, splits=10):
         return inception_score_from_probs(self._extract(images, softmax=True), splits)

@@ -17,6 +17,7 @@ from logger.main_logger import MainLogger
 from logger.utils import time_to_str
 from model.CGAN import weights_init
 from train.dcgan_trainer import EVAL_EVERY, LOG_EVERY, DCGANTrainer, _as_tensor, _make_grid, _save_png, inception_input
+from train.async_eval import AsyncEval, snapshot_to_cpu
 from train.trainer import Trainer
 from utils import require_gpu
 
@@ -75,7 +76,7 @@ class CGANTrainer(DCGANTrainer):
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------
-    def save_model(self, typ, iters, inception_score, fid, intra_fid, images):
+    def save_model(self, typ, iters, inception_score, fid, intra_fid, images, snapshot=None):
         if self.rank != 0:
             return
         self.engine.join()                      # the G phase of the last step may still be in flight on its stream
@@ -85,10 +86,11 @@ class CGANTrainer(DCGANTrainer):
             fp = os.path.join(save_path, filename)
             if os.path.isfile(fp) and filename.endswith(".pt"):
                 os.remove(fp)
-        torch.save({"model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
-                    "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
-                    "optimizer_g": self.optimizer_g.state_dict(), "optimizer_d": self.optimizer_d.state_dict()},
-                   os.path.join(save_path, f"{iters}_{inception_score:.04f}_{fid:.04f}_{intra_fid:.04f}.pt"))
+        state = snapshot_to_cpu(snapshot) if snapshot is not None else {
+            "model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
+            "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
+            "optimizer_g": self.optimizer_g.state_dict(), "optimizer_d": self.optimizer_d.state_dict()}
+        torch.save(state, os.path.join(save_path, f"{iters}_{inception_score:.04f}_{fid:.04f}_{intra_fid:.04f}.pt"))
         self.save_image(save_path, iters, images)
 
     def save_image(self, path, iters, images):
@@ -118,30 +120,51 @@ class CGANTrainer(DCGANTrainer):
 
     # ------------------------------------------------------------------------------------------------------
     def _evaluate(self, fixed_noise, fixed_labels, iters, best, image_save_path):
+        """Device part of the evaluation (reference :222-252) on a side stream (train/async_eval.py): 1000 images = ONE
+        BatchNorm batch as in the reference, the fused 299x299 resize + normalise, ONE pass of the metric network, fp64 mean /
+        covariance of the logits (all 1000 and per superclass) - training resumes behind the sampling kernels only."""
+        self._finish_eval(best, wait=True)
         eng = self._engine_for(fixed_noise.size(0))
-        fake = eng.sample(fixed_noise, fixed_labels)                # 1000 images = ONE BatchNorm batch, as in the reference
-        denorm = (0.5 * fake + 0.5).cpu()
-        if self.metric is not None:
-            x = inception_input(fake).cpu()                         # :227-231 in one device pass
-            mk = lambda: torch.utils.data.DataLoader(x, batch_size=128, shuffle=False)
-            inception_score, fid, intra = self.metric.inception_score(mk()), self.metric.fid(mk()), self.metric.intra_fid(x)
+        self._image_save_path = image_save_path
+
+        def device_part(fake):
+            out = {"denorm": (0.5 * fake + 0.5)[::10].contiguous()}
+            if self.metric is not None:
+                logits = self.metric.logits(inception_input(fake))       # :227-231 in one device pass, then the metric network
+                out["logits"] = logits
+                if logits.is_cuda:
+                    out.update(self.metric.fake_stats_device(logits, intra=True))
+            return out
+        self._eval.launch(iters, lambda: eng.sample(fixed_noise, fixed_labels), device_part)
+
+    def _finish_eval(self, best, wait):
+        p = self._eval.take(wait)
+        if p is None:
+            return
+        iters, host, snap = p["iters"], p["host"], p["snapshot"]
+        denorm = host["denorm"]
+        if "logits" in host:
+            if "mu" in host:
+                inception_score, fid, intra = self.metric.scores_from_stats(host["logits"], host, intra=True)
+            else:
+                inception_score, fid, intra = self.metric.scores_from_logits(host["logits"], intra=True)
             self.logger.debug(f"inception score: {inception_score}\tfid: {fid}\tintra fid: {intra}")
             if best["fid"] > fid:
                 best["fid"] = fid
                 self.logger.debug(f"{iters} lowest fid")
-                self.save_model("fid", iters, inception_score, fid, intra, denorm[::10])
+                self.save_model("fid", iters, inception_score, fid, intra, denorm, snap)
             if best["intra"] > intra:
                 best["intra"] = intra
                 self.logger.debug(f"{iters} lowest intra fid")
-                self.save_model("intra_fid", iters, inception_score, fid, intra, denorm[::10])
+                self.save_model("intra_fid", iters, inception_score, fid, intra, denorm, snap)
             if best["is"] < inception_score:
                 best["is"] = inception_score
                 self.logger.debug(f"{iters} highest is")
-                self.save_model("is", iters, inception_score, fid, intra, denorm[::10])
+                self.save_model("is", iters, inception_score, fid, intra, denorm, snap)
         else:
-            self.save_model("latest", iters, 0.0, 0.0, 0.0, denorm[::10])
+            self.save_model("latest", iters, 0.0, 0.0, 0.0, denorm, snap)
         if self.rank == 0:
-            self.save_image(image_save_path, iters, denorm[::10])
+            self.save_image(self._image_save_path, iters, denorm)
 
     def train(self):
         loader = self.train_loader
@@ -152,6 +175,7 @@ class CGANTrainer(DCGANTrainer):
         fixed_noise = torch.vstack(noises).to(dev)
         fixed_labels = torch.nn.functional.one_hot(torch.arange(100).repeat_interleave(10), 100).to(torch.int64).to(dev)
         best = {"fid": 1e10, "intra": 1e10, "is": 0}
+        self._eval = AsyncEval(self)
         if self.rank == 0:
             real_batch = next(iter(loader))
             _save_png(os.path.join(self.model_save_path, "real_image.png"), _make_grid(_as_tensor(real_batch[0])[:64], padding=5, normalize=True),
@@ -188,12 +212,15 @@ class CGANTrainer(DCGANTrainer):
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:
+                    self._finish_eval(best, wait=False)              # host part of a finished evaluation (scores, checkpoint)
                     s = eng.scalars()
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
                                       + f"\tD(x): {s['d_x']:.4f}\tD(G(z)): {s['d_gz1']:.4f} / {s['d_gz2']:.4f}")
                 if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
                     self._evaluate(fixed_noise, fixed_labels, iters, best, image_save_path)
                 iters += 1
+        self._finish_eval(best, wait=True)
+        self.engine.join()
         torch.cuda.synchronize()
         self.logger.debug(f"train finish\ttiem: {time_to_str(time.time() - start)}")
         hist = history[:iters].cpu()

@@ -24,6 +24,7 @@ from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
 from logger.utils import time_to_str
 from model.DCGAN import weights_init
+from train.async_eval import AsyncEval, snapshot_to_cpu
 from train.trainer import Trainer
 from utils import require_gpu
 
@@ -162,7 +163,8 @@ class DCGANTrainer(Trainer):
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------
-    def save_model(self, typ, iters, value, images):
+    def save_model(self, typ, iters, value, images, snapshot=None):
+        """snapshot: the state captured at the evaluation iteration (train/async_eval.py); None = the live state."""
         if self.rank != 0:
             return
         self.engine.join()                      # the G phase of the last step may still be in flight on its stream
@@ -172,11 +174,11 @@ class DCGANTrainer(Trainer):
             fp = os.path.join(save_path, filename)
             if os.path.isfile(fp) and filename.endswith(".pt"):
                 os.remove(fp)
-        torch.save({"model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
-                    "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
-                    "optimizer_g": self.optimizer_g.state_dict(),
-                    "optimizer_d": self.optimizer_d.state_dict()},
-                   os.path.join(save_path, f"{iters}_{value:.04f}.pt"))
+        state = snapshot_to_cpu(snapshot) if snapshot is not None else {
+            "model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
+            "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
+            "optimizer_g": self.optimizer_g.state_dict(), "optimizer_d": self.optimizer_d.state_dict()}
+        torch.save(state, os.path.join(save_path, f"{iters}_{value:.04f}.pt"))
         _save_png(os.path.join(save_path, f"{iters}_fake_image.png"), _make_grid(images, padding=2, normalize=True), "fake images")
         self.logger.debug(f"{iters} model save")
 
@@ -200,29 +202,50 @@ class DCGANTrainer(Trainer):
 
     # ------------------------------------------------------------------------------------------------------
     def _evaluate(self, fixed_noise, iters, best):
-        fake = self._engine_for(fixed_noise.size(0)).sample(fixed_noise)     # one train-mode BN batch, like the reference (:199-200)
-        if self.metric is None:
-            self.save_model("latest", iters, 0.0, fake.cpu())
+        """Device part of the evaluation (reference :198-212) on a side stream; training resumes behind the sampling kernels
+        only (train/async_eval.py).  The host part runs in _finish_eval."""
+        self._finish_eval(best, wait=True)          # the evaluation of 500 iterations ago, if its host part is still owed
+        eng = self._engine_for(fixed_noise.size(0))
+
+        def device_part(fake):
+            if self.metric is None:
+                return {"images": fake}
+            x = inception_input(fake)                # :202-206 in one device pass
+            logits = self.metric.logits(x)           # ONE pass of the metric network: IS and FID are scored on the same features
+            out = {"images": x, "logits": logits}
+            if logits.is_cuda:
+                out.update(self.metric.fake_stats_device(logits))      # fp64 mean / covariance on the device
+            return out
+        self._eval.launch(iters, lambda: eng.sample(fixed_noise), device_part)      # sample: one train-mode BN batch (:199-200)
+
+    def _finish_eval(self, best, wait):
+        p = self._eval.take(wait)
+        if p is None:
             return
-        fake = inception_input(fake).cpu()                       # :202-206 in one device pass
-        loader = torch.utils.data.DataLoader(fake, batch_size=64)
-        inception_score = self.metric.inception_score(loader)
-        fid = self.metric.fid(torch.utils.data.DataLoader(fake, batch_size=64))
+        iters, host, snap = p["iters"], p["host"], p["snapshot"]
+        if "logits" not in host:
+            self.save_model("latest", iters, 0.0, host["images"], snap)
+            return
+        if "mu" in host:
+            inception_score, fid = self.metric.scores_from_stats(host["logits"], host)
+        else:
+            inception_score, fid = self.metric.scores_from_logits(host["logits"])
         self.logger.debug(f"inception score: {inception_score}\tfid: {fid}")
         if best["fid"] > fid:
             best["fid"] = fid
             self.logger.debug(f"{iters} lowest fid")
-            self.save_model("fid", iters, fid, fake)
+            self.save_model("fid", iters, fid, host["images"], snap)
         if best["is"] < inception_score:
             best["is"] = inception_score
             self.logger.debug(f"{iters} highest is")
-            self.save_model("is", iters, inception_score, fake)
+            self.save_model("is", iters, inception_score, host["images"], snap)
 
     def train(self):
         loader = self.train_loader
         n_iter = self.epoch * len(loader)
         fixed_noise = torch.randn(64, 100, 1, 1).to(self.device) if self.host_rng else torch.randn(64, 100, 1, 1, device=self.device)
         best = {"fid": 1e10, "is": 0}
+        self._eval = AsyncEval(self)
         if self.rank == 0:
             real_batch = next(iter(loader))
             _save_png(os.path.join(self.model_save_path, "real_image.png"),
@@ -248,12 +271,14 @@ class DCGANTrainer(Trainer):
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:
+                    self._finish_eval(best, wait=False)              # host part of a finished evaluation (scores, checkpoint)
                     s = eng.scalars()                                # the only host sync of the iteration
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
                                       + f"\tD(x): {s['d_x']:.4f}\tD(G(z)): {s['d_gz1']:.4f} / {s['d_gz2']:.4f}")
                 if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
                     self._evaluate(fixed_noise, iters, best)
                 iters += 1
+        self._finish_eval(best, wait=True)
         self.engine.join()
         torch.cuda.synchronize()
         end = time.time()

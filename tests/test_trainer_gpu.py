@@ -132,3 +132,41 @@ def test_cgan_trainer_reproduces_reference_run(key, tmp_path, monkeypatch):
     d2.load_state_dict(ck["model_d"])
     torch.optim.Adam(d2.parameters(), lr=0.1, betas=[0.5, 0.999]).load_state_dict(ck["optimizer_d"])
     _fresh_logger()
+
+
+def test_evaluation_branch_runs_on_a_side_stream_with_the_hip_metric_network(tmp_path, monkeypatch):
+    """The every-500-iterations branch (reference train/dcgan_trainer.py:198-221) with a real metric network: G(fixed_noise) ->
+    299x299 -> Inception-v3 (HIP chain, seeded random weights: the fine-tuned ones are not available offline) -> IS / FID with
+    device-side fp64 mean / covariance -> best-score checkpoints.  The device part sits on a side stream and the host part is
+    deferred (train/async_eval.py); the checkpoint must still hold the state of the EVALUATION iteration, not of the moment it
+    is written."""
+    from inception import InceptionV3Hip
+    from metrics import Metrics
+    from model import DCGAN
+    from oracle.inception_oracle import random_state_dict
+    from train.dcgan_trainer import DCGANTrainer
+    from util import synth_images
+    monkeypatch.chdir(tmp_path)
+    _fresh_logger()
+    B, steps = 8, 3
+    imgs = synth_images(B * steps)
+    batches = [(imgs[i * B:(i + 1) * B],) for i in range(steps)]
+    args = argparse.Namespace(epoch=1, max_learning_rate=2e-4, model_path="ev", log_file=0,
+                              save_path=str(tmp_path / "save" / "dcgan" / "ev"), batch_size=B, num_worker=0)
+    net = InceptionV3Hip(random_state_dict(0))
+    real = torch.randn(300, 100, generator=torch.Generator().manual_seed(1)).numpy()
+    monkeypatch.setattr(DCGANTrainer, "_make_metrics", lambda self, loader: Metrics(None, extractor=net, real_features=real))
+    torch.manual_seed(12345)
+    tr = DCGANTrainer(args, DCGAN.Generator(), DCGAN.Discriminator(), SynthPre(batches), prec="f32")
+    tr.train()
+    root = tmp_path / "save" / "dcgan" / "ev"
+    for typ in ("fid", "is"):
+        pts = [f for f in os.listdir(root / typ) if f.endswith(".pt")]
+        assert len(pts) == 1, (typ, pts)                       # older checkpoints of the folder are deleted, as in the reference
+        it = int(pts[0].split("_")[0])
+        assert it in (0, steps - 1)                            # evaluated at iteration 0 and at the very last one
+        ck = torch.load(root / typ / pts[0], weights_only=False)
+        assert float(ck["optimizer_g"]["state"][0]["step"]) == it + 1        # the snapshot of THAT iteration
+        assert int(ck["model_g"]["norm1.num_batches_tracked"]) == (it + 1) + (1 if it == 0 else 2)   # steps so far + samplings so far
+        assert any(f.endswith("_fake_image.png") for f in os.listdir(root / typ))
+    _fresh_logger()
