@@ -164,6 +164,7 @@ def measure(a, model, world, rank, dev, dist):
     net_d.apply(M.weights_init)
     eng.load_state(net_g.state_dict(), net_d.state_dict())
     gen = torch.Generator(device=dev).manual_seed(2024 + rank)
+    eng.set_noise_seed(2024 + rank)                      # in-kernel instance noise: its own stream per rank
     batches = [torch.rand(B, 3, S, S, device=dev, generator=gen) * 2 - 1 for _ in range(4)]
     if a.input == "u8":
         data = (torch.rand(50000, 3, 32, 32, device=dev, generator=gen) * 255).to(torch.uint8)        # CIFAR-sized

@@ -256,7 +256,7 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
 #define JCK_PHASE_D_FAKE 6
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
-  const float* noise_real; /* [B,3,64,64] N(0,1) */
+  const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */
   const float* z;          /* [B,100] N(0,1) */
   const float* noise_fake; /* [B,3,64,64] N(0,1) */
   const float* alpha;      /* [B] U[0,1) */
@@ -308,6 +308,16 @@ int jck_mean_cov_f64(const float* x, double* mean, double* cov, int N, int D, vo
  * returns an executable graph; launch replays it.  The jck_step_inputs pointers are baked: keep the buffers in place,
  * refresh their contents, keep one graph per step parity, call jck_engine_set_step before every launch. */
 int jck_engine_set_step(jck_engine*, int step, float lr, void* stream);
+/* Instance noise drawn INSIDE the image kernels (steps whose jck_step_inputs.noise_real / noise_fake are NULL): Philox4x32-10
+ * keyed by `seed`, counter = (pixel, tensor, optimiser step), Box-Muller normals - no 25 MB noise tensor per step.  The *_rng
+ * entry points are the per-op forms (rng: device uint32[4] = {seed lo, seed hi, step, 0}; tensor_id separates real / fake). */
+int jck_engine_set_noise_seed(jck_engine*, unsigned long long seed);
+int jck_img_prep_rng(int prec, const float* img_nchw, const unsigned* rng, int tensor_id, float keep, float mix, void* out, int N, int HW,
+                     void* stream);
+int jck_img_prep_u8_rng(int prec, const unsigned char* data, const int64_t* idx, const unsigned* rng, int tensor_id, float keep,
+                        float mix, void* out_nhwc4, int B, int Hs, int Ws, void* stream);
+int jck_axpy_noise_rng(int prec, const void* x, const unsigned* rng, int tensor_id, float keep, float mix, void* out, int N, int HW,
+                       void* stream);
 int jck_engine_capture_begin(jck_engine*, void* stream);
 int jck_engine_capture_end(jck_engine*, void* stream, void** graph_exec);
 int jck_engine_capture_abort(jck_engine*, void* stream);

@@ -161,7 +161,8 @@ struct jck_engine {
   float *acc2, *scal2;                  // acc2: [2 parities][8 rows][acc_ld] per-image scalar table (summed by the step tail)
   int acc_ld = 0;
   float *head_ws, *gp2_ws;              // partial rows of the head weight gradients (deterministic two-stage sums)
-  float* hp2;                           // [2 parities][4]: {step_size, bc2_sqrt} of the optimiser step in flight (jck_engine_set_step)
+  float* hp2;                           // [2 parities][8]: {step_size, bc2_sqrt, -, -, noise seed lo, hi, step, 0} of the step in flight (jck_engine_set_step)
+  unsigned long long noise_seed = 0x6a636b67616e0001ull;      // in-kernel instance noise (jck_engine_set_noise_seed)
   int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases)
   bool capturing = false;
   float* wg_ws; size_t wg_ws_bytes;
@@ -239,7 +240,7 @@ struct jck_engine {
     acc_ld = (B + 63) / 64 * 64;
     acc2 = c.take<float>((size_t)2 * 8 * acc_ld); scal2 = c.take<float>(16);
     acc = acc2; scal_out = scal2;
-    hp2 = c.take<float>(8);
+    hp2 = c.take<float>(16);
     head_ws = c.take<float>(jck_head_bwd_ws_floats(TT.FEAT));
     gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
     size_t w = 0;
@@ -273,6 +274,12 @@ struct jck_engine {
   }
 
   float* P(const NetLayout& L, float* arena, const char* name) const { return arena + find(L, name)->offset; }
+  const unsigned* rng() const { return reinterpret_cast<const unsigned*>(hp2 + 8 * parity + 4); }     // this step's Philox words
+  // fake = 0.9 * G(z) + 0.1 * N(0,1) (:171): uploaded noise, or drawn in the kernel when the step carries none
+  int mix_fake_noise(const jck_step_inputs* in, int B, hipStream_t st) {
+    if (!in->noise_fake) return jck_axpy_noise_rng(prec, fake_raw, rng(), 1, 0.9f, 0.1f, fake, B, T.HW, st);
+    return jck_axpy_noise(prec, fake_raw, in->noise_fake, 0.9f, 0.1f, fake, B, T.HW, st);
+  }
 };
 
 
@@ -785,8 +792,11 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
 static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_t st) {
   if (in->real_u8) {
     if (TT.S != 64) JCK_FAIL(JCK_E_ARG, "the device-resident uint8 pipeline is the reference's Resize(64) of 32x32 images: 64x64 engines only");
+    if (!in->noise_real)
+      return jck_img_prep_u8_rng(e->prec, in->real_u8, in->real_idx, e->rng(), 0, 0.9f, 0.1f, e->real_noisy, B, 32, 32, st);
     return jck_img_prep_u8(e->prec, in->real_u8, in->real_idx, in->noise_real, 0.9f, 0.1f, e->real_noisy, nullptr, B, 32, 32, st);
   }
+  if (!in->noise_real) return jck_img_prep_rng(e->prec, in->real_nchw, e->rng(), 0, 0.9f, 0.1f, e->real_noisy, B, TT.HW, st);
   return jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, TT.HW, st);
 }
 
@@ -807,6 +817,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
   e->parity = in->step & 1;
   if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL) e->bucket_ready = false;
+  // eager callers that did not call jck_engine_set_step: the step's scalars / Philox words are written by its first phase
+  if (e->hp_step[e->parity] != in->step && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
@@ -817,8 +829,13 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   // costs 0.18 ms per replay) - so CGAN keeps everything on one stream unless JCK_CGAN_SIDE=1.
   static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
   static const bool cgan_side = getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) != 0;
-  hipStream_t sA = (e->overlap && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
-  const bool ov_g = e->overlap, ov_gp = e->overlap && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
+  // Under a stream capture everything stays on the capturing stream: a hipGraph with parallel branches makes the ROCm 7.2
+  // runtime keep per-graph side streams (hip::Graph::UpdateStreams), which costs ~7 us of host time per node at launch, ran
+  // slower than the linear graph for CGAN, and crashed inside hipGraphLaunch after a few dozen such graphs had been
+  // instantiated in one process.  Same kernels, same order per stream as the eager schedule - bitwise the same results.
+  const bool par = e->overlap && !e->capturing;
+  hipStream_t sA = (par && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
+  const bool ov_g = par, ov_gp = par && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
     JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
@@ -840,7 +857,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
         JCK_TRY(prep_real(e, in, B, st));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));
-        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));
+        JCK_TRY(e->mix_fake_noise(in, B, st));
         JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
         JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st));
         auto& S = e->bset;
@@ -864,7 +881,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
         JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
-        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, e->sB));   // :171
+        JCK_TRY(e->mix_fake_noise(in, B, e->sB));   // :171
         HIPCHK(hipEventRecord(e->evF, e->sB));
         JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                             // :162
@@ -883,7 +900,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
-        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, st));   // :171
+        JCK_TRY(e->mix_fake_noise(in, B, st));   // :171
         JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
@@ -906,7 +923,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         if (ov_gp && !in->alpha) JCK_FAIL(JCK_E_ARG, "alpha is needed here (the penalty pass starts inside this phase)");
         if (ov_g) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0)); sG = e->sB; }
         JCK_TRY(g_forward(e, in->z, in->labels, B, sG));                                          // :168-169
-        JCK_TRY(jck_axpy_noise(e->prec, e->fake_raw, in->noise_fake, 0.9f, 0.1f, e->fake, B, HW, sG));   // :171
+        JCK_TRY(e->mix_fake_noise(in, B, sG));   // :171
         if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
       }
       if (phase != JCK_PHASE_D_FAKE) {
@@ -969,7 +986,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_D_STEP: {                                                                      // :180
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
       if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));   // (eager callers)
-      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 4 * e->parity, st));
+      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
@@ -983,7 +1000,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
       if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
-      JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 4 * e->parity, st));
+      JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
       {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
         TailJobs t = {};
@@ -1012,8 +1029,16 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
 extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
-  JCK_TRY(jck_adam_set_step(e->hp2 + 4 * (step & 1), (double)lr, 0.5, 0.999, step, (hipStream_t)stream));
+  JCK_TRY(jck_adam_set_step(e->hp2 + 8 * (step & 1), (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream));
   e->hp_step[step & 1] = step;
+  return JCK_OK;
+}
+// Seed of the in-kernel instance noise (steps whose jck_step_inputs carry no noise tensors draw 0.1*N(0,1) inside the image
+// kernels: Philox4x32-10 keyed by this seed, counter = pixel | tensor | optimiser step).  Data-parallel ranks pass seed + rank.
+extern "C" int jck_engine_set_noise_seed(jck_engine* e, unsigned long long seed) {
+  if (!e) JCK_FAIL(JCK_E_ARG, "null engine");
+  e->noise_seed = seed;
+  e->hp_step[0] = e->hp_step[1] = 0;      // the next step rewrites the device copy
   return JCK_OK;
 }
 

@@ -8,21 +8,56 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------------------------------------------
+// In-kernel instance noise (perf mode): the reference draws 0.1 * N(0,1) for every pixel of the real and of the fake batch each
+// step (train/dcgan_trainer.py:160,171).  Drawing it with ATen costs a 25 MB write plus two 12.6 MB reads per step; here each
+// pixel's three normals come out of ONE Philox4x32-10 block (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3":
+// counter = (pixel index, tensor id, optimiser step), key = seed) and a Box-Muller transform, inside the kernel that mixes them
+// in.  rng: device uint32[4] = {seed lo, seed hi, step, 0}, written per step by jck_engine_set_step (so a captured graph of the
+// step carries no per-step argument).  A different stream than torch's generator - parity runs upload their noise instead.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// three N(0,1) values for pixel `i` of tensor `tensor_id` at the step held in rng[2]
+__device__ __forceinline__ void pixel_normals(const unsigned* __restrict__ rng, unsigned tensor_id, long long i, float (&nz)[3]) {
+  unsigned o[4];
+  philox4x32_10((unsigned)i, (unsigned)(i >> 32), tensor_id, rng[2], rng[0], rng[1], o);
+  const float u0 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(o[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(o[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1;
+  (void)s1;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // image prep: out[n][p][0..3] = keep * img[n][c][p] + mix * noise[n][c][p]   (NCHW f32 -> NHWC4 T)
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void img_prep_kernel(const float* __restrict__ img, const float* __restrict__ noise, float keep, float mix,
-                                T* __restrict__ out, int N, int HW) {
+                                T* __restrict__ out, int N, int HW, const unsigned* __restrict__ rng = nullptr, unsigned rng_tensor = 0) {
   const long long total = (long long)N * HW;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / HW;
     const int px = (int)(i - n * HW);
-    float v[4];
+    float v[4], nz[3] = {0.f, 0.f, 0.f};
+    if (rng) pixel_normals(rng, rng_tensor, i, nz);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const long long s = (n * 3 + c) * HW + px;
       float x = __fmul_rn(keep, img[s]);
       if (noise) x = __fmaf_rn(mix, noise[s], x);                  // explicit: the same rounding in every kernel that mixes noise
+      else if (rng) x = __fmaf_rn(mix, nz[c], x);
       v[c] = x;
     }
     v[3] = 0.f;
@@ -44,7 +79,8 @@ __device__ __forceinline__ int up2_pil(int o, int L, int a_km1, int a_k, int a_k
 template <typename T>
 __global__ void img_prep_u8_kernel(const unsigned char* __restrict__ data, const long long* __restrict__ idx,
                                    const float* __restrict__ noise, float keep, float mix, T* __restrict__ out_nhwc4,
-                                   float* __restrict__ out_nchw, int B, int Hs, int Ws) {
+                                   float* __restrict__ out_nchw, int B, int Hs, int Ws, const unsigned* __restrict__ rng = nullptr,
+                                   unsigned rng_tensor = 0) {
   const int H = 2 * Hs, W = 2 * Ws;
   const long long total = (long long)B * H * W;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -53,7 +89,8 @@ __global__ void img_prep_u8_kernel(const unsigned char* __restrict__ data, const
     const unsigned char* src = data + (idx ? idx[n] : n) * 3ll * Hs * Ws;
     const int kx = x >> 1, ky = y >> 1;
     const int xm = max(kx - 1, 0), xp = min(kx + 1, Ws - 1), ym = max(ky - 1, 0), yp = min(ky + 1, Hs - 1);
-    float v[4];
+    float v[4], nz[3] = {0.f, 0.f, 0.f};
+    if (rng) pixel_normals(rng, rng_tensor, i, nz);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const unsigned char* pl = src + (long long)c * Hs * Ws;
@@ -69,6 +106,7 @@ __global__ void img_prep_u8_kernel(const unsigned char* __restrict__ data, const
       if (out_nchw) out_nchw[((n * 3 + c) * H + y) * W + x] = t;
       float o = __fmul_rn(keep, t);
       if (noise) o = __fmaf_rn(mix, noise[((n * 3 + c) * H + y) * W + x], o);
+      else if (rng) o = __fmaf_rn(mix, nz[c], o);
       v[c] = o;
     }
     v[3] = 0.f;
@@ -118,17 +156,19 @@ __global__ void nhwc4_to_nchw_kernel(const T* __restrict__ in, float* __restrict
 // out = keep * x(NHWC4 T) + mix * noise(NCHW f32)
 template <typename T>
 __global__ void axpy_noise_kernel(const T* __restrict__ x, const float* __restrict__ noise, float keep, float mix,
-                                  T* __restrict__ out, int N, int HW) {
+                                  T* __restrict__ out, int N, int HW, const unsigned* __restrict__ rng = nullptr, unsigned rng_tensor = 0) {
   const long long total = (long long)N * HW;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / HW;
     const int px = (int)(i - n * HW);
-    float v[4];
+    float v[4], nz[3] = {0.f, 0.f, 0.f};
     ld4(x + i * 4, v);
+    if (rng) pixel_normals(rng, rng_tensor, i, nz);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float r = keep * v[c];
       if (noise) r += mix * noise[(n * 3 + c) * HW + px];
+      else if (rng) r += mix * nz[c];
       v[c] = r;
     }
     v[3] = 0.f;
@@ -527,8 +567,14 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // hp (optional): device float[2] = {step_size, bc2_sqrt} of THIS step, written by adam_hp_kernel before the step is enqueued
 // - the whole-step engine passes its per-step scalars this way so that a captured hipGraph of the step carries no
 // per-step kernel argument; the values are the same host-computed floats either way.
-static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { hp[0] = step_size; hp[1] = bc2_sqrt; }
+// hp[0..1] = Adam's per-step scalars; hp[4..7] (as uint32) = {noise seed lo, hi, step, 0} for the in-kernel Philox noise
+static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt, unsigned seed_lo, unsigned seed_hi,
+                                      unsigned step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    hp[0] = step_size; hp[1] = bc2_sqrt;
+    unsigned* r = reinterpret_cast<unsigned*>(hp + 4);
+    r[0] = seed_lo; r[1] = seed_hi; r[2] = step; r[3] = 0u;
+  }
 }
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float w1 /*1-beta1*/, float beta2, float omb2 /*1-beta2*/,

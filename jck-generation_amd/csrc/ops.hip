@@ -708,6 +708,32 @@ extern "C" int jck_img_prep_u8(int prec, const unsigned char* data, const int64_
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
+// in-kernel Philox noise instead of an uploaded noise tensor (ew.hpp: pixel_normals); rng = device uint32[4]
+extern "C" int jck_img_prep_rng(int prec, const float* img, const unsigned* rng, int tensor_id, float keep, float mix, void* out, int N,
+                                int HW, void* stream) {
+  if (!rng) JCK_FAIL(JCK_E_ARG, "img_prep_rng: rng is NULL");
+  DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0, (hipStream_t)stream, img,
+                                      (const float*)nullptr, keep, mix, (T*)out, N, HW, rng, (unsigned)tensor_id));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_img_prep_u8_rng(int prec, const unsigned char* data, const int64_t* idx, const unsigned* rng, int tensor_id,
+                                   float keep, float mix, void* out_nhwc4, int B, int Hs, int Ws, void* stream) {
+  if (!data || !rng || !out_nhwc4 || B < 1) JCK_FAIL(JCK_E_ARG, "img_prep_u8_rng: bad arguments");
+  DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_u8_kernel<T>, dim3(ew_grid((long long)B * 4 * Hs * Ws)), dim3(256), 0, (hipStream_t)stream,
+                                      data, (const long long*)idx, (const float*)nullptr, keep, mix, (T*)out_nhwc4, (float*)nullptr, B,
+                                      Hs, Ws, rng, (unsigned)tensor_id));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_axpy_noise_rng(int prec, const void* x, const unsigned* rng, int tensor_id, float keep, float mix, void* out, int N,
+                                  int HW, void* stream) {
+  if (!rng) JCK_FAIL(JCK_E_ARG, "axpy_noise_rng: rng is NULL");
+  DISPATCH_T(prec, hipLaunchKernelGGL(axpy_noise_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)x, (const float*)nullptr, keep, mix, (T*)out, N, HW, rng, (unsigned)tensor_id));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 extern "C" int jck_img_prep(int prec, const float* img, const float* noise, float keep, float mix, void* out, int N, int HW,
                             void* stream) {
   DISPATCH_T(prec, hipLaunchKernelGGL(img_prep_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0,
@@ -810,10 +836,11 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
   return JCK_OK;
 }
 // the same update with {step_size, bc2_sqrt} read from device memory: jck_adam_set_step writes them (same host arithmetic)
-int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, hipStream_t st) {
+int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st) {
   if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
-  hipLaunchKernelGGL(adam_hp_kernel, dim3(1), dim3(64), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2));
+  hipLaunchKernelGGL(adam_hp_kernel, dim3(1), dim3(64), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,
+                     (unsigned)(seed >> 32), (unsigned)step);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

@@ -109,6 +109,10 @@ PROTOS = {
     "jck_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "jck_mean_cov_f64": (i32, [vp, vp, vp, i32, i32, vp]),
     "jck_engine_set_step": (i32, [vp, i32, f32, vp]),
+    "jck_engine_set_noise_seed": (i32, [vp, C.c_ulonglong]),
+    "jck_img_prep_rng": (i32, [i32, vp, vp, i32, f32, f32, vp, i32, i32, vp]),
+    "jck_img_prep_u8_rng": (i32, [i32, vp, vp, vp, i32, f32, f32, vp, i32, i32, i32, vp]),
+    "jck_axpy_noise_rng": (i32, [i32, vp, vp, i32, f32, f32, vp, i32, i32, vp]),
     "jck_engine_capture_begin": (i32, [vp, vp]),
     "jck_engine_capture_end": (i32, [vp, vp, C.POINTER(vp)]),
     "jck_engine_capture_abort": (i32, [vp, vp]),

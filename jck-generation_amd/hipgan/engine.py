@@ -108,7 +108,14 @@ class DcganEngine:
         self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
         self._packed_version = -1
         # hipGraph replay of the step (JCK_GRAPH=0 disables): one captured graph per (segment, step parity, input kind)
-        self.graphs = os.environ.get("JCK_GRAPH", "1") != "0"
+        # Default: on for CGAN (its step is one stream anyway: 0.18 ms of host time per step instead of 2.4), off for DCGAN, whose
+        # eager schedule overlaps the weight gradients with the dgrad chain on a second stream (+8 %) - a captured step is
+        # linear (see jck_engine_phase) and the DCGAN host is not the bottleneck (1.2 ms of enqueue for a 2.1 ms step).
+        # JCK_GRAPH=1 / 0 forces it either way.
+        self.graphs = os.environ.get("JCK_GRAPH", "1" if self.family == 1 else "0") != "0"
+        # steps without a noise dict draw z / alpha with torch and the two instance-noise tensors INSIDE the image kernels
+        # (Philox, jck_engine_set_noise_seed); JCKGAN_FAST_NOISE=0 draws them with torch.randn as round 1 did
+        self.fast_noise = os.environ.get("JCKGAN_FAST_NOISE", "1") != "0"
         self._graph_cache, self._sbuf, self._st, self._eager_steps = {}, None, None, 0
         h = C.c_void_p()
         dll = load_library()
@@ -274,10 +281,32 @@ class DcganEngine:
                 si.drop_mask[i] = ptr(m, B * 256)
         return si, keep
 
-    def draw_noise(self, generator=None, labels=None, out=None):
+    def set_noise_seed(self, seed):
+        """Seed of the in-kernel instance noise (data-parallel ranks: base seed + rank)."""
+        lib.jck_engine_set_noise_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+    def draw_noise(self, generator=None, labels=None, out=None, fast=False):
         """Device-side draws in the reference's order (train/dcgan_trainer.py:160,168,171,111).  out: the engine's
-        fixed-address input buffers (graph replay) - filled in place with the same draws, no extra copy."""
+        fixed-address input buffers (graph replay) - filled in place with the same draws, no extra copy.  fast: only z and
+        alpha (and the dropout masks); the two [B,3,S,S] instance-noise tensors are then drawn inside the step's kernels."""
         B, dev, S = self.batch, self.device, self.size
+        if fast:
+            if out is None:
+                z = torch.randn(B, 100, 1, 1, device=dev, generator=generator)
+                alpha = torch.rand(B, 1, 1, 1, device=dev, generator=generator)
+            else:
+                z = torch.randn(B, 100, 1, 1, generator=generator, out=out["z"])
+                alpha = torch.rand(B, 1, 1, 1, generator=generator, out=out["alpha"])
+            nz = {"n1": None, "z": z, "n2": None, "alpha": alpha}
+            if self.family == 1:
+                nz["labels"] = labels
+                for i in range(4):
+                    if out is None:
+                        nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
+                    else:
+                        u = torch.rand(B, 256, generator=generator, out=out["u"])
+                        nz[f"m{i + 1}"] = out[f"m{i + 1}"].copy_(u >= 0.25)
+            return nz
         # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
         ni, nzz = B * 3 * S * S, B * 100
         if out is None:
@@ -332,6 +361,7 @@ class DcganEngine:
             B, dev, S = self.batch, self.device, self.size
             f32 = dict(dtype=torch.float32, device=dev)
             sb = {"nbuf": torch.empty(2 * B * 3 * S * S + B * 100, **f32), "alpha": torch.empty(B, 1, 1, 1, **f32),
+                  "z": torch.empty(B, 100, 1, 1, **f32),
                   "real": torch.empty(B, 3, S, S, **f32), "idx": torch.empty(B, dtype=torch.int64, device=dev)}
             if self.family == 1:
                 sb["labels"] = torch.empty(B, 100, dtype=torch.int64, device=dev)
@@ -351,15 +381,17 @@ class DcganEngine:
                 if labels is None:
                     raise JckError("CGAN step without a noise dict needs labels=")
                 sb["labels"].copy_(labels.to(torch.int64).view(B, 100), non_blocking=True)
-            nz = self.draw_noise(generator, labels=sb.get("labels"), out=sb)
+            nz = self.draw_noise(generator, labels=sb.get("labels"), out=sb, fast=self.fast_noise)
         else:
             buf = sb["nbuf"]
-            buf[:ni].view(B, 3, S, S).copy_(noise["n1"], non_blocking=True)
+            up = noise.get("n1") is not None or noise.get("n2") is not None      # uploaded instance noise (else: drawn in-kernel)
+            if up:
+                buf[:ni].view(B, 3, S, S).copy_(noise["n1"], non_blocking=True)
+                buf[ni + nzz:].view(B, 3, S, S).copy_(noise["n2"], non_blocking=True)
             buf[ni:ni + nzz].view(B, 100, 1, 1).copy_(noise["z"].view(B, 100, 1, 1), non_blocking=True)
-            buf[ni + nzz:].view(B, 3, S, S).copy_(noise["n2"], non_blocking=True)
             sb["alpha"].copy_(noise["alpha"].view(B, 1, 1, 1), non_blocking=True)
-            nz = {"n1": buf[:ni].view(B, 3, S, S), "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
-                  "n2": buf[ni + nzz:].view(B, 3, S, S), "alpha": sb["alpha"]}
+            nz = {"n1": buf[:ni].view(B, 3, S, S) if up else None, "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
+                  "n2": buf[ni + nzz:].view(B, 3, S, S) if up else None, "alpha": sb["alpha"]}
             if self.family == 1:
                 lab = noise.get("labels")
                 if lab is None or lab.shape != (B, 100) or lab.dtype != torch.int64:
@@ -383,15 +415,19 @@ class DcganEngine:
     def _step_graph(self, real, noise, lr, reduce_d, reduce_g, grad_scale, generator, labels):
         main, est = torch.cuda.current_stream(), self._e_stream()
         est.wait_stream(main)                                       # inputs produced on the caller's stream
-        for t in ([real] if torch.is_tensor(real) else [real.data, real.idx]) + [v for v in (noise or {}).values() if torch.is_tensor(v)]:
-            if t.is_cuda:
-                t.record_stream(est)                                # read by the copies below, on the engine stream
         h, st = self._h, est.cuda_stream
         with torch.cuda.stream(est):
             gs = self._shared["g_stream"]
             if gs is not None:
                 est.wait_stream(gs)
             real_s, nz = self._fill_static(real, noise, generator, labels)
+            # The caller's tensors were read by copies on THIS stream: the caller's stream waits for those copies, so memory
+            # it frees and reuses afterwards cannot be overwritten under them.  (Tensor.record_stream would do the same, but
+            # the caching allocator then records an event on this stream whenever such a tensor is freed - also in the
+            # middle of a capture, where that event becomes a node of the graph and is gone by the time the graph replays.)
+            copied = torch.cuda.Event()
+            copied.record(est)
+            main.wait_event(copied)
             si, keep = self._inputs(real_s, nz, lr, grad_scale)
             step = self.t + 1
             lib.jck_engine_set_step(h, step, lr, st)
@@ -401,7 +437,7 @@ class DcganEngine:
                 segs = ([[PHASE_D_LOSS, PHASE_D_GP]], [[PHASE_D_STEP, PHASE_G_LOSS]], [[PHASE_G_STEP]])
             else:
                 segs = ([[PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP]], [], [])
-            kind = ("u8", real.data.data_ptr()) if isinstance(real, DeviceBatch) else ("f32",)
+            kind = (("u8", real.data.data_ptr()) if isinstance(real, DeviceBatch) else ("f32",)) + (nz.get("n1") is None, nz["z"].data_ptr())
             handle = None
 
             launched = []
@@ -411,6 +447,9 @@ class DcganEngine:
                 ge = self._graph_cache.get(key)
                 if ge is None:
                     global _CAPTURES_OPEN
+                    import gc
+                    gc_was = gc.isenabled()
+                    gc.disable()            # no destructor of unrelated objects (tensors, events, engines) inside the capture
                     try:
                         lib.jck_engine_capture_begin(h, st)
                         _CAPTURES_OPEN += 1
@@ -426,9 +465,13 @@ class DcganEngine:
                             _CAPTURES_OPEN -= 1
                             _flush_deferred()
                     except JckError as e:
+                        if gc_was:
+                            gc.enable()
                         if launched:        # part of the step already ran: no clean fallback
                             raise
                         raise _GraphUnavailable(str(e))
+                    if gc_was:
+                        gc.enable()
                     ge = self._graph_cache[key] = out.value
                 lib.jck_graph_launch(ge, st)
                 launched.append(seg_id)
@@ -473,7 +516,7 @@ class DcganEngine:
                 self.graphs = False
                 torch.cuda.current_stream().wait_stream(self._e_stream())
         self._eager_steps += 1
-        noise = noise if noise is not None else self.draw_noise(generator, labels=labels)
+        noise = noise if noise is not None else self.draw_noise(generator, labels=labels, fast=self.fast_noise)
         si, keep = self._inputs(real, noise, lr, grad_scale)
         main = torch.cuda.current_stream()
         st = main.cuda_stream

@@ -61,6 +61,7 @@ class CGANTrainer(DCGANTrainer):
             from change_randomseed import RANDOMSEED
             self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
             self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
+            self.engine.set_noise_seed(RANDOMSEED + 1 + self.rank)
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.criterion = nn.BCELoss()
@@ -73,6 +74,9 @@ class CGANTrainer(DCGANTrainer):
             return self.engine
         if b not in self._tail_engines:
             self._tail_engines[b] = CganEngine(batch=b, share=self.engine)
+            if self.world > 1:
+                from change_randomseed import RANDOMSEED
+                self._tail_engines[b].set_noise_seed(RANDOMSEED + 1 + self.rank)
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------
@@ -208,7 +212,7 @@ class CGANTrainer(DCGANTrainer):
                     noise["m4"] = keep()
                     noise["labels"] = labels
                 else:
-                    noise = eng.draw_noise(self.noise_gen, labels=labels)
+                    noise = eng.draw_noise(self.noise_gen, labels=labels, fast=eng.fast_noise)
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:

@@ -136,6 +136,7 @@ class DCGANTrainer(Trainer):
             from change_randomseed import RANDOMSEED
             self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
             self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
+            self.engine.set_noise_seed(RANDOMSEED + 1 + self.rank)       # the in-kernel instance noise, per rank too
 
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
@@ -160,6 +161,9 @@ class DCGANTrainer(Trainer):
             return self.engine
         if b not in self._tail_engines:
             self._tail_engines[b] = DcganEngine(batch=b, share=self.engine)
+            if self.world > 1:
+                from change_randomseed import RANDOMSEED
+                self._tail_engines[b].set_noise_seed(RANDOMSEED + 1 + self.rank)
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------
@@ -267,7 +271,7 @@ class DCGANTrainer(Trainer):
                     noise = {"n1": torch.randn(b, 3, 64, 64, generator=hg), "z": torch.randn(b, 100, 1, 1, generator=hg),
                              "n2": torch.randn(b, 3, 64, 64, generator=hg), "alpha": torch.rand(b, 1, 1, 1, generator=hg)}
                 elif self.noise_gen is not None:
-                    noise = eng.draw_noise(self.noise_gen)
+                    noise = eng.draw_noise(self.noise_gen, fast=eng.fast_noise)
                 eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:

@@ -355,3 +355,41 @@ def test_image_ops(G, prec):
     yv = G.rnd(torch.tanh(torch.randn(n, 3, 64, 64, generator=g)), prec)
     G.lib.jck_tanh_bwd(prec, G.to_nhwc(x, prec), G.to_nhwc(yv, prec), 0.9, o4, n * hw * 4, G.cur_stream())
     G.check(G.from_nhwc(o4, 3), 0.9 * x * (1 - yv * yv), tol, "tanh_bwd")
+
+
+def test_inkernel_philox_noise(G):
+    """The instance noise drawn inside the image kernels (jck_*_rng; perf mode of train/dcgan_trainer.py:160,171): N(0,1) moments,
+    independent across channels / tensors / steps, and a pure function of (seed, tensor, step, pixel)."""
+    n, hw = 16, 64 * 64
+    img = torch.zeros(n, 3, 64, 64, device="cuda")
+
+    def draw(seed, step, tensor):
+        rng = torch.tensor([seed & 0xFFFFFFFF, seed >> 32, step, 0], dtype=torch.int64).to(torch.int32).cuda()     # uint32 words
+        out = torch.empty(n, 64, 64, 4, device="cuda")
+        G.lib.jck_img_prep_rng(G.PREC_F32, img, rng, tensor, 0.9, 1.0, out, n, hw, G.cur_stream())
+        torch.cuda.synchronize()
+        return out
+
+    a = draw(12345, 7, 0)
+    assert torch.equal(a, draw(12345, 7, 0))                         # deterministic
+    x = a[..., :3].double().reshape(-1)
+    assert float(a[..., 3].abs().max()) == 0.0
+    assert abs(x.mean().item()) < 3e-3 and abs(x.var().item() - 1.0) < 5e-3
+    assert abs((x ** 4).mean().item() - 3.0) < 0.05 and abs((x ** 3).mean().item()) < 0.02      # kurtosis / skew of a normal
+    assert 4.5 < x.abs().max().item() < 7.0                          # tails exist and are finite
+    c = torch.corrcoef(a[..., :3].double().reshape(-1, 3).t())
+    assert float((c.cpu() - torch.eye(3, dtype=torch.float64)).abs().max()) < 5e-3    # channels of a pixel are independent
+    for other in (draw(12345, 7, 1), draw(12345, 8, 0), draw(12346, 7, 0)):          # tensor id, step, seed each change the stream
+        y = other[..., :3].double().reshape(-1)
+        assert abs(torch.corrcoef(torch.stack([x, y]))[0, 1].item()) < 5e-3
+    # the same words through the other two kernels: axpy on an NHWC4 tensor, and the uint8 gather path
+    rng = torch.tensor([12345, 0, 7, 0], dtype=torch.int32).cuda()
+    o2 = torch.empty(n, 64, 64, 4, device="cuda")
+    G.lib.jck_axpy_noise_rng(G.PREC_F32, torch.zeros(n, 64, 64, 4, device="cuda"), rng, 0, 0.9, 1.0, o2, n, hw, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o2, a)
+    data = torch.full((n, 3, 32, 32), 127, dtype=torch.uint8, device="cuda")
+    o3 = torch.empty(n, 64, 64, 4, device="cuda")
+    G.lib.jck_img_prep_u8_rng(G.PREC_F32, data, None, rng, 0, 0.0, 1.0, o3, n, 32, 32, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o3, a)
