@@ -4,8 +4,8 @@ train/cgan_trainer.py:222-252).
 The reference stops training every 500 iterations: G(fixed_noise), resize to 299x299, two or three Inception-v3 passes, numpy /
 scipy on the host, torch.save.  Here the device part - sampling (ONE train-mode BatchNorm batch, as in the reference), the
 fused resize + normalise, the metric network, the copies to pinned host memory - is enqueued on a second stream, and the
-training stream waits only for the SAMPLING kernels (they read G's weights and move its BatchNorm running statistics, so the
-next step must come after them, exactly where the reference has them).  The host part (softmax / KL, fp64 mean-cov read-back,
+training stream waits only for the SAMPLING kernels and the checkpoint snapshot's device copies (they read G's weights and move
+its BatchNorm running statistics, so the next step must come after them, exactly where the reference has them).  The host part (softmax / KL, fp64 mean-cov read-back,
 scipy sqrtm, log line, checkpoint) runs when the copies have landed - checked at the next log points, forced before the next
 evaluation and at the end of training.  What is written is a snapshot taken at the evaluation iteration, so the checkpoint
 holds the same state the reference would have saved."""
@@ -51,13 +51,13 @@ class AsyncEval:
         self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
             fake = sample()
+            snap = checkpoint_snapshot(tr) if tr.rank == 0 else None      # device copies, BEFORE training may touch the state again
             sampled = torch.cuda.Event()
             sampled.record(self.stream)
-            snap = checkpoint_snapshot(tr) if tr.rank == 0 else None
             host = {k: to_host_async(v) for k, v in device_part(fake).items()}
             done = torch.cuda.Event()
             done.record(self.stream)
-        main.wait_event(sampled)                           # training resumes behind the sampling kernels, not behind the metric network
+        main.wait_event(sampled)                           # training resumes behind sampling + snapshot, not behind the metric network
         self.pending = {"iters": iters, "snapshot": snap, "host": host, "done": done}
 
     def take(self, wait):
