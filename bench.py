@@ -57,7 +57,7 @@ def step_flops_per_image(dead_wgrad=False):
 # profiler variant label (csrc/ops.hip PROF_NAMES) -> substring of the kernel symbol rocprofv3 reports
 _SYMBOL = {"igemm<bf16,128,256>": "igemm_dma_kernel<128, 256,", "igemm<bf16,128,128>": "igemm_dma_kernel<128, 128,",
            "igemm<bf16,128,64>": "igemm_dma_kernel<128, 64,", "igemm<bf16,64,128>": "igemm_dma_kernel<64, 128,",
-           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>", "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2>",
+           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>", "wgrad_halo<bf16,64,512>": "wgrad_halo_kernel<", "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2>",
            "wgrad<bf16,64,64,img>": "wgrad_kernel<PrecBf16, 64, 64, 2>", "img_down<bf16>": "img_down_kernel", "img_up<bf16>": "img_up_kernel"}
 
 
@@ -72,11 +72,13 @@ def pmc_traffic(kernel):
         return None
     with open(files[-1]) as f:
         tr = json.load(f)
-    for name, v in tr.items():
-        if pat in name:
-            return {"bytes_per_launch": round(v["read_bytes"] + v["write_bytes"]), "read": round(v["read_bytes"]),
-                    "write": round(v["write_bytes"]), "source": os.path.basename(files[-1])}
-    return None
+    hits = [v for name, v in tr.items() if pat in name]           # a template kernel may appear as several instantiations
+    n = sum(v["launches"] for v in hits)
+    if not n:
+        return None
+    rd = sum(v["read_bytes"] * v["launches"] for v in hits) / n
+    wr = sum(v["write_bytes"] * v["launches"] for v in hits) / n
+    return {"bytes_per_launch": round(rd + wr), "read": round(rd), "write": round(wr), "source": os.path.basename(files[-1])}
 
 
 def _host_cpus():

@@ -58,7 +58,9 @@ Topo make_topo(int S) {
   }
   return T;
 }
-const int N_CLASS = 100, EMB = 200, L1_OUT = 256, L1_FEAT = 8192, L1_K = L1_FEAT + EMB, L1_KPAD = 8448, L1_KSPLIT = 12;   // model/CGAN.py:83,104
+const int N_CLASS = 100, EMB = 200, L1_OUT = 256, L1_FEAT = 8192, L1_K = L1_FEAT + EMB, L1_KPAD = 8448;   // model/CGAN.py:83,104
+// split-K of Linear(8392, 256): 132 k-steps of 64 over L1_KSPLIT workgroups per tile (a divisor of 132; JCK_L1_KSPLIT to A/B)
+static const int L1_KSPLIT = [] { const char* v = getenv("JCK_L1_KSPLIT"); const int k = v ? atoi(v) : 12; return (k > 0 && 132 % k == 0) ? k : 12; }();
 inline int z_dim(int family) { return family == 1 ? 200 : 100; }      // model/CGAN.py:132: ConvTranspose2d(200, 512)
 inline int z_pad(int family) { return family == 1 ? 256 : 128; }
 

@@ -1,6 +1,7 @@
 // C-ABI launchers for the per-op entry points of include/jckgan.h (host side; kernels in *.hpp).
 #include "ops_internal.hpp"
 #include "thin.hpp"
+#include "wgrad_halo.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -31,11 +32,12 @@ static int g_wgrad_small_wgs = env_int("JCK_WGRAD_SMALL_WGS", 512);
 static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
 static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
+static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
 extern "C" int jck_tune(const char* key, int value) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
-                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}};
+                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
   for (auto& t : tab)
     if (key && !strcmp(t.k, key)) { *t.p = value; return JCK_OK; }
   JCK_FAIL(JCK_E_ARG, std::string("jck_tune: unknown key ") + (key ? key : "(null)"));
@@ -62,7 +64,7 @@ const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "
                                   "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
                                   "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
                                   "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>",
-                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>"};
+                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>",    "wgrad_halo<bf16,64,512>"};
 struct ProfScope {
   ProfRec r; bool on; hipStream_t st;
   ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
@@ -459,6 +461,52 @@ static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, h
   JCK_FAIL(JCK_E_ARG, "wgrad: unsupported tile plan");
 }
 
+// ---- tap-reuse plan (wgrad_halo.hpp): a workgroup owns 64 cs x (16 taps x 32 cb); split-K over 64-pixel k-steps ----
+static bool wgrad_halo_shape(int prec, int Hb, int Wb, int Cb, int cbp, int Cs) {
+  const int OW = Wb / 2;
+  return prec == JCK_PREC_BF16 && Hb == Wb && (OW == 4 || OW == 8 || OW == 16 || OW == 32) && cbp == Cb && Cb % 32 == 0 &&
+         Cs % 64 == 0;
+}
+static WgradPlan plan_wgrad_halo(long long Mtot, int cbp, int Cs) {
+  WgradPlan pl;
+  pl.ncols = 16 * cbp; pl.BG = 512; pl.BS = 64;
+  pl.gx = cbp / 32; pl.gy = Cs / 64; pl.CsRows = Cs;
+  const long long nsteps = (Mtot + 63) / 64;
+  long long Z = std::max<long long>(1, std::min<long long>(g_wgrad_wgs / (pl.gx * pl.gy), nsteps));
+  const long long per = (nsteps + Z - 1) / Z;
+  Z = (nsteps + per - 1) / per;
+  pl.Z = (int)Z; pl.mchunk = (int)(per * 64);
+  pl.ws = (size_t)Z * pl.CsRows * pl.ncols * sizeof(float);
+  return pl;
+}
+template <int LOGOW>
+static int launch_wgrad_halo_t(const WgradParams& q, int grid, hipStream_t st) {
+  constexpr int LDSB = HaloGeo<LOGOW>::LDS_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel<LOGOW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_halo_kernel<LOGOW>), dim3(grid), dim3(768), LDSB, st, q);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+static int launch_wgrad_halo(const WgradParams& p, const WgradPlan& pl, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws_bytes < pl.ws) JCK_FAIL(JCK_E_WS, "wgrad: workspace too small: need " + std::to_string(pl.ws));
+  ProfScope prof(22, p.flops, st);
+  WgradParams q = p;
+  q.part = ws; q.CsRows = pl.CsRows; q.ncols = pl.ncols; q.mchunk = pl.mchunk;
+  q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
+  const int grid = pl.gx * pl.gy * pl.Z;
+  switch (q.logOW) {
+    case 2: return launch_wgrad_halo_t<2>(q, grid, st);
+    case 3: return launch_wgrad_halo_t<3>(q, grid, st);
+    case 4: return launch_wgrad_halo_t<4>(q, grid, st);
+    case 5: return launch_wgrad_halo_t<5>(q, grid, st);
+  }
+  JCK_FAIL(JCK_E_ARG, "wgrad_halo: unsupported image width");
+}
+
 static int run_wgrad(int prec, WgradParams& p, const WgradPlan& pl, int nsub, float* ws, size_t ws_bytes, hipStream_t st) {
   if (ws_bytes < pl.ws) JCK_FAIL(JCK_E_WS, "wgrad: workspace too small: need " + std::to_string(pl.ws));
   p.part = ws; p.CsRows = pl.CsRows; p.ncols = pl.ncols; p.mchunk = pl.mchunk;
@@ -492,7 +540,8 @@ extern "C" size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs)
   const int cbp = jck_pad_chan(Cb);
   // the larger of the two plans, whatever the knobs say right now (a workspace outlives a jck_tune call)
   const bool wide_shape = cbp >= 64 && (16 * cbp) % 256 == 0 && Cs % 128 == 0;
-  return std::max(plan_wgrad(M, 16 * cbp, Cs).ws, wide_shape ? plan_wgrad(M, 16 * cbp, Cs, true).ws : (size_t)0);
+  const size_t halo = wgrad_halo_shape(JCK_PREC_BF16, Hb, Wb, Cb, cbp, Cs) ? plan_wgrad_halo(M, cbp, Cs).ws : (size_t)0;
+  return std::max(halo, std::max(plan_wgrad(M, 16 * cbp, Cs).ws, wide_shape ? plan_wgrad(M, 16 * cbp, Cs, true).ws : (size_t)0));
 }
 
 extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes,
@@ -504,9 +553,15 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
   p.sside = small_side; p.big = big_side; p.Mtot = N * OH * OW; p.CsStride = Cs; p.logCb = ilog2(cbp);
   p.H = Hb; p.W = Wb; p.logOW = ilog2(OW); p.logOHW = ilog2(OH * OW); p.sy = p.sx = 2; p.ntaps = 16;
   for (int t = 0; t < 16; ++t) { p.dy[t] = (signed char)(t / 4 - 1); p.dx[t] = (signed char)(t % 4 - 1); }
-  const WgradPlan pl = plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
   p.flops = 2.0 * p.Mtot * Cs * 16.0 * Cb;
-  int rc = run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
+  // tap-reuse kernel where it measured faster than the per-tap gather (tests/_mb2.py wgrad_halo 0 1 ...): >= 32 k-steps per
+  // workgroup (the 2B-image products of the D phase: +4..12 %; 16 k-steps: -5..-12 %, the 128 KB fp32 tile each workgroup
+  // writes into its split-K slab is then a third of its time).  JCK_WGRAD_HALO=2 forces it for every admissible shape.
+  bool halo = g_wgrad_halo && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs);
+  if (halo && g_wgrad_halo != 2 && plan_wgrad_halo(p.Mtot, cbp, Cs).mchunk < 32 * 64) halo = false;
+  const WgradPlan pl = halo ? plan_wgrad_halo(p.Mtot, cbp, Cs) : plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
+  int rc = halo ? launch_wgrad_halo(p, pl, ws, ws_bytes, (hipStream_t)stream)
+                : run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
   if (rc) return rc;
   JCK_TRY(launch_wgrad_reduce(ws, pl.Z, pl.CsRows, pl.ncols, Cs, Cb, p.logCb, grad, accumulate, (hipStream_t)stream));
   return JCK_OK;

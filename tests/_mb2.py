@@ -9,7 +9,7 @@ shapes = sys.argv[4].split(",")
 Bs = [int(x) for x in sys.argv[5:]] or [256]
 CFG = {"down2": ("down", 32, 64, 128), "down3": ("down", 16, 128, 256), "down4": ("down", 8, 256, 512),
        "up2": ("up", 4, 512, 256), "up3": ("up", 8, 256, 128), "up4": ("up", 16, 128, 64),
-       "wg2": ("wg", 32, 64, 128), "wg3": ("wg", 16, 128, 256), "wg4": ("wg", 8, 256, 512)}
+       "wg2": ("wg", 32, 64, 128), "wg3": ("wg", 16, 128, 256), "wg4": ("wg", 8, 256, 512), "wg1": ("wg", 64, 64, 128)}
 prec = 0
 def make(which, B):
     cfg = CFG[which]; kind = cfg[0]

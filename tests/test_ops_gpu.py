@@ -84,11 +84,17 @@ def test_conv_up(G, prec, shape):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("halo", [2, 0])
 @pytest.mark.parametrize("shape", [(2, 8, 64, 128), (3, 64, 3, 64), (2, 16, 128, 256), (4, 8, 256, 512), (7, 8, 64, 128),
-                                   (16, 32, 64, 128)])
-def test_conv_wgrad(G, prec, shape):
-    """dW of Conv2d(big->small) == dW of ConvTranspose2d(small->big): one kernel, checked against both."""
+                                   (16, 32, 64, 128), (3, 64, 64, 128), (9, 16, 32, 64), (5, 8, 32, 192), (21, 8, 64, 64)])
+def test_conv_wgrad(G, prec, shape, halo):
+    """dW of Conv2d(big->small) == dW of ConvTranspose2d(small->big): one kernel, checked against both.  halo=2: the
+    tap-reuse kernel (wgrad_halo.hpp: all four patch geometries, ragged image counts, split-K over several workgroups) where
+    the shape admits it; halo=0: the per-tap gather kernels."""
     n, hb, cb, cs = shape
+    if halo == 0 and prec == 1:
+        pytest.skip("the fp32 path has one kernel")
+    G.lib.jck_tune(b"wgrad_halo", halo)
     g = torch.Generator().manual_seed(3)
     big = G.rnd(torch.randn(n, cb, hb, hb, generator=g), prec)
     small = G.rnd(torch.randn(n, cs, hb // 2, hb // 2, generator=g), prec)
@@ -109,6 +115,7 @@ def test_conv_wgrad(G, prec, shape):
                          G.cur_stream())
     torch.cuda.synchronize()
     G.check(grad.cpu(), ref, 3e-6 if prec == 1 else 2e-3, "conv_wgrad(overwrite)")
+    G.lib.jck_tune(b"wgrad_halo", 1)
 
 
 @pytest.mark.parametrize("prec", PRECS)
