@@ -176,9 +176,16 @@ def measure(a, model, world, rank, dev, dist):
               for _ in range(4)] if cgan else None
     red = GradReducer(world) if world > 1 else None
 
-    def one_step(i):
+    count = [0]
+
+    def one_step(_i):
         # device-side RNG inside the step like the reference: noise=None draws n1 | z | n2, alpha (and the dropout masks)
-        kw = dict(reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world) if red else {}
+        i = count[0]
+        count[0] += 1
+        kw = {}
+        if red:     # data parallel: SUM all-reduce of both gradient arenas; the next batch is announced so that the forward half
+            #         of its D(real) pass runs under G's all-reduce
+            kw = dict(reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world, next_real=None if cgan else batches[(i + 1) % 4])
         eng.step_async(batches[i % 4], None, 2e-4, generator=gen, labels=labels[i % 4] if cgan else None, **kw)
 
     for i in range(a.warmup):

@@ -254,6 +254,13 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
  * activation set, and scalar accumulators / BatchNorm records are double-buffered on the parity of `step`. */
 #define JCK_PHASE_D_REAL 5
 #define JCK_PHASE_D_FAKE 6
+/* PHASE_D_REAL_FWD (DCGAN, batched schedule): the forward half of D(real) of step k+1 only - input transform, instance noise,
+ * conv stack with its BatchNorm statistics (:160-162) - issued with the inputs of step k+1 between PHASE_G_LOSS and
+ * PHASE_G_STEP of step k, i.e. while G's gradient all-reduce of step k is in flight (data parallel): it needs D's weights
+ * (final since PHASE_D_STEP of step k) and nothing of G.  PHASE_D_LOSS of step k+1 then skips that part and runs
+ * [fake | penalty] as one 2B forward behind it; everything else (heads, losses, the 3B backward) is unchanged, so results
+ * are bitwise those of the plain order.  Returns JCK_E_ARG when the engine's schedule has no such split (CGAN, per-pass). */
+#define JCK_PHASE_D_REAL_FWD 7
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */

@@ -146,6 +146,7 @@ struct jck_engine {
   struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds; } bset;
   int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
   bool gp_done = false;
+  long long real_fwd_step = -1;         // step whose D(real) forward already ran (PHASE_D_REAL_FWD), -1: none
   float* d_rs[JCK_MAX_STAGES];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
@@ -898,15 +899,19 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       if (!cg && e->batched == 3) {                   // [real | fake | penalty] as one 3B pass after G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
+        // D(real)'s forward of this step may already have run under the previous step's G all-reduce (PHASE_D_REAL_FWD)
+        const bool pre = e->real_fwd_step == (long long)in->step;
+        e->real_fwd_step = -1;
         HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
-        JCK_TRY(prep_real(e, in, B, st));   // :160
+        if (!pre) JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
         JCK_TRY(e->mix_fake_noise(in, B, st));   // :171
         JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
-        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA));                   // :162-176, 178
+        if (pre) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                          // :173, 118 as one 2B forward
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, pre));              // :162-176, 178
         e->gp_done = true;
         return JCK_OK;
       }
@@ -960,6 +965,17 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       JCK_TRY(d_forward(e, D0, e->fake, B, 1, in->drop_mask[1], st));                             // :173
       JCK_TRY(d_head(e, D0, B, 0.1f, 0, 1, 4, st));                                               // :174,176
       JCK_TRY(d_backward(e, D0, e->fake, B, true, false, in->drop_mask[1], st, sA));              // :175
+      return JCK_OK;
+    }
+    case JCK_PHASE_D_REAL_FWD: {
+      // forward half of D(real) of step in->step, ahead of its PHASE_D_LOSS: touches only real_noisy and group 0 of the batched
+      // set (activations, statistic slots, scale/shift table) and the BatchNorm record of (parity of in->step, pass 0) - nothing
+      // the G phase of the step before it reads or writes
+      if (cg || e->batched != 3 || e->capturing) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL_FWD: only with the batched DCGAN schedule, outside a capture");
+      if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL_FWD needs real_nchw (or real_u8)");
+      JCK_TRY(prep_real(e, in, B, st));                                                           // :160
+      JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                               // :162
+      e->real_fwd_step = in->step;
       return JCK_OK;
     }
     case JCK_PHASE_D_GP: {

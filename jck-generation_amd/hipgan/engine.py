@@ -12,7 +12,7 @@ import torch
 
 from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, load_library
 
-PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE = range(7)
+PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD = range(8)
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
@@ -493,20 +493,31 @@ class DcganEngine:
         self._keep = keep
 
     def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None, graph=None,
-                   generator=None, labels=None):
+                   generator=None, labels=None, next_real=None, next_noise=None):
         """Enqueues one full step; no host sync.  noise=None draws on the device (generator= / labels= as draw_noise takes
         them).  graph (default: on, env JCK_GRAPH=0 disables; never with the pipeline or per-launch profiling): replay the
         step from captured hipGraphs on the engine's own stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
         optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
         env JCK_PIPELINE=1 enables): run the G phase - with G's gradient all-reduce - on a second stream so that the next
         step's D(real) pass overlaps it.  On one GPU the in-step overlap already saturates the memory system and the
-        pipeline measured 8 % slower; it exists for the multi-GPU case where it hides the G all-reduce."""
+        pipeline measured 8 % slower; it exists for the multi-GPU case where it hides the G all-reduce.
+        next_real (with reduce_g; DCGAN, batched schedule, eager launches): the NEXT step's real batch.  The forward half of
+        its D(real) pass (input transform, instance noise - next_noise["n1"] when the caller supplies noise tensors -, conv
+        stack + BatchNorm statistics) is then enqueued right behind the start of G's gradient all-reduce, so the collective
+        runs under ~0.13 ms of compute that needs no G weights, instead of being waited for at once; the next step_async call
+        must be given that same batch.  Results are bitwise those of the plain order (PHASE_D_REAL_FWD, include/jckgan.h)."""
         if pipeline is None:
             pipeline = self.family == 0 and os.environ.get("JCK_PIPELINE", "0") == "1"
         if self._packed_version != self._shared["version"]:
             self.join()
             self.repack()
         use_graph = (self.graphs if graph is None else graph) and not pipeline and self._eager_steps >= 1
+        pre_key = getattr(self, "_prefetched_real", None)
+        if pre_key is not None:
+            self._prefetched_real = None
+            if pre_key != self._real_key(real):
+                raise JckError("step_async: the batch announced as next_real of the previous step must be this step's real batch")
+            use_graph = False                       # D(real)'s forward of this step is already enqueued
         if use_graph:
             try:
                 return self._step_graph(real, noise, lr, reduce_d, reduce_g, grad_scale, generator, labels)
@@ -550,6 +561,8 @@ class DcganEngine:
             lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
             handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
             if handle is not None:
+                if next_real is not None and self.family == 0 and getattr(self, "_prefetch_ok", True) and not (self.graphs if graph is None else graph):
+                    keep += self._prefetch_real(next_real, next_noise, lr, grad_scale, st)     # runs under G's all-reduce
                 handle()
             lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1
@@ -557,6 +570,22 @@ class DcganEngine:
         self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
         self._packed_version = self._shared["version"]
         self._keep = keep
+
+    @staticmethod
+    def _real_key(real):
+        return (real.data.data_ptr(), real.idx.data_ptr()) if isinstance(real, DeviceBatch) else (real.data_ptr(),)
+
+    def _prefetch_real(self, next_real, next_noise, lr, grad_scale, st):
+        """PHASE_D_REAL_FWD of step t+2 (self.t is still t during step t+1).  -> tensors to keep alive until the stream has run."""
+        si2, keep2 = self._inputs(next_real, {"n1": (next_noise or {}).get("n1")}, lr, grad_scale)
+        si2.step = self.t + 2
+        try:
+            lib.jck_engine_phase(self._h, PHASE_D_REAL_FWD, C.byref(si2), st)
+        except JckError:
+            self._prefetch_ok = False               # per-pass schedule (batch % 8 != 0, JCK_BATCHED): no such split
+            return []
+        self._prefetched_real = self._real_key(next_real)
+        return keep2
 
     def _reduce_d(self, reduce_d):
         """Starts D's gradient all-reduce; hands the reducer the early bucket of the batched schedule when it takes one."""

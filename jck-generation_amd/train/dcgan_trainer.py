@@ -262,8 +262,21 @@ class DCGANTrainer(Trainer):
         for epoch in range(self.epoch):
             if hasattr(getattr(loader, "sampler", None), "set_epoch"):
                 loader.sampler.set_epoch(epoch)                   # host-data path: a new shuffle / shard every epoch
-            for i, data in enumerate(loader):
-                real = data[0] if isinstance(data[0], DeviceBatch) else data[0].to(self.device, torch.float32, non_blocking=True).contiguous()
+            to_dev = lambda d: d[0] if isinstance(d[0], DeviceBatch) else d[0].to(self.device, torch.float32, non_blocking=True).contiguous()
+            it, nxt_real = iter(loader), None
+            nxt = next(it, None)
+            for i in range(len(loader)):
+                if nxt is None:
+                    break
+                real = nxt_real if nxt_real is not None else to_dev(nxt)
+                nxt = next(it, None)
+                # data parallel: the next batch is announced to the step, which runs the forward half of its D(real) pass under
+                # G's gradient all-reduce (hipgan/engine.py step_async next_real); same-sized batches only (one engine per size)
+                nxt_real = to_dev(nxt) if (nxt is not None and self.world > 1 and not self.host_rng) else None
+                if nxt_real is not None and nxt_real.size(0) != real.size(0):
+                    announce = None
+                else:
+                    announce = nxt_real
                 eng = self._engine_for(real.size(0))
                 noise = None
                 if self.host_rng:           # reference order: train/dcgan_trainer.py:160,168,171,111
@@ -272,7 +285,8 @@ class DCGANTrainer(Trainer):
                              "n2": torch.randn(b, 3, 64, 64, generator=hg), "alpha": torch.rand(b, 1, 1, 1, generator=hg)}
                 elif self.noise_gen is not None:
                     noise = eng.draw_noise(self.noise_gen, fast=eng.fast_noise)
-                eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world)
+                eng.step_async(real, noise, self.optimizer_d.lr, reduce_d=reduce, reduce_g=reduce, grad_scale=1.0 / self.world,
+                               next_real=announce)
                 eng.record_scalars(history[iters])
                 if i % LOG_EVERY == 0:
                     self._finish_eval(best, wait=False)              # host part of a finished evaluation (scores, checkpoint)

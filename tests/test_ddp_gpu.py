@@ -39,11 +39,17 @@ def _worker(rank, world, port, q, steps, B):
     red = GradReducer(world)
     imgs = synth_images(B * world * steps)
     out = []
+    batch = lambda s: (imgs[(s * world + rank) * B:(s * world + rank + 1) * B].cuda(),
+                       {k: v.cuda() for k, v in _noise(B, 1000 + 10 * s + rank).items()})
+    cur = batch(0)
     for s in range(steps):
-        real = imgs[(s * world + rank) * B:(s * world + rank + 1) * B].cuda()
-        nz = {k: v.cuda() for k, v in _noise(B, 1000 + 10 * s + rank).items()}
-        eng.step_async(real, nz, 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
+        nxt = batch(s + 1) if s + 1 < steps else (None, None)
+        # the next batch is announced: with the batched schedule (B = 8) the forward half of its D(real) pass runs under G's
+        # all-reduce; the per-pass schedule (B = 4) has no such split and ignores the announcement
+        eng.step_async(cur[0], cur[1], 2e-4, reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world,
+                       next_real=nxt[0], next_noise=nxt[1])
         out.append(eng.scalars())
+        cur = nxt
     gs, ds = eng.state_dicts()
     np_ = lambda sd: {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}      # numpy: no shared-memory handles
     q.put((rank, out, np_(gs), np_(ds)))
@@ -57,7 +63,7 @@ def test_two_replicas_match_ddp_oracle(B):
     all-reduced from a side stream as soon as the engine's bucket event fires, the rest at the end of the phase."""
     from oracle.gan_oracle import GanOracle, ddp_step
     from util import synth_images
-    world, steps = 2, 2
+    world, steps = 2, 2                  # the second step's D(real) forward is announced by the first (B = 8)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
@@ -196,3 +202,45 @@ def test_rccl_world1_reduce_paths_leave_every_bit_unchanged(tmp_path):
     port = str(29500 + ((os.getpid() + 13) % 2000))
     r = subprocess.run([sys.executable, str(script), ROOT, port], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL1-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("prec,explicit", [("bf16", False), ("f32", True)])
+def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
+    """step_async(next_real=...) moves the forward half of the next step's D(real) pass in front of this step's G optimiser
+    phase (PHASE_D_REAL_FWD - the work that hides G's gradient all-reduce when data parallel).  Same kernels on the same data
+    in the same per-tensor order: every weight, Adam moment, BatchNorm statistic and logged scalar must be bit-identical to
+    the plain order, with in-kernel instance noise and with explicit noise tensors."""
+    sys.path.insert(0, os.path.join(ROOT, "jck-generation_amd"))
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images
+    B, steps = 16, 4
+    imgs = synth_images(B * steps).cuda()
+    res = []
+    for announce in (False, True):
+        torch.manual_seed(12345)
+        g, d = build_params("dcgan")
+        eng = DcganEngine(batch=B, prec=prec, device="cuda:0")
+        eng.graphs = False
+        eng.load_state(g, d)
+        eng.set_noise_seed(77)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        waits = []
+        red = lambda flat, **kw: (lambda: waits.append(1))            # a reducer that changes nothing (world 1)
+        scal = []
+        for s in range(steps):
+            nz = {k: v.cuda() for k, v in _noise(B, 300 + s).items()} if explicit else None
+            nn = ({k: v.cuda() for k, v in _noise(B, 300 + s + 1).items()} if explicit else None) if s + 1 < steps else None
+            kw = dict(next_real=imgs[(s + 1) * B:(s + 2) * B], next_noise=nn) if (announce and s + 1 < steps) else {}
+            eng.step_async(imgs[s * B:(s + 1) * B], nz, 2e-4, reduce_d=red, reduce_g=red, generator=gen, **kw)
+            scal.append(eng.scalars())
+        assert len(waits) == 2 * steps
+        if announce:
+            assert getattr(eng, "_prefetch_ok", True)
+        gs, ds = eng.state_dicts()
+        res.append((scal, {k: v.clone() for k, v in gs.items()}, {k: v.clone() for k, v in ds.items()},
+                    {t: {k: v.clone() for k, v in eng.named_views(t, w).items()} for t in "gd" for w in ("m",)}))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2]), (res[0][3]["g"], res[1][3]["g"]), (res[0][3]["d"], res[1][3]["d"])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
