@@ -186,6 +186,12 @@ int jck_label_embed_fwd(int prec, const int64_t* labels, const float* W, const f
                         void* cbuf, int ld, int col0, float* pre, void* stream);
 int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope, int B,
                         int NI, int NO, float* dW, float* db, void* stream);
+/* `_tiled`: the B rows are label_period-row batches stacked on top of each other that share one [label_period][NI] label
+ * tensor - the real | fake | penalty groups of a CGAN step (train/cgan_trainer.py:181-203); label_period 0 = one label row per row */
+int jck_label_embed_fwd_tiled(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI, int NO,
+                              void* cbuf, int ld, int col0, float* pre, int label_period, void* stream);
+int jck_label_embed_bwd_tiled(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
+                              int B, int NI, int NO, float* dW, float* db, int label_period, void* stream);
 /* torch.cat([flatten(a4), e], 1) (model/CGAN.py:117-120) and its backward split */
 int jck_concat_rows(int prec, const void* a4, int K0, void* cbuf, int ld, int B, void* stream);
 int jck_split_rows(int prec, const void* gc, int ld, int K0, void* ga4, int B, void* stream);

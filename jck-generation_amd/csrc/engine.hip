@@ -147,6 +147,7 @@ struct jck_engine {
   int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
   bool gp_done = false;
   long long real_fwd_step = -1;         // step whose D(real) forward already ran (PHASE_D_REAL_FWD), -1: none
+  int head_row0 = 0;                    // CGAN: first row of the head buffers the pass in hand uses (2B: penalty group of a batched head)
   float* d_rs[JCK_MAX_STAGES];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
@@ -253,17 +254,20 @@ struct jck_engine {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, TT.G_HS[i] * 2, TT.G_HS[i] * 2, TT.G_CB[i], TT.G_CS[i]));
     }
     w = std::max(w, jck_g1_wgrad_ws_bytes(B, z_pad(family), TT.G_C1));
-    if (family == 1) w = std::max(w, jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT));
+    if (family == 1) w = std::max(std::max(w, jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT)), jck_linear_wgrad_ws_bytes(2 * B, L1_KPAD, L1_OUT));
     wg_ws_bytes = w;
     wg_ws = c.take<float>(w / 4);
     if (family == 1) {
       l1_w = c.take<unsigned char>(bytes((size_t)L1_OUT * L1_KPAD)); l1_wT = c.take<unsigned char>(bytes((size_t)L1_KPAD * L1_OUT));
-      cbuf = c.take<unsigned char>(bytes((size_t)B * L1_KPAD)); cbuf2 = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
-      h_pre = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); h_drop = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
-      g_h = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); g_hd = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
+      // head buffers: HR batches of rows - the batched schedule runs the label / Linear / Dropout head of the real | fake |
+      // penalty groups as ONE 3B-row pass (cg_head_batched)
+      const size_t HR = batched ? 3 : 1;
+      cbuf = c.take<unsigned char>(bytes(HR * B * L1_KPAD)); cbuf2 = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
+      h_pre = c.take<unsigned char>(bytes(HR * B * L1_OUT)); h_drop = c.take<unsigned char>(bytes(HR * B * L1_OUT));
+      g_h = c.take<unsigned char>(bytes(HR * B * L1_OUT)); g_hd = c.take<unsigned char>(bytes(HR * B * L1_OUT));
       gh_b1 = c.take<unsigned char>(bytes((size_t)B * L1_OUT)); ughd = c.take<unsigned char>(bytes((size_t)B * L1_OUT));
-      gc = c.take<unsigned char>(bytes((size_t)B * L1_KPAD));
-      pre_e = c.take<float>((size_t)B * EMB); l1_slab = c.take<float>((size_t)L1_KSPLIT * B * L1_OUT);
+      gc = c.take<unsigned char>(bytes(HR * B * L1_KPAD));
+      pre_e = c.take<float>(HR * B * EMB); l1_slab = c.take<float>((size_t)L1_KSPLIT * HR * B * L1_OUT);
       gw1p = c.take<float>((size_t)L1_OUT * L1_KPAD); rs = c.take<float>(B); prob_gp = c.take<float>(B);
       for (int i = 0; i < TT.NS; ++i) {
         const size_t n = (size_t)B * (TT.D_HB[i] / 2) * (TT.D_HB[i] / 2) * TT.D_CS[i];
@@ -467,14 +471,17 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 // D forward up to (not including) the sigmoid head.  family 1: concat + Linear(8392,256) + Dropout (model/CGAN.py:117-122)
 // CGAN head up to the dropped-out hidden layer from the conv features a4 [B][8192] (model/CGAN.py:111-121): concat with the
 // label embedding, Linear(8392,256), Dropout.  Leaves cbuf, pre_e, h_pre, h_drop for the matching d_head_backward.
-static int cg_head_forward(jck_engine* e, const void* a4, int B, const float* drop_mask, hipStream_t st) {
+// rows: B, or 3B for the batched head (label_period = B: the three groups share the batch's labels; drop_mask = their three
+// [B][256] masks back to back)
+static int cg_head_forward(jck_engine* e, const void* a4, int rows, const float* drop_mask, hipStream_t st, int label_period = 0) {
   if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
-  JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, B, st));
-  JCK_TRY(jck_label_embed_fwd(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
-                              e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, B, N_CLASS, EMB, e->cbuf, L1_KPAD, TT.FEAT, e->pre_e, st));
-  JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
+  JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, rows, st));
+  JCK_TRY(jck_label_embed_fwd_tiled(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
+                                    e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, rows, N_CLASS, EMB, e->cbuf, L1_KPAD, TT.FEAT,
+                                    e->pre_e, label_period, st));
+  JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, rows, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   return jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
-                           e->h_drop, B, L1_OUT, st);
+                           e->h_drop, rows, L1_OUT, st);
 }
 
 static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
@@ -496,21 +503,44 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
   if (e->family == 0)
     return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, ga4_out, want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr,
                              e->head_ws, st);
-  // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds
-  JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), e->h_drop, B, L1_OUT, e->g_hd,
+  // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds.  Head buffers from row e->head_row0 on (the
+  // penalty group of a batched head sits at rows [2B, 3B))
+  const size_t r0 = (size_t)e->head_row0;
+  auto hb = [&](void* p, size_t per_row) { return (void*)((unsigned char*)p + r0 * per_row * e->esz); };
+  void *h_drop = hb(e->h_drop, L1_OUT), *g_hd = hb(e->g_hd, L1_OUT), *g_h = hb(e->g_h, L1_OUT), *cbuf = hb(e->cbuf, L1_KPAD), *gc = hb(e->gc, L1_KPAD);
+  const float* pre_e = e->pre_e + r0 * EMB;
+  JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), h_drop, B, L1_OUT, g_hd,
                        want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, e->head_ws, st));
   if (want_wgrad) JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), st));
-  JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)B * L1_OUT, st));
+  JCK_TRY(jck_dropout(e->prec, g_hd, drop_mask, 1.0f / 0.75f, g_h, (long long)B * L1_OUT, st));
   if (want_wgrad) {
-    JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
-    JCK_TRY(jck_colsum(e->prec, e->g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
+    JCK_TRY(jck_linear_wgrad(e->prec, g_h, L1_OUT, cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
+    JCK_TRY(jck_colsum(e->prec, g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
   }
-  JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
-  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, TT.FEAT, ga4_out, B, st));
+  JCK_TRY(jck_linear_fwd(e->prec, g_h, e->l1_wT, nullptr, gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
+  JCK_TRY(jck_split_rows(e->prec, gc, L1_KPAD, TT.FEAT, ga4_out, B, st));
   if (want_wgrad)
-    JCK_TRY(jck_label_embed_bwd(e->prec, e->gc, L1_KPAD, TT.FEAT, e->pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
+    JCK_TRY(jck_label_embed_bwd(e->prec, gc, L1_KPAD, TT.FEAT, pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
                                 e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), st));
   return JCK_OK;
+}
+
+// The head backward of the real | fake | penalty groups as ONE pass over 3B rows (forward: cg_head_forward(rows = 3B)): input
+// gradients for all three, parameter gradients from the first two (the penalty's come from its double backward, PHASE_D_GP).
+// 11 launches instead of 26; the penalty group's rows [2B, 3B) stay behind as gp_double_backward expects them.
+static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const float* drop_mask, void* ga4_out, hipStream_t st) {
+  const int R3 = 3 * B, R2 = 2 * B;
+  const float* w2 = e->P(e->LD, e->dp, "linear2.weight");
+  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R3, L1_OUT, e->g_hd, nullptr, 1, e->head_ws, st));
+  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, st));
+  JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), st));
+  JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)R3 * L1_OUT, st));
+  JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, R2, L1_OUT, st));
+  JCK_TRY(jck_colsum(e->prec, e->g_h, R2, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
+  JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, R3, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
+  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, TT.FEAT, ga4_out, R3, st));
+  return jck_label_embed_bwd_tiled(e->prec, e->gc, L1_KPAD, TT.FEAT, e->pre_e, e->cur_labels, LRELU, R2, N_CLASS, EMB,
+                                   e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), B, st);
 }
 
 // D backward on set `D`.  With `side` != nullptr the weight-gradient products run on that stream beside the dgrad chain
@@ -688,7 +718,8 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
     (void)hipEventRecord(e->evWdone, side);
     (void)hipStreamWaitEvent(st, e->evWdone, 0);
   };
-  HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->gh_b1, (const unsigned char*)e->g_h + (size_t)e->head_row0 * L1_OUT * esz, (size_t)B * L1_OUT * esz,
+                        hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->prob_gp, P.prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
   JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, TT.HW, e->d_u0, st));
   // ---- v-chain: adjoint of the first backward, swept forward through D
@@ -865,14 +896,24 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st));
         auto& S = e->bset;
         const float tg[2] = {0.9f, 0.1f};
+        // the three dropout masks back to back (hipgan/engine.py hands them over that way): the head runs once over 3B rows
+        const bool head3 = in->drop_mask[0] && in->drop_mask[1] == in->drop_mask[0] + (size_t)B * L1_OUT &&
+                           in->drop_mask[2] == in->drop_mask[0] + (size_t)2 * B * L1_OUT;
+        e->head_row0 = 0;
+        if (head3) JCK_TRY(cg_head_forward(e, S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B));
         for (int g = 0; g < 3; ++g) {
           const bool pen = g == 2;
           void* a4 = (unsigned char*)S.a[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;
           void* g4 = (unsigned char*)S.g[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;
-          JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
-          JCK_TRY(jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
+          if (!head3) JCK_TRY(cg_head_forward(e, a4, B, in->drop_mask[g], st));
+          const void* hd = (const unsigned char*)e->h_drop + (head3 ? (size_t)g * B * L1_OUT * e->esz : 0);
+          JCK_TRY(jck_head_fwd(e->prec, hd, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
                                pen ? 0.f : tg[g], pen ? 1 : 0, S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : g, pen ? -1 : 3 + g, e->acc_ld, st));
-          JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
+          if (!head3) JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
+        }
+        if (head3) {
+          JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st));
+          e->head_row0 = 2 * B;                        // where PHASE_D_GP finds the penalty group's head state
         }
         JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
         e->gp_done = true;
@@ -984,6 +1025,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         e->gp_done = false;
         static const bool cg_side2 = cgan_side;
         JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side2 ? sA : nullptr));
+        e->head_row0 = 0;
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
         return JCK_OK;
       }

@@ -855,12 +855,13 @@ static __global__ void unperm_linear_grad_kernel(const float* __restrict__ gp, i
 template <typename T>
 __global__ void label_embed_fwd_kernel(const long long* __restrict__ labels, const float* __restrict__ W,
                                        const float* __restrict__ bias, float slope, int B, int NI, int NO, T* __restrict__ cbuf,
-                                       int ld, int col0, float* __restrict__ pre) {
+                                       int ld, int col0, float* __restrict__ pre, int label_period = 0) {
   // one workgroup per image: the label row goes to LDS once; its zeros (99 of 100 for a one-hot row) are skipped - a
   // workgroup-uniform branch, and adding an exact 0 * W changes nothing
   extern __shared__ float lab[];                      // [NI]
   const int b = blockIdx.x;
-  for (int k = threadIdx.x; k < NI; k += blockDim.x) lab[k] = (float)labels[(long long)b * NI + k];
+  const int lb = label_period > 0 ? b % label_period : b;       // rows of several batches that share one label tensor
+  for (int k = threadIdx.x; k < NI; k += blockDim.x) lab[k] = (float)labels[(long long)lb * NI + k];
   __syncthreads();
   for (int j = threadIdx.x; j < NO; j += blockDim.x) {
     float s = bias[j];
@@ -880,7 +881,7 @@ __global__ void label_embed_fwd_kernel(const long long* __restrict__ labels, con
 template <typename T>
 __global__ __launch_bounds__(256) void label_embed_bwd_kernel(const T* __restrict__ gc, int ld, int col0, const float* __restrict__ pre,
                                                               const long long* __restrict__ labels, float slope, int B, int NI,
-                                                              int NO, float* __restrict__ dW, float* __restrict__ db) {
+                                                              int NO, float* __restrict__ dW, float* __restrict__ db, int label_period = 0) {
   extern __shared__ float lcol[];                     // [B]: this label column, fetched by all threads at once
   const int i = blockIdx.x;
   if (i >= NI) {
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void label_embed_bwd_kernel(const T* __restric
   }
   __shared__ int nnz;
   int* rows = reinterpret_cast<int*>(lcol + B);       // [B]: indices of the rows with a non-zero label, in order
-  for (int b = threadIdx.x; b < B; b += blockDim.x) lcol[b] = (float)labels[(long long)b * NI + i];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) lcol[b] = (float)labels[(long long)(label_period > 0 ? b % label_period : b) * NI + i];
   if (threadIdx.x == 0) nnz = 0;
   __syncthreads();
   // ordered compaction (deterministic summation order) by wavefront ballots, 256 rows per round; a serial loop of one thread

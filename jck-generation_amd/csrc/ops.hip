@@ -462,10 +462,11 @@ static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, h
 }
 
 // ---- tap-reuse plan (wgrad_halo.hpp): a workgroup owns 64 cs x (16 taps x 32 cb); split-K over 64-pixel k-steps ----
-static bool wgrad_halo_shape(int prec, int Hb, int Wb, int Cb, int cbp, int Cs) {
+static bool wgrad_halo_shape(int prec, int Hb, int Wb, int Cb, int cbp, int Cs, long long N = 1) {
   const int OW = Wb / 2;
+  const long long big_bytes = N * Hb * Wb * (long long)Cb * 2, s_bytes = N * (Hb / 2) * (Wb / 2) * (long long)Cs * 2;
   return prec == JCK_PREC_BF16 && Hb == Wb && (OW == 4 || OW == 8 || OW == 16 || OW == 32) && cbp == Cb && Cb % 32 == 0 &&
-         Cs % 64 == 0;
+         Cs % 64 == 0 && big_bytes < (1ll << 31) && s_bytes < (1ll << 31);      // 32-bit byte offsets inside the kernel
 }
 static WgradPlan plan_wgrad_halo(long long Mtot, int cbp, int Cs) {
   WgradPlan pl;
@@ -557,7 +558,7 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
   // tap-reuse kernel where it measured faster than the per-tap gather (tests/_mb2.py wgrad_halo 0 1 ...): >= 32 k-steps per
   // workgroup (the 2B-image products of the D phase: +4..12 %; 16 k-steps: -5..-12 %, the 128 KB fp32 tile each workgroup
   // writes into its split-K slab is then a third of its time).  JCK_WGRAD_HALO=2 forces it for every admissible shape.
-  bool halo = g_wgrad_halo && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs);
+  bool halo = g_wgrad_halo && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs, N);
   if (halo && g_wgrad_halo != 2 && plan_wgrad_halo(p.Mtot, cbp, Cs).mchunk < 32 * 64) halo = false;
   const WgradPlan pl = halo ? plan_wgrad_halo(p.Mtot, cbp, Cs) : plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
   int rc = halo ? launch_wgrad_halo(p, pl, ws, ws_bytes, (hipStream_t)stream)
@@ -995,19 +996,31 @@ extern "C" int jck_linear_finish(int prec, const float* slab, int Z, const float
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
+// `_tiled`: B rows that are `label_period`-row batches stacked on top of each other, all labelled by the same [label_period][NI]
+// tensor (the real | fake | penalty groups of one CGAN step share the batch's labels, train/cgan_trainer.py:181-203)
+extern "C" int jck_label_embed_fwd_tiled(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI,
+                                         int NO, void* cbuf, int ld, int col0, float* pre, int label_period, void* stream) {
+  if (label_period < 0 || (label_period > 0 && B % label_period)) JCK_FAIL(JCK_E_ARG, "label_embed: rows are not a multiple of the label period");
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_fwd_kernel<T>, dim3(B), dim3(256), (size_t)NI * sizeof(float), (hipStream_t)stream,
+                                      (const long long*)labels, W, b, slope, B, NI, NO, (T*)cbuf, ld, col0, pre, label_period));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float* W, const float* b, float slope, int B, int NI,
                                    int NO, void* cbuf, int ld, int col0, float* pre, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_fwd_kernel<T>, dim3(B), dim3(256), (size_t)NI * sizeof(float), (hipStream_t)stream,
-                                      (const long long*)labels, W, b, slope, B, NI, NO, (T*)cbuf, ld, col0, pre));
+  return jck_label_embed_fwd_tiled(prec, labels, W, b, slope, B, NI, NO, cbuf, ld, col0, pre, 0, stream);
+}
+extern "C" int jck_label_embed_bwd_tiled(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
+                                         int B, int NI, int NO, float* dW, float* db, int label_period, void* stream) {
+  if (label_period < 0 || (label_period > 0 && B % label_period)) JCK_FAIL(JCK_E_ARG, "label_embed: rows are not a multiple of the label period");
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + cdiv(NO, 64)), dim3(256), (size_t)B * (sizeof(float) + sizeof(int)), (hipStream_t)stream,
+                                      (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db, label_period));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
 extern "C" int jck_label_embed_bwd(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
                                    int B, int NI, int NO, float* dW, float* db, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + cdiv(NO, 64)), dim3(256), (size_t)B * (sizeof(float) + sizeof(int)), (hipStream_t)stream,
-                                      (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db));
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
+  return jck_label_embed_bwd_tiled(prec, gc, ld, col0, pre, labels, slope, B, NI, NO, dW, db, 0, stream);
 }
 extern "C" int jck_concat_rows(int prec, const void* a4, int K0, void* cbuf, int ld, int B, void* stream) {
   if (K0 % 8 || ld % 8) JCK_FAIL(JCK_E_ARG, "concat_rows: K0 % 8 or ld % 8");

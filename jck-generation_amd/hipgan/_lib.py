@@ -64,6 +64,8 @@ PROTOS = {
     "jck_unperm_linear_grad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "jck_label_embed_fwd": (i32, [i32, vp, vp, vp, f32, i32, i32, i32, vp, i32, i32, vp, vp]),
     "jck_label_embed_bwd": (i32, [i32, vp, i32, i32, vp, vp, f32, i32, i32, i32, vp, vp, vp]),
+    "jck_label_embed_fwd_tiled": (i32, [i32, vp, vp, vp, f32, i32, i32, i32, vp, i32, i32, vp, i32, vp]),
+    "jck_label_embed_bwd_tiled": (i32, [i32, vp, i32, i32, vp, vp, f32, i32, i32, i32, vp, vp, i32, vp]),
     "jck_concat_rows": (i32, [i32, vp, i32, vp, i32, i32, vp]),
     "jck_split_rows": (i32, [i32, vp, i32, i32, vp, i32, vp]),
     "jck_dropout": (i32, [i32, vp, vp, f32, vp, i64, vp]),

@@ -274,11 +274,19 @@ class DcganEngine:
             lab = labels.to(self.device).contiguous()
             keep.append(lab)
             si.labels = lab.data_ptr()
+            ms = [noise.get(f"m{i + 1}") for i in range(4)]
+            if any(m is None for m in ms):
+                raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
+            # the engine runs the head of the real | fake | penalty groups as one 3B-row pass when their masks lie back to
+            # back: hand them over as one [4, B, 256] tensor (draw_noise already makes them that way)
+            adjacent = all(torch.is_tensor(m) and m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.numel() == B * 256
+                           for m in ms) and all(ms[i + 1].data_ptr() == ms[i].data_ptr() + B * 256 * 4 for i in range(3))
+            if not adjacent:
+                mm = torch.stack([m.to(self.device, torch.float32).reshape(B, 256) for m in ms])
+                keep.append(mm)
+                ms = [mm[i] for i in range(4)]
             for i in range(4):
-                m = noise.get(f"m{i + 1}")
-                if m is None:
-                    raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
-                si.drop_mask[i] = ptr(m, B * 256)
+                si.drop_mask[i] = ptr(ms[i], B * 256)
         return si, keep
 
     def set_noise_seed(self, seed):
@@ -300,12 +308,7 @@ class DcganEngine:
             nz = {"n1": None, "z": z, "n2": None, "alpha": alpha}
             if self.family == 1:
                 nz["labels"] = labels
-                for i in range(4):
-                    if out is None:
-                        nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
-                    else:
-                        u = torch.rand(B, 256, generator=generator, out=out["u"])
-                        nz[f"m{i + 1}"] = out[f"m{i + 1}"].copy_(u >= 0.25)
+                self._draw_masks(nz, generator, out)
             return nz
         # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
         ni, nzz = B * 3 * S * S, B * 100
@@ -321,13 +324,20 @@ class DcganEngine:
               "alpha": alpha}
         if self.family == 1:
             nz["labels"] = labels
-            for i in range(4):          # nn.Dropout(0.25) keep masks of the four D passes (model/CGAN.py:105)
-                if out is None:
-                    nz[f"m{i + 1}"] = (torch.rand(B, 256, device=dev, generator=generator) >= 0.25).float()
-                else:
-                    u = torch.rand(B, 256, generator=generator, out=out["u"])
-                    nz[f"m{i + 1}"] = out[f"m{i + 1}"].copy_(u >= 0.25)
+            self._draw_masks(nz, generator, out)
         return nz
+
+    def _draw_masks(self, nz, generator, out):
+        """nn.Dropout(0.25) keep masks of the four D passes (model/CGAN.py:105) from ONE uniform draw [4, B, 256] (three launches
+        instead of twelve: the step is a serial chain, every ~5 us launch counts)."""
+        B, dev = self.batch, self.device
+        if out is None:
+            m = (torch.rand(4, B, 256, device=dev, generator=generator) >= 0.25).float()
+        else:
+            u = torch.rand(4, B, 256, generator=generator, out=out["u"])
+            m = out["m"].copy_(u >= 0.25)
+        for i in range(4):
+            nz[f"m{i + 1}"] = m[i]
 
     # ---- cross-step pipeline -------------------------------------------------------------------------------
     # The G phase of step k (D pass on the fake batch, backward into G, Adam(G), G's gradient all-reduce) runs on a second
@@ -365,9 +375,10 @@ class DcganEngine:
                   "real": torch.empty(B, 3, S, S, **f32), "idx": torch.empty(B, dtype=torch.int64, device=dev)}
             if self.family == 1:
                 sb["labels"] = torch.empty(B, 100, dtype=torch.int64, device=dev)
-                sb["u"] = torch.empty(B, 256, **f32)
+                sb["u"] = torch.empty(4, B, 256, **f32)
+                sb["m"] = torch.empty(4, B, 256, **f32)
                 for i in range(4):
-                    sb[f"m{i + 1}"] = torch.empty(B, 256, **f32)
+                    sb[f"m{i + 1}"] = sb["m"][i]              # one address per mask whether it is drawn or handed in
             self._sbuf = sb
         return self._sbuf
 
