@@ -147,7 +147,8 @@ struct jck_engine {
   int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
   bool gp_done = false;
   long long real_fwd_step = -1;         // step whose D(real) forward already ran (PHASE_D_REAL_FWD), -1: none
-  int head_row0 = 0;                    // CGAN: first row of the head buffers the pass in hand uses (2B: penalty group of a batched head)
+  int head_row0 = 0;                    // CGAN: first row of the head state (h_drop, cbuf, pre_e) the pass in hand READS (2B: penalty group of a batched head)
+  int head_wrow0 = 0;                   //       first row of the head buffers it WRITES (g_hd, g_h, gc)
   float* d_rs[JCK_MAX_STAGES];                       // deferred BatchNorm running-stat records of D: [step parity][pass 0..3][2*C] per layer
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
@@ -505,9 +506,10 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
                              e->head_ws, st);
   // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds.  Head buffers from row e->head_row0 on (the
   // penalty group of a batched head sits at rows [2B, 3B))
-  const size_t r0 = (size_t)e->head_row0;
-  auto hb = [&](void* p, size_t per_row) { return (void*)((unsigned char*)p + r0 * per_row * e->esz); };
-  void *h_drop = hb(e->h_drop, L1_OUT), *g_hd = hb(e->g_hd, L1_OUT), *g_h = hb(e->g_h, L1_OUT), *cbuf = hb(e->cbuf, L1_KPAD), *gc = hb(e->gc, L1_KPAD);
+  const size_t r0 = (size_t)e->head_row0, w0 = (size_t)e->head_wrow0;
+  auto hb = [&](void* p, size_t row, size_t per_row) { return (void*)((unsigned char*)p + row * per_row * e->esz); };
+  void *h_drop = hb(e->h_drop, r0, L1_OUT), *cbuf = hb(e->cbuf, r0, L1_KPAD);
+  void *g_hd = hb(e->g_hd, w0, L1_OUT), *g_h = hb(e->g_h, w0, L1_OUT), *gc = hb(e->gc, w0, L1_KPAD);
   const float* pre_e = e->pre_e + r0 * EMB;
   JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), h_drop, B, L1_OUT, g_hd,
                        want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, e->head_ws, st));
@@ -718,9 +720,18 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
     (void)hipEventRecord(e->evWdone, side);
     (void)hipStreamWaitEvent(st, e->evWdone, 0);
   };
-  HIPCHK(hipMemcpyAsync(e->gh_b1, (const unsigned char*)e->g_h + (size_t)e->head_row0 * L1_OUT * esz, (size_t)B * L1_OUT * esz,
-                        hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->prob_gp, P.prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // the first backward's gradient at the Linear(8392,256) output and the penalty pass's probabilities: read in place after a
+  // batched head (its penalty rows [2B, 3B) are not written again: the head backward below writes rows [0, B)), copied aside
+  // otherwise (the per-pass head backward below overwrites g_h)
+  const void* gh1 = e->gh_b1;
+  const float* prob1 = e->prob_gp;
+  if (e->head_row0 > 0) {
+    gh1 = (const unsigned char*)e->g_h + (size_t)e->head_row0 * L1_OUT * esz;
+    prob1 = P.prob;
+  } else {
+    HIPCHK(hipMemcpyAsync(e->gh_b1, e->g_h, (size_t)B * L1_OUT * esz, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->prob_gp, P.prob, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   JCK_TRY(jck_gp_grad(e->prec, e->d_gx, e->norms, 2.0f * lambda / (float)B, B, TT.HW, e->d_u0, st));
   // ---- v-chain: adjoint of the first backward, swept forward through D
   const void* u = e->d_u0;
@@ -736,10 +747,10 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   }
   // head: gc[:, :8192] = gh W1 -> adj(gh) = [u4 | 0] W1^T, dW1 += gh^T [u4 | 0]; gh = gh' * m/(1-p); gh' = ds w2; ds = p(1-p)
   JCK_TRY(jck_concat_rows(e->prec, e->d_v[TT.NS - 1], TT.FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
-  JCK_TRY(jck_linear_wgrad(e->prec, e->gh_b1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
+  JCK_TRY(jck_linear_wgrad(e->prec, gh1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
-  JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), e->prob_gp, B, L1_OUT, e->rs,
+  JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
                        e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
   join();
@@ -914,6 +925,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         if (head3) {
           JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st));
           e->head_row0 = 2 * B;                        // where PHASE_D_GP finds the penalty group's head state
+          e->head_wrow0 = 0;
         }
         JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
         e->gp_done = true;

@@ -1065,8 +1065,11 @@ __global__ __launch_bounds__(256) void bn2_reduce_kernel(const T* __restrict__ a
 
 // sums[i] = sum over workgroups of partial[blk][i], i < NA*C (a multiple of 4): one workgroup per 4 outputs, 256 lanes over
 // the partials with 16-byte loads (one thread per output looping over 256 strided partials took 64 us for C = 64)
+// mode 1 (v-chain): dgamma[c] += sum(v*gy)[c] / gamma[c] (the direct parameter gradient of the v-chain);  mode 2 (reverse sweep):
+// dgamma[c] += sum uz*xhat, dbeta[c] += sum uz - by the thread that owns that sum, instead of a launch of their own
 static __global__ __launch_bounds__(256) void bn2_sums_kernel(const float* __restrict__ partial, int nblk, int NA, int C,
-                                                              float* __restrict__ sums) {
+                                                              float* __restrict__ sums, int mode = 0, const float* __restrict__ gamma = nullptr,
+                                                              float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
   __shared__ float sh[4][4];
   const int i0 = blockIdx.x * 4, n = NA * C;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -1078,7 +1081,14 @@ static __global__ __launch_bounds__(256) void bn2_sums_kernel(const float* __res
     for (int j = 0; j < 4; ++j) sh[threadIdx.x >> 6][j] = s[j];
   }
   __syncthreads();
-  if (threadIdx.x < 4) sums[i0 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (threadIdx.x < 4) {
+    const int i = i0 + threadIdx.x;
+    const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    sums[i] = t;
+    if (mode == 1 && i >= 2 * C && i < 3 * C) dgamma[i - 2 * C] += t / gamma[i - 2 * C];
+    if (mode == 2 && i < C) dbeta[i] += t;
+    if (mode == 2 && i >= C && i < 2 * C) dgamma[i - C] += t;
+  }
 }
 
 // v-chain apply:  u = act'(z) * (gamma/sigma) (v - mean v - xhat * mean(v xhat))                 (may overwrite v)
@@ -1110,12 +1120,6 @@ __global__ void bn2_vchain_apply_kernel(const T* __restrict__ v, const T* __rest
     st8(xdir + i * 8, ox);
   }
 }
-// direct parameter gradient of the v-chain: dgamma[c] += sum(v*gy) / gamma[c]
-static __global__ void bn2_vchain_dgamma_kernel(const float* __restrict__ s3, const float* __restrict__ gamma, float* __restrict__ dgamma, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) dgamma[c] += s3[2 * C + c] / gamma[c];
-}
-
 // reverse-sweep apply with the penalty's extra inputs:
 //   q = gamma*uz + xdir;  uy = (q - mean q - xhat*mean(q xhat)) / sigma  -  (sum(v*gy)/sigma) * xhat / n
 // s4 = {sum uz, sum uz*xhat, sum xdir, sum xdir*xhat};  vgy = sum v*gy (from the v-chain).  dgamma += sum uz*xhat, dbeta += sum uz
@@ -1144,11 +1148,6 @@ __global__ void bn2_reverse_apply_kernel(const T* __restrict__ ua, const T* __re
     st8(uy + i * 8, o);
   }
 }
-static __global__ void bn2_reverse_dparam_kernel(const float* __restrict__ s4, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) { dgamma[c] += s4[C + c]; dbeta[c] += s4[c]; }
-}
-
 // h[b][j] = sum_z slab[z][b][j] + bias[j];  hd = h * mask * scale     (Linear(8392,256) finish + Dropout, model/CGAN.py:104-105,122)
 template <typename T>
 __global__ void linear_finish_kernel(const float* __restrict__ slab, int Z, long long zstride, const float* __restrict__ bias,

@@ -1086,16 +1086,13 @@ extern "C" int jck_bn2_vchain(int prec, const void* v, const void* y, const void
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 3 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)v, (const T*)y, (const T*)gy, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn2_sums_kernel, dim3(3 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws);
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(3 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws, dgamma ? 1 : 0, gamma,
+                     dgamma, (float*)nullptr);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn2_vchain_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream, (const T*)v,
                                       (const T*)y, (const T*)gy, aux, s1, ws, slope, 1.0f / (float)rows, (T*)u, (T*)xdir, total8, C));
   HIPCHK(hipGetLastError());
-  if (dgamma) {
-    hipLaunchKernelGGL(bn2_vchain_dgamma_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, gamma, dgamma, C);
-    HIPCHK(hipGetLastError());
-  }
   return JCK_OK;
 }
 // reverse-sweep BatchNorm backward with the penalty's extra inputs (xdir, sum v*gy from the v-chain at vsums[2C..3C)).
@@ -1109,17 +1106,14 @@ extern "C" int jck_bn2_reverse(int prec, const void* ua, const void* y, const vo
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 4 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)ua, (const T*)y, (const T*)xdir, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn2_sums_kernel, dim3(4 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws);
+  hipLaunchKernelGGL(bn2_sums_kernel, dim3(4 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws,
+                     (dgamma && dbeta) ? 2 : 0, (const float*)nullptr, dgamma, dbeta);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, hipLaunchKernelGGL(bn2_reverse_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)ua, (const T*)y, (const T*)xdir, aux, gamma, ws, vsums + 2 * C, slope,
                                       1.0f / (float)rows, (T*)uy, total8, C));
   HIPCHK(hipGetLastError());
-  if (dgamma && dbeta) {
-    hipLaunchKernelGGL(bn2_reverse_dparam_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, dgamma, dbeta, C);
-    HIPCHK(hipGetLastError());
-  }
   return JCK_OK;
 }
 
