@@ -151,6 +151,11 @@ int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out,
  * stores, summed in a fixed order by the step tail (no float atomics anywhere on the path). */
 int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias /* device scalar or NULL */, int B, int K,
                  float target, int mode, float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream);
+/* G (<= 4) batches of B rows stacked in a4 / prob / ds (the real | fake | penalty groups of a batched D pass), each with its own
+ * target, mode and scalar slots, in one launch; the scalar table is indexed by the row inside its group */
+int jck_head_fwd_grouped(int prec, const void* a4, const float* wp, const float* bias, int B, int K, int G, const float* targets,
+                         const int* modes, float* prob, float* ds, float* scal, const int* slot_loss, const int* slot_p,
+                         int scal_ld, void* stream);
 /* floats of workspace for the weight-gradient partial rows of jck_head_bwd / jck_head_bwd_conv (K = 16*C there) */
 size_t jck_head_bwd_ws_floats(int K);
 /* g_a4[n][k] = ds[n]*wp[k];  dwp[k] (+)= sum_n ds[n]*a4[n][k] through `ws` (partial rows summed in order: deterministic) */

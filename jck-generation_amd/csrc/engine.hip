@@ -665,10 +665,14 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   const int gw = G - 1;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   if (!forward_done) JCK_TRY(d_batched_forward(e, x_in, B, 0, G, pass0, st));
-  for (int g = 0; g < G; ++g) {
-    const bool pen = g == G - 1;
-    JCK_TRY(jck_head_fwd(e->prec, at(S.a[TT.NS - 1], (size_t)g * B * TT.FEAT), e->d_head_wp, nullptr, B, TT.FEAT, pen ? 0.f : targets[g], pen ? 1 : 0,
-                         S.prob + g * B, S.ds + g * B, e->acc, pen ? -1 : slot_loss[g], pen ? -1 : slot_p[g], e->acc_ld, st));
+  {
+    float tg[4] = {0.f, 0.f, 0.f, 0.f};
+    int md[4] = {0, 0, 0, 0}, sl[4] = {-1, -1, -1, -1}, sp[4] = {-1, -1, -1, -1};
+    for (int g = 0; g < G; ++g) {
+      const bool pen = g == G - 1;
+      tg[g] = pen ? 0.f : targets[g]; md[g] = pen ? 1 : 0; sl[g] = pen ? -1 : slot_loss[g]; sp[g] = pen ? -1 : slot_p[g];
+    }
+    JCK_TRY(jck_head_fwd_grouped(e->prec, S.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, G, tg, md, S.prob, S.ds, e->acc, sl, sp, e->acc_ld, st));
   }
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]), e->head_ws, st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[TT.NS - 1], (size_t)gw * B * TT.FEAT), B, TT.G_C1,
@@ -912,7 +916,13 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
                            in->drop_mask[2] == in->drop_mask[0] + (size_t)2 * B * L1_OUT;
         e->head_row0 = 0;
         if (head3) JCK_TRY(cg_head_forward(e, S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B));
-        for (int g = 0; g < 3; ++g) {
+        if (head3) {
+          const float tg3[3] = {tg[0], tg[1], 0.f};
+          const int md3[3] = {0, 0, 1}, sl3[3] = {0, 1, -1}, sp3[3] = {3, 4, -1};
+          JCK_TRY(jck_head_fwd_grouped(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
+                                       3, tg3, md3, S.prob, S.ds, e->acc, sl3, sp3, e->acc_ld, st));
+        }
+        for (int g = 0; g < 3 && !head3; ++g) {
           const bool pen = g == 2;
           void* a4 = (unsigned char*)S.a[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;
           void* g4 = (unsigned char*)S.g[TT.NS - 1] + (size_t)g * B * TT.FEAT * e->esz;

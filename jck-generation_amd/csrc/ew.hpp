@@ -428,12 +428,19 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restric
 //   mode 0: loss = mean BCE;  dp = (p - t) / max(p(1-p), 1e-12) / B;  ds = dp * p(1-p)      (ATen formulas)
 //   mode 1: gradient-penalty pass, grad_outputs = ones:          ds = p(1-p)
 // ------------------------------------------------------------------------------------------------------
+// Several batches stacked row-wise (the real | fake | penalty groups of the batched D pass) go through ONE launch: group
+// g = row / rows_per_group has its own target, mode and scalar slots; prob / ds are indexed by the stacked row, the scalar table
+// by the row inside the group.
+struct HeadGroups { float target[4]; int mode[4], slot_loss[4], slot_p[4]; int rows_per_group; };
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4, const float* __restrict__ w, int K,
-                                                       const float* __restrict__ bias, float target, int mode, float invB,
+                                                       const float* __restrict__ bias, const HeadGroups hg, float invB,
                                                        float* __restrict__ prob, float* __restrict__ ds,
-                                                       float* __restrict__ scal, int slot_loss, int slot_p, int scal_ld) {
+                                                       float* __restrict__ scal, int scal_ld) {
   __shared__ float sm[4];
+  const int grp = blockIdx.x / hg.rows_per_group, nrow = blockIdx.x - grp * hg.rows_per_group;
+  const float target = hg.target[grp];
+  const int mode = hg.mode[grp], slot_loss = hg.slot_loss[grp], slot_p = hg.slot_p[grp];
   const T* x = a4 + (long long)blockIdx.x * K;
   float s = 0.f;
   for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
@@ -454,11 +461,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4,
       const float loss = -(target * lp + (1.f - target) * lq);
       const float dp = (p - target) / fmaxf(pq, 1e-12f) * invB;
       ds[blockIdx.x] = dp * pq;
-      if (slot_loss >= 0) scal[(long long)slot_loss * scal_ld + blockIdx.x] = loss;
+      if (slot_loss >= 0) scal[(long long)slot_loss * scal_ld + nrow] = loss;
     } else {
       ds[blockIdx.x] = pq;
     }
-    if (slot_p >= 0) scal[(long long)slot_p * scal_ld + blockIdx.x] = p;
+    if (slot_p >= 0) scal[(long long)slot_p * scal_ld + nrow] = p;
   }
 }
 

@@ -830,14 +830,26 @@ extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale,
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
-extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias, int B, int K, float target, int mode,
-                            float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream) {
+// G (<= 4) batches of B rows stacked in a4 / prob / ds, each with its own target, mode and scalar slots - one launch
+extern "C" int jck_head_fwd_grouped(int prec, const void* a4, const float* wp, const float* bias, int B, int K, int G,
+                                    const float* targets, const int* modes, float* prob, float* ds, float* scal,
+                                    const int* slot_loss, const int* slot_p, int scal_ld, void* stream) {
   if (K % 8) JCK_FAIL(JCK_E_ARG, "head_fwd: K % 8 != 0");
-  if ((slot_loss >= 0 || slot_p >= 0) && (!scal || scal_ld < B)) JCK_FAIL(JCK_E_ARG, "head_fwd: scalar slots need scal with scal_ld >= B");
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K, bias,
-                                      target, mode, 1.0f / (float)B, prob, ds, scal, slot_loss, slot_p, scal_ld));
+  if (G < 1 || G > 4 || B < 1) JCK_FAIL(JCK_E_ARG, "head_fwd: 1..4 groups of >= 1 rows");
+  HeadGroups hg = {};
+  hg.rows_per_group = B;
+  for (int g = 0; g < G; ++g) {
+    hg.target[g] = targets[g]; hg.mode[g] = modes[g]; hg.slot_loss[g] = slot_loss[g]; hg.slot_p[g] = slot_p[g];
+    if ((slot_loss[g] >= 0 || slot_p[g] >= 0) && (!scal || scal_ld < B)) JCK_FAIL(JCK_E_ARG, "head_fwd: scalar slots need scal with scal_ld >= B");
+  }
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(G * B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K, bias,
+                                      hg, 1.0f / (float)B, prob, ds, scal, scal_ld));
   HIPCHK(hipGetLastError());
   return JCK_OK;
+}
+extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, const float* bias, int B, int K, float target, int mode,
+                            float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream) {
+  return jck_head_fwd_grouped(prec, a4, wp, bias, B, K, 1, &target, &mode, prob, ds, scal, &slot_loss, &slot_p, scal_ld, stream);
 }
 #define HEAD_NS 8          /* partial rows of jck_head_bwd */
 #define HEAD_CONV_NS 16    /* partial rows of jck_head_bwd_conv */

@@ -55,6 +55,7 @@ PROTOS = {
     "jck_gp_norm": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp]),
     "jck_tanh_bwd": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "jck_head_fwd": (i32, [i32, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "jck_head_fwd_grouped": (i32, [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "jck_head_bwd_ws_floats": (sz, [i32]),
     "jck_pack_linear": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "jck_linear_fwd": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
