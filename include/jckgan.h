@@ -275,15 +275,16 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */
-  const float* z;          /* [B,100] N(0,1) */
+  const float* z;          /* [B,100] N(0,1); NULL: the engine's own draw for this step (jck_engine_set_step, jck_step_rng) */
   const float* noise_fake; /* [B,3,64,64] N(0,1) */
-  const float* alpha;      /* [B] U[0,1) */
+  const float* alpha;      /* [B] U[0,1); NULL: the engine's own draw */
   float lr;
   float grad_scale;        /* 1/world_size when grads were SUM-all-reduced, else 1 */
   int step;                /* 1-based optimiser step (Adam bias correction) */
   /* family 1 (CGAN) only: */
   const int64_t* labels;   /* [B,100] one-hot int64 (preprocess/cgan_data_preprocessor.py:11-16) */
-  const float* drop_mask[4]; /* [B,256] 0/1 keep masks of nn.Dropout(0.25) for the 4 D passes (real, fake, GP, G phase) */
+  const float* drop_mask[4]; /* [B,256] 0/1 keep masks of nn.Dropout(0.25) for the 4 D passes (real, fake, GP, G phase); all four
+                              * NULL: the engine's own draws.  Masks 0..2 back to back in memory let the head run once over 3B rows */
   /* device-resident dataset (optional; used instead of real_nchw when real_u8 != NULL): uint8 [Ntot,3,32,32] + the batch's
    * indices int64 [B]; the step applies the input transform itself (jck_img_prep_u8) */
   const unsigned char* real_u8;
@@ -330,6 +331,11 @@ int jck_engine_set_step(jck_engine*, int step, float lr, void* stream);
  * keyed by `seed`, counter = (pixel, tensor, optimiser step), Box-Muller normals - no 25 MB noise tensor per step.  The *_rng
  * entry points are the per-op forms (rng: device uint32[4] = {seed lo, seed hi, step, 0}; tensor_id separates real / fake). */
 int jck_engine_set_noise_seed(jck_engine*, unsigned long long seed);
+/* The step's small random inputs as jck_engine_set_step draws them when jck_step_inputs carries none (z, alpha, CGAN's
+ * Dropout keep masks NULL): z [nz] ~ N(0,1) (train/dcgan_trainer.py:168), alpha [nalpha] ~ U[0,1) (:111), masks [nmask] in {0,1}
+ * with P(1) = keep_p (model/CGAN.py:105); Philox4x32-10, counter = (index/4, tensor id, step), key = seed.  hp: 8 floats scratch. */
+int jck_step_rng(float* hp, int step, unsigned long long seed, float* z, long long nz, float* alpha, long long nalpha,
+                 float* masks, long long nmask, float keep_p, void* stream);
 int jck_img_prep_rng(int prec, const float* img_nchw, const unsigned* rng, int tensor_id, float keep, float mix, void* out, int N, int HW,
                      void* stream);
 int jck_img_prep_u8_rng(int prec, const unsigned char* data, const int64_t* idx, const unsigned* rng, int tensor_id, float keep,

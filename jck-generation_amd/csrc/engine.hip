@@ -168,6 +168,7 @@ struct jck_engine {
   float *head_ws, *gp2_ws;              // partial rows of the head weight gradients (deterministic two-stage sums)
   float* hp2;                           // [2 parities][8]: {step_size, bc2_sqrt, -, -, noise seed lo, hi, step, 0} of the step in flight (jck_engine_set_step)
   unsigned long long noise_seed = 0x6a636b67616e0001ull;      // in-kernel instance noise (jck_engine_set_noise_seed)
+  float *rz[2] = {nullptr, nullptr}, *ralpha[2] = {nullptr, nullptr}, *rmask[2] = {nullptr, nullptr};
   int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases)
   bool capturing = false;
   float* wg_ws; size_t wg_ws_bytes;
@@ -246,6 +247,11 @@ struct jck_engine {
     acc2 = c.take<float>((size_t)2 * 8 * acc_ld); scal2 = c.take<float>(16);
     acc = acc2; scal_out = scal2;
     hp2 = c.take<float>(16);
+    // the step's small random inputs when the caller hands over none, per step parity (jck_engine_set_step draws them)
+    for (int q = 0; q < 2; ++q) {
+      rz[q] = c.take<float>((size_t)B * 100); ralpha[q] = c.take<float>((size_t)(B + 3) / 4 * 4);
+      rmask[q] = family == 1 ? c.take<float>((size_t)4 * B * L1_OUT) : nullptr;
+    }
     head_ws = c.take<float>(jck_head_bwd_ws_floats(TT.FEAT));
     gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
     size_t w = 0;
@@ -852,8 +858,18 @@ static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_
 // ---------------------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in, void* stream) {
-  if (!e || !e->bound || !in) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
+extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream) {
+  if (!e || !e->bound || !in_) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
+  // z, alpha and (CGAN) the Dropout keep masks left NULL: the engine's own draws for this step (jck_engine_set_step)
+  jck_step_inputs loc = *in_;
+  {
+    const int q = loc.step & 1;
+    if (!loc.z) loc.z = e->rz[q];
+    if (!loc.alpha) loc.alpha = e->ralpha[q];
+    if (e->family == 1 && !loc.drop_mask[0] && !loc.drop_mask[1] && !loc.drop_mask[2] && !loc.drop_mask[3])
+      for (int i = 0; i < 4; ++i) loc.drop_mask[i] = e->rmask[q] + (size_t)i * e->B * L1_OUT;
+  }
+  const jck_step_inputs* in = &loc;
   hipStream_t st = (hipStream_t)stream;
   const int B = e->B, HW = TT.HW;
   const bool cg = e->family == 1;
@@ -1111,7 +1127,9 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
 extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
-  JCK_TRY(jck_adam_set_step(e->hp2 + 8 * (step & 1), (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream));
+  const int q = step & 1;
+  JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream, e->rz[q], (long long)e->B * 100,
+                            e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f));
   e->hp_step[step & 1] = step;
   return JCK_OK;
 }

@@ -574,13 +574,43 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // hp (optional): device float[2] = {step_size, bc2_sqrt} of THIS step, written by adam_hp_kernel before the step is enqueued
 // - the whole-step engine passes its per-step scalars this way so that a captured hipGraph of the step carries no
 // per-step kernel argument; the values are the same host-computed floats either way.
-// hp[0..1] = Adam's per-step scalars; hp[4..7] (as uint32) = {noise seed lo, hi, step, 0} for the in-kernel Philox noise
+// hp[0..1] = Adam's per-step scalars; hp[4..7] (as uint32) = {noise seed lo, hi, step, 0} for the in-kernel Philox noise.
+// The same launch draws the step's SMALL random inputs when the caller hands over none (perf mode): z [nz] ~ N(0,1)
+// (train/dcgan_trainer.py:168), alpha [nalpha] ~ U[0,1) (:111), CGAN's Dropout keep masks [nmask] in {0,1} with P(keep) = keep_p
+// (model/CGAN.py:105) - Philox4x32-10, counter = (index/4, tensor id 8 / 9 / 10, step), key = seed.  No ATen launch is left
+// in the step, and a captured step replays with fresh draws without any copy into static buffers.
+struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; };
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt, unsigned seed_lo, unsigned seed_hi,
-                                      unsigned step) {
+                                      unsigned step, const StepRng r) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     hp[0] = step_size; hp[1] = bc2_sqrt;
-    unsigned* r = reinterpret_cast<unsigned*>(hp + 4);
-    r[0] = seed_lo; r[1] = seed_hi; r[2] = step; r[3] = 0u;
+    unsigned* w = reinterpret_cast<unsigned*>(hp + 4);
+    w[0] = seed_lo; w[1] = seed_hi; w[2] = step; w[3] = 0u;
+  }
+  const long long q0 = (r.nz + 3) / 4, q1 = (r.nalpha + 3) / 4, q2 = (r.nmask + 3) / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q0 + q1 + q2; i += (long long)gridDim.x * blockDim.x) {
+    unsigned o[4];
+    if (i < q0) {                                                     // four normals: two Box-Muller pairs
+      philox4x32_10((unsigned)i, (unsigned)(i >> 32), 8u, step, seed_lo, seed_hi, o);
+      const float r0 = sqrtf(-2.0f * logf(u01(o[0]))), r1 = sqrtf(-2.0f * logf(u01(o[2])));
+      float s0, c0, s1, c1;
+      sincosf(6.283185307179586f * u01(o[1]), &s0, &c0);
+      sincosf(6.283185307179586f * u01(o[3]), &s1, &c1);
+      const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+      for (int k = 0; k < 4; ++k)
+        if (i * 4 + k < r.nz) r.z[i * 4 + k] = v[k];
+    } else if (i < q0 + q1) {
+      const long long j = i - q0;
+      philox4x32_10((unsigned)j, (unsigned)(j >> 32), 9u, step, seed_lo, seed_hi, o);
+      for (int k = 0; k < 4; ++k)
+        if (j * 4 + k < r.nalpha) r.alpha[j * 4 + k] = (float)(o[k] >> 8) * (1.0f / 16777216.0f);      // [0, 1)
+    } else {
+      const long long j = i - q0 - q1;
+      philox4x32_10((unsigned)j, (unsigned)(j >> 32), 10u, step, seed_lo, seed_hi, o);
+      for (int k = 0; k < 4; ++k)
+        if (j * 4 + k < r.nmask) r.masks[j * 4 + k] = (float)(o[k] >> 8) * (1.0f / 16777216.0f) < r.keep_p ? 1.f : 0.f;
+    }
   }
 }
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

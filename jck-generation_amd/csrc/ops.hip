@@ -904,13 +904,25 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
   return JCK_OK;
 }
 // the same update with {step_size, bc2_sqrt} read from device memory: jck_adam_set_step writes them (same host arithmetic)
-int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st) {
+// ... and (rz / ralpha / rmasks, each optional) the step's small random inputs, drawn by the same launch (ew.hpp: adam_hp_kernel)
+int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st, float* rz,
+                      long long nz, float* ralpha, long long nalpha, float* rmasks, long long nmask, float keep_p) {
   if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
-  hipLaunchKernelGGL(adam_hp_kernel, dim3(1), dim3(64), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,
-                     (unsigned)(seed >> 32), (unsigned)step);
+  StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p};
+  const long long quads = (r.nz + 3) / 4 + (r.nalpha + 3) / 4 + (r.nmask + 3) / 4;
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 512));
+  hipLaunchKernelGGL(adam_hp_kernel, dim3(blocks), dim3(256), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,
+                     (unsigned)(seed >> 32), (unsigned)step, r);
   HIPCHK(hipGetLastError());
   return JCK_OK;
+}
+// test / binding access to the per-step draws: fills z [nz] ~ N(0,1), alpha [nalpha] ~ U[0,1), masks [nmask] ~ Bernoulli(keep_p)
+// exactly as jck_engine_set_step does for step `step` and noise seed `seed`; hp: device float[8] scratch
+extern "C" int jck_step_rng(float* hp, int step, unsigned long long seed, float* z, long long nz, float* alpha, long long nalpha,
+                            float* masks, long long nmask, float keep_p, void* stream) {
+  if (!hp) JCK_FAIL(JCK_E_ARG, "step_rng: hp scratch (8 floats) is required");
+  return jck_adam_set_step(hp, 2e-4, 0.5, 0.999, step, seed, (hipStream_t)stream, z, nz, alpha, nalpha, masks, nmask, keep_p);
 }
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st) {

@@ -35,7 +35,9 @@ void jck_set_error(const std::string& s);
 
 int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots);
 // Adam with {step_size, bc2_sqrt} in device memory (ops.hip): the engine's step has no per-step kernel argument
-int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st);
+int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st,
+                      float* rz = nullptr, long long nz = 0, float* ralpha = nullptr, long long nalpha = 0, float* rmasks = nullptr,
+                      long long nmask = 0, float keep_p = 0.75f);
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st);
 bool jck_prof_is_on();

@@ -113,6 +113,7 @@ PROTOS = {
     "jck_mean_cov_f64": (i32, [vp, vp, vp, i32, i32, vp]),
     "jck_engine_set_step": (i32, [vp, i32, f32, vp]),
     "jck_engine_set_noise_seed": (i32, [vp, C.c_ulonglong]),
+    "jck_step_rng": (i32, [vp, i32, C.c_ulonglong, vp, C.c_longlong, vp, C.c_longlong, vp, C.c_longlong, f32, vp]),
     "jck_img_prep_rng": (i32, [i32, vp, vp, i32, f32, f32, vp, i32, i32, vp]),
     "jck_img_prep_u8_rng": (i32, [i32, vp, vp, vp, i32, f32, f32, vp, i32, i32, i32, vp]),
     "jck_axpy_noise_rng": (i32, [i32, vp, vp, i32, f32, f32, vp, i32, i32, vp]),

@@ -275,8 +275,10 @@ class DcganEngine:
             keep.append(lab)
             si.labels = lab.data_ptr()
             ms = [noise.get(f"m{i + 1}") for i in range(4)]
+            if all(m is None for m in ms):
+                return si, keep                     # the engine draws its own masks (and z / alpha when those are None too)
             if any(m is None for m in ms):
-                raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
+                raise JckError("CGAN step needs all four dropout keep-masks m1..m4 [B,256] (or none: drawn by the engine)")
             # the engine runs the head of the real | fake | penalty groups as one 3B-row pass when their masks lie back to
             # back: hand them over as one [4, B, 256] tensor (draw_noise already makes them that way)
             adjacent = all(torch.is_tensor(m) and m.is_cuda and m.dtype == torch.float32 and m.is_contiguous() and m.numel() == B * 256
@@ -299,16 +301,12 @@ class DcganEngine:
         alpha (and the dropout masks); the two [B,3,S,S] instance-noise tensors are then drawn inside the step's kernels."""
         B, dev, S = self.batch, self.device, self.size
         if fast:
-            if out is None:
-                z = torch.randn(B, 100, 1, 1, device=dev, generator=generator)
-                alpha = torch.rand(B, 1, 1, 1, device=dev, generator=generator)
-            else:
-                z = torch.randn(B, 100, 1, 1, generator=generator, out=out["z"])
-                alpha = torch.rand(B, 1, 1, 1, generator=generator, out=out["alpha"])
-            nz = {"n1": None, "z": z, "n2": None, "alpha": alpha}
+            # perf mode: NOTHING is drawn here - z, alpha and CGAN's dropout masks come out of the engine's per-step launch
+            # (jck_engine_set_step: Philox keyed by set_noise_seed and the step), the two instance-noise tensors out of the
+            # image kernels; `generator` plays no part
+            nz = {"n1": None, "z": None, "n2": None, "alpha": None}
             if self.family == 1:
                 nz["labels"] = labels
-                self._draw_masks(nz, generator, out)
             return nz
         # one normal draw for n1 | z | n2 (three launches -> one; the order inside the buffer is the reference's)
         ni, nzz = B * 3 * S * S, B * 100
@@ -399,10 +397,13 @@ class DcganEngine:
             if up:
                 buf[:ni].view(B, 3, S, S).copy_(noise["n1"], non_blocking=True)
                 buf[ni + nzz:].view(B, 3, S, S).copy_(noise["n2"], non_blocking=True)
-            buf[ni:ni + nzz].view(B, 100, 1, 1).copy_(noise["z"].view(B, 100, 1, 1), non_blocking=True)
-            sb["alpha"].copy_(noise["alpha"].view(B, 1, 1, 1), non_blocking=True)
-            nz = {"n1": buf[:ni].view(B, 3, S, S) if up else None, "z": buf[ni:ni + nzz].view(B, 100, 1, 1),
-                  "n2": buf[ni + nzz:].view(B, 3, S, S) if up else None, "alpha": sb["alpha"]}
+            zin, ain = noise.get("z"), noise.get("alpha")
+            if zin is not None:
+                buf[ni:ni + nzz].view(B, 100, 1, 1).copy_(zin.view(B, 100, 1, 1), non_blocking=True)
+            if ain is not None:
+                sb["alpha"].copy_(ain.view(B, 1, 1, 1), non_blocking=True)
+            nz = {"n1": buf[:ni].view(B, 3, S, S) if up else None, "z": buf[ni:ni + nzz].view(B, 100, 1, 1) if zin is not None else None,
+                  "n2": buf[ni + nzz:].view(B, 3, S, S) if up else None, "alpha": sb["alpha"] if ain is not None else None}
             if self.family == 1:
                 lab = noise.get("labels")
                 if lab is None or lab.shape != (B, 100) or lab.dtype != torch.int64:
@@ -410,9 +411,8 @@ class DcganEngine:
                 nz["labels"] = sb["labels"].copy_(lab, non_blocking=True)
                 for i in range(4):
                     m = noise.get(f"m{i + 1}")
-                    if m is None:
-                        raise JckError("CGAN step needs dropout keep-masks m1..m4 [B,256]")
-                    nz[f"m{i + 1}"] = sb[f"m{i + 1}"].copy_(m.view(B, 256), non_blocking=True)
+                    if m is not None:
+                        nz[f"m{i + 1}"] = sb[f"m{i + 1}"].copy_(m.view(B, 256), non_blocking=True)
         if isinstance(real, DeviceBatch):
             if real.size(0) != B:
                 raise JckError(f"DeviceBatch must index {B} images")
@@ -448,7 +448,7 @@ class DcganEngine:
                 segs = ([[PHASE_D_LOSS, PHASE_D_GP]], [[PHASE_D_STEP, PHASE_G_LOSS]], [[PHASE_G_STEP]])
             else:
                 segs = ([[PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP]], [], [])
-            kind = (("u8", real.data.data_ptr()) if isinstance(real, DeviceBatch) else ("f32",)) + (nz.get("n1") is None, nz["z"].data_ptr())
+            kind = (("u8", real.data.data_ptr()) if isinstance(real, DeviceBatch) else ("f32",)) + (nz.get("n1") is None, nz.get("z") is None, nz.get("alpha") is None, nz.get("m1") is None)
             handle = None
 
             launched = []

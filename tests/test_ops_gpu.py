@@ -400,3 +400,34 @@ def test_inkernel_philox_noise(G):
     G.lib.jck_img_prep_u8_rng(G.PREC_F32, data, None, rng, 0, 0.0, 1.0, o3, n, 32, 32, G.cur_stream())
     torch.cuda.synchronize()
     assert torch.equal(o3, a)
+
+
+def test_step_rng_small_inputs(G):
+    """z ~ N(0,1), alpha ~ U[0,1), Dropout keep masks ~ Bernoulli(0.75) as the engine draws them when a step is given none
+    (jck_engine_set_step -> adam_hp_kernel; perf mode of train/dcgan_trainer.py:168,111 and model/CGAN.py:105): moments,
+    independence across the three tensors / steps / seeds, and a pure function of (seed, step, index)."""
+    nz, na, nm = 256 * 100, 4099, 4 * 256 * 256
+
+    def draw(seed, step):
+        hp = torch.zeros(8, device="cuda")
+        z, a, m = torch.empty(nz, device="cuda"), torch.empty(na, device="cuda"), torch.empty(nm, device="cuda")
+        G.lib.jck_step_rng(hp, step, seed, z, nz, a, na, m, nm, 0.75, G.cur_stream())
+        torch.cuda.synchronize()
+        return z.double().cpu(), a.double().cpu(), m.double().cpu(), hp.cpu()
+    z, a, m, hp = draw(99, 5)
+    z2, a2, m2, _ = draw(99, 5)
+    assert torch.equal(z, z2) and torch.equal(a, a2) and torch.equal(m, m2)
+    assert hp.view(torch.int32)[4:7].tolist() == [99, 0, 5]                      # the Philox words the image kernels read
+    assert abs(z.mean().item()) < 0.02 and abs(z.var().item() - 1.0) < 0.03 and abs((z ** 4).mean().item() - 3.0) < 0.15
+    assert 0.0 <= a.min().item() and a.max().item() < 1.0 and abs(a.mean().item() - 0.5) < 0.02 and abs(a.var().item() - 1 / 12) < 0.005
+    assert set(m.unique().tolist()) == {0.0, 1.0} and abs(m.mean().item() - 0.75) < 3e-3
+    for other in (draw(99, 6), draw(100, 5)):                                     # step and seed each change every stream
+        for x, y in zip((z, a, m), other[:3]):
+            assert abs(torch.corrcoef(torch.stack([x, y]))[0, 1].item()) < 0.03
+    k = min(nz, nm)
+    assert abs(torch.corrcoef(torch.stack([z[:k], m[:k]]))[0, 1].item()) < 0.02  # tensor ids decorrelate z from the masks
+    # ragged counts: nothing is written past the ends
+    pad = torch.full((nz + 8,), 7.0, device="cuda")
+    G.lib.jck_step_rng(torch.zeros(8, device="cuda"), 5, 99, pad, nz - 3, None, 0, None, 0, 0.75, G.cur_stream())
+    torch.cuda.synchronize()
+    assert float(pad[nz - 3:].min()) == 7.0 and torch.equal(pad[:nz - 3].double().cpu(), z[:nz - 3])
