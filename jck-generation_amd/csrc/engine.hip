@@ -171,6 +171,7 @@ struct jck_engine {
   float *rz[2] = {nullptr, nullptr}, *ralpha[2] = {nullptr, nullptr}, *rmask[2] = {nullptr, nullptr};
   int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases)
   bool capturing = false;
+  float* g1_ws = nullptr; size_t g1_ws_bytes = 0;
   float* wg_ws; size_t wg_ws_bytes;
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
@@ -264,6 +265,10 @@ struct jck_engine {
     if (family == 1) w = std::max(std::max(w, jck_linear_wgrad_ws_bytes(B, L1_KPAD, L1_OUT)), jck_linear_wgrad_ws_bytes(2 * B, L1_KPAD, L1_OUT));
     wg_ws_bytes = w;
     wg_ws = c.take<float>(w / 4);
+    // G.conv1's weight gradient runs on the MAIN stream at the very end of G's backward (it needs the last BatchNorm backward,
+    // which is on that stream): its own split-K workspace, because the side stream may still be using wg_ws
+    g1_ws_bytes = jck_g1_wgrad_ws_bytes(B, z_pad(family), TT.G_C1);
+    g1_ws = c.take<float>(g1_ws_bytes / 4);
     if (family == 1) {
       l1_w = c.take<unsigned char>(bytes((size_t)L1_OUT * L1_KPAD)); l1_wT = c.take<unsigned char>(bytes((size_t)L1_KPAD * L1_OUT));
       // head buffers: HR batches of rows - the batched schedule runs the label / Linear / Dropout head of the real | fake |
@@ -833,11 +838,10 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
     }
     gbig = e->g_gr[i];
   }
-  // the split-K workspace belongs to the side stream: G.conv1's weight gradient goes there too
-  hipStream_t ws1 = st;
-  if (side) { HIPCHK(hipEventRecord(e->evW[0], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[0], 0)); ws1 = side; }
-  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[0]), 1, B, z_dim(e->family),
-                       z_pad(e->family), TT.G_C1, ws1));
+  // G.conv1's weight gradient depends on the last kernel of the main stream: it runs there, behind it, with its own
+  // workspace (forking it to the side stream cost a ~12 us cross-stream hand-over at the very end of the step, twice)
+  JCK_TRY(jck_g1_wgrad(e->prec, e->g_z, e->g_gr[0], e->g1_ws, e->g1_ws_bytes, e->P(e->LG, e->gg, CWN[0]), 1, B, z_dim(e->family),
+                       z_pad(e->family), TT.G_C1, st));
   if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
   return JCK_OK;
 }
