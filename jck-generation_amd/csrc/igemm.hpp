@@ -558,3 +558,148 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dead tail loads before the epilogue reuses nothing of LDS
   igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form of the wave-specialised LDS-DMA kernel (round 2): gridDim.x <= (workgroups the chip holds) workgroups walk
+// the logical tiles L = blockIdx.x, blockIdx.x + gridDim.x, ...  The loader waves run two k-steps ahead ACROSS tile borders:
+// while the consumer waves store a tile (epilogue: 2-5 us of NHWC stores and BatchNorm partials), the first two stages of the
+// workgroup's next tile are already in flight, and no workgroup launch / LDS allocation sits between two tiles of a CU.
+// Same tiles, same k order, same epilogue as igemm_dma_kernel<.., WS = true> - bitwise the same results.  Both roles
+// execute exactly (tiles of this workgroup) x (K / 64) barriers.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BCH, int BPIX, bool BNB, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const IgemmParams p) {
+  typedef PrecBf16 P;
+  typedef IgemmCfg<P, BCH, BPIX, NCW> C;
+  constexpr int FM = C::FM, FN = C::FN, LD = IG_BK;
+  constexpr int STG_BYTES = (BCH + BPIX) * LD * 2;
+  constexpr int NLD = (BCH + BPIX) / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* lds = smem_raw;
+
+  const bool loader = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= NCW;
+  const int tid = loader ? (int)threadIdx.x - NCW * 64 : (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = p.gx * p.gy * p.gz;
+  const int nk = p.K / IG_BK;
+  const int Cc = 1 << p.logC;
+  // logical tile L -> (bidx, bidy, z): the XCD-aware order of igemm_dma_kernel over ntiles (L % 8 = XCD of every tile of this
+  // workgroup, because gridDim.x is a multiple of 8 whenever a workgroup takes more than one tile)
+  int bidx = 0, bidy = 0, z = 0, m0 = 0, ch0 = 0;
+  auto locate = [&](int L) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = L & 7, idx = L >> 3;
+    const int wgid = __builtin_amdgcn_readfirstlane((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx);
+    bidy = wgid % p.gy;
+    z = (wgid / p.gy) % p.gz;
+    bidx = wgid / (p.gy * p.gz);
+    m0 = bidx * BPIX; ch0 = bidy * BCH;
+  };
+  int my_tiles = 0;
+  for (int L = blockIdx.x; L < ntiles; L += gridDim.x) ++my_tiles;
+  my_tiles = __builtin_amdgcn_readfirstlane(my_tiles);
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  if (loader) {
+    const int lrow = (tid & 255) >> 3, unit = tid & 7;
+    const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;
+    unsigned rowoff[C::APASS], wrowoff[C::WPASS];
+    int riy[C::APASS], rix[C::APASS];
+    auto setup = [&](int L) {
+      locate(L);
+#pragma unroll
+      for (int ps = 0; ps < C::APASS; ++ps) {
+        const int m = m0 + ps * 32 + lrow;
+        const int n = m >> p.logOHW;
+        const int rem = m & ((1 << p.logOHW) - 1);
+        const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
+        rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC)) * 2u;
+        riy[ps] = m < p.M ? iy0 : 0x40000000;
+        rix[ps] = ix0;
+      }
+#pragma unroll
+      for (int ps = 0; ps < C::WPASS; ++ps)
+        wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + lrow) * p.K) * 2);
+    };
+    const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page);
+    auto issue = [&](int kc, int stage) {
+      const int kbase = kc * IG_BK;
+      unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
+#pragma unroll
+      for (int ps = 0; ps < C::WPASS; ++ps) {
+        const unsigned char* src = wb + (wrowoff[ps] + (unsigned)kbase * 2u + src_chunk);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
+      }
+      const int t = __builtin_amdgcn_readfirstlane(kbase >> p.logC);
+      const int tp = p.tap[z][t];
+      const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
+      const unsigned toffb = (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
+#pragma unroll
+      for (int ps = 0; ps < C::APASS; ++ps) {
+        const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
+        const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+      }
+    };
+    // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads
+    int Lq = blockIdx.x, kq = 0, slot = 0;
+    if (my_tiles > 0) setup(Lq);
+    auto next = [&]() {
+      issue(kq, slot);
+      slot = slot == 2 ? 0 : slot + 1;
+      if (kq + 1 < nk) { ++kq; return; }
+      if (Lq + (int)gridDim.x < ntiles) { Lq += gridDim.x; kq = 0; setup(Lq); }   // else: stay on the last k-step (dead re-loads)
+    };
+    if (my_tiles > 0) { next(); next(); }
+    const int steps = my_tiles * nk;
+    for (int s = 0; s < steps; ++s) {
+      if constexpr (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (NLD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else static_assert(NLD == 8 || NLD == 6 || NLD == 12, "add the vmcnt literal");
+      __builtin_amdgcn_s_barrier();                                   // consumers may read this step's stage; the one before is free
+      next();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  const int wch = (C::WCH == 2) ? (wave / C::WPIX) : 0;
+  const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
+  const int sw = ((lane & 15) >> 1) & 7;
+  int slot = 0;
+  for (int L = blockIdx.x; L < ntiles; L += gridDim.x) {
+    locate(L);
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
+    if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
+    for (int k = 0; k < nk; ++k) {
+      __builtin_amdgcn_s_barrier();
+      const bf16_t* wt0 = reinterpret_cast<const bf16_t*>(lds + slot * STG_BYTES);
+      const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD;
+      const bf16_t* at = wt0 + BCH * LD + (wpix * FN * 16 + (lane & 15)) * LD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int col = (((lane >> 4) + ks * 4) ^ sw) * 8;
+        bf16x8 a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + col);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + col);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+      }
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, z, bidx, bidy, m0, ch0, ypre);
+  }
+}

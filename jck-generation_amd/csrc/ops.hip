@@ -25,6 +25,7 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static int g_igemm_dma = env_int("JCK_IGEMM_DMA", 1);        // LDS-DMA gather-GEMM for bf16 tiles
 static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised 128x64 tiles when < 512 tiles of 128x128
 static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
+static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 3);   // persistent form of the wave-specialised gather-GEMMs (igemm.hpp)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
 static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
@@ -34,7 +35,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -160,6 +161,35 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
   return JCK_OK;
 }
 
+// persistent wave-specialised form: at most `cap` workgroups (what the chip holds at this tile's LDS footprint) walk the tiles
+template <int BCH, int BPIX, int NCW>
+static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
+  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2;
+  constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
+  ProfScope prof(variant, p.flops, st);
+  auto kern = p.bn_y ? igemm_dma_persist_kernel<BCH, BPIX, true, NCW> : igemm_dma_persist_kernel<BCH, BPIX, false, NCW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, true, NCW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, false, NCW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
+  IgemmParams q = p;
+  q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
+  if (q.stats) {
+    q.ytiles_per_cset = std::max(1, q.cstat / BCH);
+    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
+  }
+  const int ntiles = (int)(grid.x * grid.y * grid.z);
+  const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
+  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, cap)), dim3((NCW + 4) * 64), LDSB, st, q);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 template <class P>
 static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   // bf16 tiles with >= 128 channel rows run on the LDS-DMA kernel with 2 LDS stages (64 / 48 KB -> 2-3 workgroups per CU,
@@ -177,9 +207,12 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     // JCK_IGEMM_256 = minimum number of such tiles (0 disables).
     const int min256 = g_igemm_256;
     const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
+    const int persist = g_igemm_persist;
     if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && p.logOHW >= 5 && p.M % 256 == 0)
-      return launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
+      return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
+                           : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
+    if (ws_mode && (persist & 2) && !p.act_row_elems) return launch_igemm_dma_persist<128, 64, 4>(p, nch_pad, phases, st, slots);
     if (ws_mode) return launch_igemm_dma<128, 64, 3, true>(p, nch_pad, phases, st, slots);
     return launch_igemm_dma<128, 64, 2>(p, nch_pad, phases, st, slots);
   }
@@ -191,8 +224,10 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     return launch_igemm_t<P, 128, 64, 1>(p, nch_pad, phases, st, slots);
   }
   if (nch_pad == 64) {
-    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases)
+    if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
+      if ((g_igemm_persist & 4) && !p.act_row_elems) return launch_igemm_dma_persist<64, 128, 4>(p, nch_pad, phases, st, slots);
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
+    }
     if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
     return launch_igemm_t<P, 64, 128, 1>(p, nch_pad, phases, st, slots);
   }
