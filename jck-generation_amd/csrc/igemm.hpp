@@ -559,6 +559,58 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
   igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
 }
 
+// Epilogue of the persistent kernel: 16-byte stores.  The loader fills LDS weight row r of every 32-row block with output
+// channel pi(r) = 8*((r&15)>>2) + 4*(r>>4) + (r&3) of that block, so that after the product lane group g = lane>>4 holds channels
+// 8g..8g+3 in fragment 2k and 8g+4..8g+7 in fragment 2k+1: ONE 16-byte store per pixel and fragment pair, 64-byte runs per
+// pixel and store instruction (the shared epilogue writes 8 bytes per lane in 32-byte runs, and an instrumented build without
+// the stores ran the 3B products 11-28 % faster: the store path, not the MFMA, was the tail of every tile).  bf16, no bias / tanh /
+// fp32 output / BatchNorm-backward statistics - the launcher sends those launches to igemm_dma_kernel.
+__device__ __forceinline__ int igemm_perm_row(int r) { return 8 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3); }
+template <int BCH, int BPIX, int FM, int FN, int WPIXN>
+__device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z,
+                                                    int bidx, int bidy, int m0, int ch0) {
+  static_assert(FM % 2 == 0, "fragment pairs");
+  long long poff[FN];
+  igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
+  const int g = lane >> 4;
+  if (p.stats) {
+    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
+    const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
+    float* sp = p.stats + slot * 2 * p.cstat;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int ch = ch0 + wch * FM * 16 + (i >> 1) * 32 + 8 * g + 4 * (i & 1);
+      const bool chok = ch < p.NchStore;
+      const int cc = ch & (p.cstat - 1);
+      float sm[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; sm[r] += v; q[r] += v * v; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); q[r] = row16_sum(q[r]); }
+      if ((lane & 15) == 0 && chok) {
+        *reinterpret_cast<f32x4*>(sp + cc) = f32x4{sm[0], sm[1], sm[2], sm[3]};
+        *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
+      }
+    }
+  }
+  bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    if (poff[j] < 0) continue;
+    const long long off = poff[j] + p.obase[z];
+#pragma unroll
+    for (int k = 0; k < FM / 2; ++k) {
+      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+      if (ch >= p.NchStore) continue;
+      const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
+                          acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
+      st8(outp + off + ch, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Persistent form of the wave-specialised LDS-DMA kernel (round 2): gridDim.x <= (workgroups the chip holds) workgroups walk
 // the logical tiles L = blockIdx.x, blockIdx.x + gridDim.x, ...  The loader waves run two k-steps ahead ACROSS tile borders:
@@ -619,8 +671,8 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
         rix[ps] = ix0;
       }
 #pragma unroll
-      for (int ps = 0; ps < C::WPASS; ++ps)
-        wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + lrow) * p.K) * 2);
+      for (int ps = 0; ps < C::WPASS; ++ps)          // LDS row ps*32 + lrow <- output channel ch0 + ps*32 + pi(lrow) (igemm_epilogue_perm)
+        wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + (BNB ? lrow : igemm_perm_row(lrow))) * p.K) * 2);
     };
     const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
@@ -700,6 +752,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
       slot = slot == 2 ? 0 : slot + 1;
     }
-    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, z, bidx, bidy, m0, ch0, ypre);
+    if constexpr (BNB) igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, z, bidx, bidy, m0, ch0, ypre);
+    else igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0);
   }
 }

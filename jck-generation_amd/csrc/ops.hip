@@ -25,7 +25,7 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 static int g_igemm_dma = env_int("JCK_IGEMM_DMA", 1);        // LDS-DMA gather-GEMM for bf16 tiles
 static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised 128x64 tiles when < 512 tiles of 128x128
 static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
-static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 3);   // persistent form of the wave-specialised gather-GEMMs (igemm.hpp)
+static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wave-specialised gather-GEMMs (igemm.hpp); bit 0: 128x256, 1: 128x64, 2: 64x128 tiles
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
 static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
@@ -207,8 +207,9 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     // JCK_IGEMM_256 = minimum number of such tiles (0 disables).
     const int min256 = g_igemm_256;
     const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
-    const int persist = g_igemm_persist;
-    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && p.logOHW >= 5 && p.M % 256 == 0)
+    // persistent kernels: plain bf16 conv / dgrad launches only (their epilogue has no bias, tanh, fp32 or split-K output)
+    const int persist = (p.bias || p.epi || p.out_f32 || p.rows_are_phases || p.out_split_stride) ? 0 : g_igemm_persist;
+    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && (p.logOHW >= 5 || !p.stats) && p.M % 256 == 0)
       return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
                            : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
