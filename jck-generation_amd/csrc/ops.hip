@@ -555,8 +555,11 @@ static int run_wgrad(int prec, WgradParams& p, const WgradPlan& pl, int nsub, fl
 static int launch_wgrad_reduce(const float* ws, int Z, int CsRows, int ncols, int Cs, int Cb, int logCbPad, float* grad,
                                int accumulate, hipStream_t st) {
   if (Cb % 64 == 0 && (1 << logCbPad) == Cb) {
-    hipLaunchKernelGGL(wgrad_reduce16_kernel, dim3(Cb / 64, Cs), dim3(256), 0, st, ws, Z, CsRows, ncols, Cb, logCbPad, grad,
-                       accumulate);
+    // few workgroups and many slabs (the tap-reuse plan): four slab groups per workgroup
+    if (Z >= 16 && (long long)(Cb / 64) * Cs <= 1024)
+      hipLaunchKernelGGL(wgrad_reduce16_kernel<4>, dim3(Cb / 64, Cs), dim3(1024), 0, st, ws, Z, CsRows, ncols, Cb, logCbPad, grad, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_reduce16_kernel<1>, dim3(Cb / 64, Cs), dim3(256), 0, st, ws, Z, CsRows, ncols, Cb, logCbPad, grad, accumulate);
   } else if (logCbPad == 2 && ncols == 64) {
     hipLaunchKernelGGL(wgrad_reduce_img_kernel, dim3(Cs), dim3(256), 0, st, ws, Z, CsRows, Cb, grad, accumulate);
   } else {

@@ -247,19 +247,36 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_img_kernel(const floa
 // 16-tap layers with Cb % 64 == 0: one workgroup per (cs, 64-channel chunk).  Reads are 256-byte runs along cb
 // (float4 per thread, summed over the Z slabs in registers), the [16][64] -> [64][16] transpose goes through LDS,
 // the 4 KB result is written as one contiguous run.
-static __global__ __launch_bounds__(256) void wgrad_reduce16_kernel(const float* __restrict__ part, int Z, int CsRows, int ncols,
-                                                                    int Cb, int logCbPad, float* __restrict__ grad,
-                                                                    int accumulate) {
+// ZG groups of 256 threads split the Z slabs between them (group q takes slabs q, q+ZG, ...: ZG times the loads in flight - with
+// 32-64 slabs and only Cs * Cb/64 workgroups the kernel was pure load latency, 42 us for D.conv2) and are summed in group order
+// through LDS: the summation order depends on (Z, ZG) only.
+template <int ZG>
+static __global__ __launch_bounds__(256 * ZG) void wgrad_reduce16_kernel(const float* __restrict__ part, int Z, int CsRows, int ncols,
+                                                                         int Cb, int logCbPad, float* __restrict__ grad,
+                                                                         int accumulate) {
   __shared__ float tile[64][17];
+  __shared__ f32x4 zsum[ZG > 1 ? ZG - 1 : 1][256];
   const int cs = blockIdx.y, cb0 = blockIdx.x * 64;
-  const int t = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  const int tid = threadIdx.x & 255, zq = threadIdx.x >> 8;
+  const int t = tid >> 4, c4 = (tid & 15) * 4;
   const float* src = part + (long long)cs * ncols + ((long long)t << logCbPad) + cb0 + c4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < Z; ++z) s += *reinterpret_cast<const f32x4*>(src + (long long)z * CsRows * ncols);
+  for (int z = zq; z < Z; z += ZG) s += *reinterpret_cast<const f32x4*>(src + (long long)z * CsRows * ncols);
+  if constexpr (ZG > 1) {
+    if (zq > 0) zsum[zq - 1][tid] = s;
+    __syncthreads();
+    if (zq == 0) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) tile[c4 + k][t] = s[k];
+      for (int q = 0; q < ZG - 1; ++q) s += zsum[q][tid];
+    }
+  }
+  if (zq == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[c4 + k][t] = s[k];
+  }
   __syncthreads();
-  const int cbl = threadIdx.x >> 2, t4 = (threadIdx.x & 3) * 4;
+  if (zq != 0) return;
+  const int cbl = tid >> 2, t4 = (tid & 3) * 4;
   float* dst = grad + ((long long)cs * Cb + cb0 + cbl) * 16 + t4;
   f32x4 o = {tile[cbl][t4], tile[cbl][t4 + 1], tile[cbl][t4 + 2], tile[cbl][t4 + 3]};
   if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);

@@ -9,14 +9,16 @@ shapes = sys.argv[4].split(",")
 Bs = [int(x) for x in sys.argv[5:]] or [256]
 CFG = {"down2": ("down", 32, 64, 128), "down3": ("down", 16, 128, 256), "down4": ("down", 8, 256, 512),
        "up2": ("up", 4, 512, 256), "up3": ("up", 8, 256, 128), "up4": ("up", 16, 128, 64),
-       "wg2": ("wg", 32, 64, 128), "wg3": ("wg", 16, 128, 256), "wg4": ("wg", 8, 256, 512), "wg1": ("wg", 64, 64, 128)}
+       "wg2": ("wg", 32, 64, 128), "wg3": ("wg", 16, 128, 256), "wg4": ("wg", 8, 256, 512), "wg1": ("wg", 64, 64, 128), "down1": ("down", 64, 3, 64)}
 prec = 0
 def make(which, B):
     cfg = CFG[which]; kind = cfg[0]
     torch.manual_seed(0)
     if kind == "down":
         _, hb, cb, cs = cfg
-        x = torch.randn(B, hb, hb, cb, device="cuda").to(torch.bfloat16)
+        x = torch.randn(B, hb, hb, 4 if cb == 3 else cb, device="cuda").to(torch.bfloat16)
+        if cb == 3:
+            x[..., 3] = 0
         w = G.pack_down(torch.randn(cs, cb, 4, 4) * 0.05, prec)
         out = torch.empty(B, hb // 2, hb // 2, cs, dtype=torch.bfloat16, device="cuda")
         stats, slots = G.stats_buf(B * (hb // 2) ** 2, cs)
