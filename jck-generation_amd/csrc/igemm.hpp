@@ -672,7 +672,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
 #pragma unroll
       for (int ps = 0; ps < C::WPASS; ++ps)          // LDS row ps*32 + lrow <- output channel ch0 + ps*32 + pi(lrow) (igemm_epilogue_perm)
-        wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + (BNB ? lrow : igemm_perm_row(lrow))) * p.K) * 2);
+        wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + igemm_perm_row(lrow)) * p.K) * 2);
     };
     const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
@@ -723,6 +723,54 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
   const int sw = ((lane & 15) >> 1) & 7;
   int slot = 0;
+  // BNB: BatchNorm-backward statistics of the tensor this launch's output is the gradient of (sum g_z, sum g_z*xhat per
+  // channel and BatchNorm group), accumulated per LANE over all tiles of the workgroup and reduced over the 16 pixel lanes only
+  // when the group changes (a workgroup's tiles come in increasing pixel order and keep their channel tile): the launch writes
+  // rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with its channel tile - a few
+  // hundred rows instead of one per (tile, wave), and no separate pass over g and y (bn_bwd_reduce_kernel) afterwards.
+  constexpr int NPAIR = FM / 2;
+  float S1[BNB ? NPAIR : 1][8], S2[BNB ? NPAIR : 1][8];
+  int cur_group = -1, next_row_group = 0;
+  const int ngroups = BNB ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
+  int rank = 0, rows_per_group = 0;
+  if constexpr (BNB) {
+    locate(blockIdx.x);
+    // first-tile wgid = base(xcd) + idx with base % gy == 0 (launcher): channel tile = idx % gy, rank = xcd * (G/8/gy) + idx / gy
+    const int idx = blockIdx.x >> 3, xcd = blockIdx.x & 7, per_xcd = (int)(gridDim.x >> 3) / p.gy;
+    rank = xcd * per_xcd + idx / p.gy;
+    rows_per_group = (int)(gridDim.x / p.gy) * C::WPIX;
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { S1[k][c] = 0.f; S2[k][c] = 0.f; }
+  }
+  auto bnb_write = [&](int grp, bool zero) __attribute__((always_inline)) {
+    float* row = p.stats + ((long long)grp * rows_per_group + rank * C::WPIX + wpix) * 2 * p.cstat;
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * (lane >> 4);
+      float a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] = zero ? 0.f : row16_sum(S1[k][c]); b[c] = zero ? 0.f : row16_sum(S2[k][c]); }
+      if ((lane & 15) == 0 && ch < p.NchStore) {
+        const int cc = ch & (p.cstat - 1);
+        *reinterpret_cast<f32x4*>(row + cc) = f32x4{a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f32x4*>(row + cc + 4) = f32x4{a[4], a[5], a[6], a[7]};
+        *reinterpret_cast<f32x4*>(row + p.cstat + cc) = f32x4{b[0], b[1], b[2], b[3]};
+        *reinterpret_cast<f32x4*>(row + p.cstat + cc + 4) = f32x4{b[4], b[5], b[6], b[7]};
+      }
+    }
+  };
+  auto bnb_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
+    if (cur_group >= 0) { bnb_write(cur_group, false); next_row_group = cur_group + 1; }
+    for (int gq = next_row_group; gq < grp; ++gq) bnb_write(gq, true);       // groups this workgroup has no tile in
+    if (grp > next_row_group) next_row_group = grp;
+    cur_group = grp;
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { S1[k][c] = 0.f; S2[k][c] = 0.f; }
+  };
   for (int L = blockIdx.x; L < ntiles; L += gridDim.x) {
     locate(L);
     f32x4 acc[FM][FN];
@@ -730,8 +778,6 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
-    if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
     for (int k = 0; k < nk; ++k) {
       __builtin_amdgcn_s_barrier();
       const bf16_t* wt0 = reinterpret_cast<const bf16_t*>(lds + slot * STG_BYTES);
@@ -752,7 +798,80 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
       slot = slot == 2 ? 0 : slot + 1;
     }
-    if constexpr (BNB) igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, z, bidx, bidy, m0, ch0, ypre);
-    else igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0);
+    if constexpr (!BNB) {
+      igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0);
+    } else {
+      long long poff[FN];
+      igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
+      const int g = lane >> 4;
+      const bf16_t* by = reinterpret_cast<const bf16_t*>(p.bn_y);
+      bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
+      const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
+      if (grp != cur_group) bnb_switch(grp);
+      const float* aux = p.bn_aux + (long long)grp * 4 * p.cstat;
+      // per chunk of JC pixel columns: the saved conv output y of this lane's 8 channels first (loads), the gradient stores next,
+      // the arithmetic last (JC = 4 keeps the 128 x 256 tile under its register budget)
+      constexpr int JC = FN < 4 ? FN : 4;
+#pragma unroll
+      for (int j0 = 0; j0 < FN; j0 += JC) {
+        u32x4 yr[NPAIR][JC];
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) {
+          const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+#pragma unroll
+          for (int jj = 0; jj < JC; ++jj) {
+            yr[k][jj] = u32x4{0u, 0u, 0u, 0u};
+            if (poff[j0 + jj] >= 0 && ch < p.NchStore) yr[k][jj] = *reinterpret_cast<const u32x4*>(by + poff[j0 + jj] + p.obase[z] + ch);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+          const int j = j0 + jj;
+          if (poff[j] < 0) continue;
+#pragma unroll
+          for (int k = 0; k < NPAIR; ++k) {
+            const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+            if (ch >= p.NchStore) continue;
+            const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
+                                acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
+            st8(outp + poff[j] + p.obase[z] + ch, v);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) {
+          const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+          if (ch >= p.NchStore) continue;
+          const int cc = ch & (p.cstat - 1);
+          float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(aux + cc + 4 * h), a1 = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc + 4 * h);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h), a3 = *reinterpret_cast<const f32x4*>(aux + 3 * p.cstat + cc + 4 * h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[4 * h + r] = a0[r]; sh[4 * h + r] = a1[r]; mu[4 * h + r] = a2[r]; is[4 * h + r] = a3[r]; }
+          }
+#pragma unroll
+          for (int jj = 0; jj < JC; ++jj) {
+            const int j = j0 + jj;
+            if (poff[j] < 0) continue;
+            float yv[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              yv[2 * r] = __uint_as_float(yr[k][jj][r] << 16);
+              yv[2 * r + 1] = __uint_as_float(yr[k][jj][r] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float v = acc[2 * k + (c >> 2)][j][c & 3];
+              const float zz = yv[c] * sc[c] + sh[c];
+              const float gz = zz > 0.f ? v : p.bn_slope * v;
+              S1[k][c] += gz;
+              S2[k][c] += gz * ((yv[c] - mu[c]) * is[c]);
+            }
+          }
+        }
+      }
+    }
   }
+  if constexpr (BNB) bnb_switch(ngroups);
 }

@@ -179,13 +179,18 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
   IgemmParams q = p;
   q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
-  if (q.stats) {
+  const int ntiles = (int)(grid.x * grid.y * grid.z);
+  const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
+  const int nwg = std::min(ntiles, cap);
+  if (q.stats && !q.bn_y) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
   }
-  const int ntiles = (int)(grid.x * grid.y * grid.z);
-  const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
-  hipLaunchKernelGGL(kern, dim3(std::min(ntiles, cap)), dim3((NCW + 4) * 64), LDSB, st, q);
+  if (q.bn_y) {     // accumulated BatchNorm-backward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
+    const int groups = q.bn_group_rows > 0 ? (q.M + q.bn_group_rows - 1) / q.bn_group_rows : 1;
+    if (slots) *slots = groups * (nwg / (int)grid.y) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3((NCW + 4) * 64), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -208,8 +213,20 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     const int min256 = g_igemm_256;
     const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
     // persistent kernels: plain bf16 conv / dgrad launches only (their epilogue has no bias, tanh, fp32 or split-K output)
-    const int persist = (p.bias || p.epi || p.out_f32 || p.rows_are_phases || p.out_split_stride) ? 0 : g_igemm_persist;
-    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && (p.logOHW >= 5 || !p.stats) && p.M % 256 == 0)
+    int persist = (p.bias || p.epi || p.out_f32 || p.rows_are_phases || p.out_split_stride) ? 0 : g_igemm_persist;
+    if (p.bn_y) {
+      // BatchNorm-backward statistics ride on the persistent form only when every workgroup takes several tiles of ONE channel
+      // tile (accumulation per workgroup: ntiles >= the resident workgroups, tile counts divisible as the row ranks assume)
+      const long long t256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases, t64 = (long long)cdiv(p.M, 64) * (nch_pad / 128) * phases;
+      const int gy = nch_pad / 128;
+      auto ok = [&](long long nt, int capw) { return nt >= capw && nt % 8 == 0 && (nt / 8) % gy == 0 && (capw / 8) % gy == 0 && p.cstat == nch_pad; };
+      if (!ok(t256, 256)) persist &= ~1;
+      if (!ok(t64, 512)) persist &= ~2;
+    }
+    // forward statistics: a tile must not straddle two BatchNorm groups (groups are multiples of 8 images: 8 * OH*OW % 256 == 0);
+    // backward statistics carry their group size
+    const bool groups_ok = !p.stats || (p.bn_y ? (p.bn_group_rows == 0 || p.bn_group_rows % 256 == 0) : p.logOHW >= 5);
+    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0)
       return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
                            : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
@@ -226,7 +243,10 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   }
   if (nch_pad == 64) {
     if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
-      if ((g_igemm_persist & 4) && !p.act_row_elems) return launch_igemm_dma_persist<64, 128, 4>(p, nch_pad, phases, st, slots);
+      const long long t128 = (long long)cdiv(p.M, 128) * phases;
+      const bool bnb_ok = !p.bn_y || (t128 >= 512 && t128 % 8 == 0 && p.cstat == nch_pad);
+      if ((g_igemm_persist & 4) && !p.act_row_elems && !p.bias && !p.epi && !p.out_f32 && !p.rows_are_phases && !p.out_split_stride && bnb_ok)
+        return launch_igemm_dma_persist<64, 128, 4>(p, nch_pad, phases, st, slots);
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
     }
     if (nsub == 2) return launch_igemm_t<P, 64, 128, 2>(p, nch_pad, phases, st, slots);
@@ -263,8 +283,10 @@ int launch_igemm(int prec, const IgemmParams& p0, int nch_pad, int phases, int n
   JCK_FAIL(JCK_E_ARG, "bad prec");
 }
 
+// rows of partial statistics a launch may write: one per (tile, wave) = at most one per 32 pixels, or - the persistent kernels'
+// accumulated BatchNorm-backward rows - [<= 4 groups][<= 512 workgroups / channel tiles][<= 4 pixel waves] <= 4096
 extern "C" size_t jck_stats_floats(long long pixels, int C, int nyrep) {
-  return (size_t)(pixels / 32 + 16) * (size_t)std::max(1, nyrep) * 2 * (size_t)C;
+  return (size_t)std::max<long long>(pixels / 32 + 16, 4096) * (size_t)std::max(1, nyrep) * 2 * (size_t)C;
 }
 extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)elems * (prec == JCK_PREC_F32 ? 4 : 2); }
 

@@ -194,7 +194,11 @@ def test_bn_act(G, prec, cfg):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("cfg", [("up", 4, 8, 256, 128, 2), ("up", 2, 16, 128, 64, 0), ("down", 4, 16, 128, 256, 0),
-                                 ("down", 4, 64, 3, 64, 2), ("down", 3, 32, 3, 64, 0)])
+                                 ("down", 4, 64, 3, 64, 2), ("down", 3, 32, 3, 64, 0),
+                                 # large enough for the persistent kernels, whose statistics are accumulated per workgroup and
+                                 # BatchNorm group (igemm.hpp): 128x256 tiles (384), 128x64 tiles (768), 64x128 tiles (1536)
+                                 ("up", 96, 16, 256, 128, 32), ("down", 96, 32, 64, 256, 32), ("up", 48, 16, 128, 64, 16),
+                                 ("up", 64, 16, 256, 128, 0)])
 def test_dgrad_with_bn_backward_stats(G, prec, cfg):
     """conv dgrad whose epilogue also leaves sum(g_z), sum(g_z*xhat) of the BatchNorm+activation in front of it, followed by
     jck_bn_bwd_finish, against autograd through batch_norm -> (leaky_)relu -> conv; grouped = independent BN batches."""
