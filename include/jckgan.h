@@ -110,6 +110,13 @@ int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float
  * without the separate reduction pass over g_a. */
 int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
                       int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
+/* jck_conv_down / jck_conv_up with the forward statistics laid out per BatchNorm group of `group_images` images
+ * (N % group_images == 0): *stats_slots rows, the first *stats_slots / (N / group_images) of them belong to group 0, and so
+ * on - what jck_bn_finalize_grouped reads.  Large launches write one row per (workgroup, group) instead of one per (tile, wave). */
+int jck_conv_down_grouped(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb,
+                          int Wb, int Cb, int Cs, int group_images, void* stream);
+int jck_conv_up_grouped(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
+                        int Ws, int Cs, int Cb, int group_images, void* stream);
 int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb,
                         int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
 int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,

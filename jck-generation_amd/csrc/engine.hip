@@ -468,7 +468,7 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
   const void* in = x_in;
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, st));
+    JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
@@ -609,7 +609,7 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
     // statistic slots of group g0 start at the g0/3 point of the buffer (sized for 3B pixels at one slot per 32 pixels)
     float* stats = S.stats[i] + (size_t)g0 * (jck_stats_floats((long long)3 * B * (hb / 2) * (hb / 2), cs, 1) / 3 / (2 * cs)) * (2 * cs);
     int slots = 0;
-    JCK_TRY(jck_conv_down(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, st));
+    JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, B, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
@@ -808,7 +808,7 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
     JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
     if (i < TT.NS - 1)
-      JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, 0, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
+      JCK_TRY(jck_conv_up_grouped(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
     else                                             // last ConvTranspose + tanh -> the image
       JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
   }

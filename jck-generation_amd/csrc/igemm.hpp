@@ -59,6 +59,9 @@ struct IgemmParams {
   const float* bn_aux;
   float bn_slope;
   int bn_group_rows;
+  // forward statistics accumulated per workgroup and BatchNorm group by the persistent kernels (rows [group][rank][2][cstat],
+  // group = pixel row / bn_group_rows) instead of one row per (tile, wave); set by the launcher for the *_grouped entry points
+  int stat_accum;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -568,12 +571,12 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
 __device__ __forceinline__ int igemm_perm_row(int r) { return 8 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3); }
 template <int BCH, int BPIX, int FM, int FN, int WPIXN>
 __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z,
-                                                    int bidx, int bidy, int m0, int ch0) {
+                                                    int bidx, int bidy, int m0, int ch0, bool tile_stats = true) {
   static_assert(FM % 2 == 0, "fragment pairs");
   long long poff[FN];
   igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
   const int g = lane >> 4;
-  if (p.stats) {
+  if (p.stats && tile_stats) {
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
     const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
@@ -728,12 +731,14 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   // when the group changes (a workgroup's tiles come in increasing pixel order and keep their channel tile): the launch writes
   // rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with its channel tile - a few
   // hundred rows instead of one per (tile, wave), and no separate pass over g and y (bn_bwd_reduce_kernel) afterwards.
+  // Forward statistics (sum y, sum y^2) take the same route when the launcher asks for it (p.stat_accum).
   constexpr int NPAIR = FM / 2;
-  float S1[BNB ? NPAIR : 1][8], S2[BNB ? NPAIR : 1][8];
+  float S1[NPAIR][8], S2[NPAIR][8];
   int cur_group = -1, next_row_group = 0;
-  const int ngroups = BNB ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
+  const bool acc_stats = BNB || (p.stats && p.stat_accum);
+  const int ngroups = acc_stats ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
   int rank = 0, rows_per_group = 0;
-  if constexpr (BNB) {
+  if (acc_stats) {
     locate(blockIdx.x);
     // first-tile wgid = base(xcd) + idx with base % gy == 0 (launcher): channel tile = idx % gy, rank = xcd * (G/8/gy) + idx / gy
     const int idx = blockIdx.x >> 3, xcd = blockIdx.x & 7, per_xcd = (int)(gridDim.x >> 3) / p.gy;
@@ -799,7 +804,21 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       slot = slot == 2 ? 0 : slot + 1;
     }
     if constexpr (!BNB) {
-      igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0);
+      igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats);
+      if (acc_stats) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
+        const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
+        if (grp != cur_group) bnb_switch(grp);
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float v = acc[2 * k + (c >> 2)][j][c & 3];
+              S1[k][c] += v;
+              S2[k][c] += v * v;
+            }
+      }
     } else {
       long long poff[FN];
       igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
@@ -873,5 +892,5 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
     }
   }
-  if constexpr (BNB) bnb_switch(ngroups);
+  if (acc_stats) bnb_switch(ngroups);
 }

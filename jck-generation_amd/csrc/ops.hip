@@ -26,6 +26,7 @@ static int g_igemm_dma = env_int("JCK_IGEMM_DMA", 1);        // LDS-DMA gather-G
 static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised 128x64 tiles when < 512 tiles of 128x128
 static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
 static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wave-specialised gather-GEMMs (igemm.hpp); bit 0: 128x256, 1: 128x64, 2: 64x128 tiles
+static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
 static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
@@ -35,7 +36,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"stat_accum", &g_stat_accum},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -182,11 +183,18 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   const int ntiles = (int)(grid.x * grid.y * grid.z);
   const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
   const int nwg = std::min(ntiles, cap);
-  if (q.stats && !q.bn_y) {
+  if (q.stats && !q.bn_y && q.stat_accum) {
+    // accumulated rows need several tiles of ONE channel tile per workgroup and tiles inside one group (igemm.hpp)
+    const int gyy = (int)grid.y;
+    if (!(g_stat_accum && ntiles >= cap && ntiles % 8 == 0 && (ntiles / 8) % gyy == 0 && (cap / 8) % gyy == 0 && q.cstat == nch_pad &&
+          (q.bn_group_rows == 0 || q.bn_group_rows % BPIX == 0)))
+      q.stat_accum = 0;
+  }
+  if (q.stats && !q.bn_y && !q.stat_accum) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
   }
-  if (q.bn_y) {     // accumulated BatchNorm-backward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
+  if (q.bn_y || (q.stats && q.stat_accum)) {     // accumulated BatchNorm-backward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
     const int groups = q.bn_group_rows > 0 ? (q.M + q.bn_group_rows - 1) / q.bn_group_rows : 1;
     if (slots) *slots = groups * (nwg / (int)grid.y) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX;
   }
@@ -327,7 +335,7 @@ static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, 
 
 static int conv_down_impl(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                           int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float bn_slope,
-                          int bn_group_images, void* stream) {
+                          int bn_group_images, void* stream, int fwd_group_images = 0) {
   const int cbp = jck_pad_chan(Cb);
   if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
@@ -344,6 +352,7 @@ static int conv_down_impl(int prec, const void* big, const void* w, void* small_
   if (stats && !is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
   p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * OH * OW : 0;
+  if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * OH * OW; p.stat_accum = 1; }
   if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH) &&
       (bn_group_images == 0 || (bn_group_images * OH * OW) % (16 * 4 * IMG_GPW) == 0))
     return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream, bn_y, bn_aux, bn_slope,
@@ -354,6 +363,14 @@ extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* sma
                              int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
   return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream);
 }
+// Forward statistics per BatchNorm group of `group_images` images (N % group_images == 0): *stats_slots rows, the first
+// *stats_slots / (N / group_images) of them belong to group 0, and so on - the layout jck_bn_finalize_grouped reads.  Large
+// launches on the persistent kernels write one row per (workgroup, group) instead of one per (tile, wave).
+extern "C" int jck_conv_down_grouped(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
+                                     int N, int Hb, int Wb, int Cb, int Cs, int group_images, void* stream) {
+  if (group_images < 1 || N % group_images) JCK_FAIL(JCK_E_ARG, "conv_down_grouped: N must be a multiple of group_images >= 1");
+  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, group_images);
+}
 extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                                    int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope,
                                    int group_images, void* stream) {
@@ -363,7 +380,7 @@ extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, voi
 
 static int conv_up_impl(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                         int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float bn_slope,
-                        int bn_group_images, void* stream) {
+                        int bn_group_images, void* stream, int fwd_group_images = 0) {
   const int cbp = jck_pad_chan(Cb);
   if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
@@ -404,11 +421,17 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   if (p.K % 64 != 0) JCK_FAIL(JCK_E_ARG, "conv_up: 4*Cs must be a multiple of 64");
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
   p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * Hs * Ws : 0;
+  if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * Hs * Ws; p.stat_accum = 1; }
   return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                            int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
   return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, epi_tanh, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream);
+}
+extern "C" int jck_conv_up_grouped(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
+                                   int N, int Hs, int Ws, int Cs, int Cb, int group_images, void* stream) {
+  if (group_images < 1 || N % group_images) JCK_FAIL(JCK_E_ARG, "conv_up_grouped: N must be a multiple of group_images >= 1");
+  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, group_images);
 }
 extern "C" int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                                  int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope,

@@ -435,3 +435,39 @@ def test_step_rng_small_inputs(G):
     G.lib.jck_step_rng(torch.zeros(8, device="cuda"), 5, 99, pad, nz - 3, None, 0, None, 0, 0.75, G.cur_stream())
     torch.cuda.synchronize()
     assert float(pad[nz - 3:].min()) == 7.0 and torch.equal(pad[:nz - 3].double().cpu(), z[:nz - 3])
+
+
+@pytest.mark.parametrize("cfg", [("down", 96, 32, 64, 128, 32), ("down", 192, 32, 64, 256, 64), ("up", 96, 16, 256, 128, 32),
+                                 ("up", 48, 16, 128, 64, 16), ("down", 8, 16, 128, 256, 4), ("up", 64, 16, 256, 128, 64)])
+def test_grouped_forward_statistics(G, cfg):
+    """jck_conv_down_grouped / jck_conv_up_grouped: per-group sum y and sum y^2 of the conv output for jck_bn_finalize_grouped -
+    on the persistent kernels one row per (workgroup, group), accumulated over the workgroup's tiles (large cases), elsewhere one
+    row per (tile, wave) (the small case); either way row r of group k is stats[k * slots/groups + r]."""
+    kind, n, hin, cin, cout, gimg = cfg
+    prec = G.PREC_BF16
+    g = torch.Generator().manual_seed(21)
+    x = G.rnd(torch.randn(n, cin, hin, hin, generator=g), prec)
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    wr = G.rnd(w, prec)
+    ref = F.conv_transpose2d(x, wr, None, 2, 1) if kind == "up" else F.conv2d(x, wr, None, 2, 1)
+    hout = ref.shape[-1]
+    out = torch.empty(n, hout, hout, cout, dtype=torch.bfloat16, device="cuda")
+    stats, slots = G.stats_buf(n * hout * hout, cout)
+    stats.fill_(float("nan"))
+    if kind == "up":
+        G.lib.jck_conv_up_grouped(prec, G.to_nhwc(x, prec), G.pack_up(w, prec), out, stats, ctypes.byref(slots), n, hin, hin, cin, cout,
+                                  gimg, G.cur_stream())
+    else:
+        G.lib.jck_conv_down_grouped(prec, G.to_nhwc(x, prec), G.pack_down(w, prec), out, stats, ctypes.byref(slots), n, hin, hin, cin,
+                                    cout, gimg, G.cur_stream())
+    torch.cuda.synchronize()
+    groups = n // gimg
+    assert slots.value % groups == 0
+    G.check(G.from_nhwc(out), ref, G.TOL[prec], "conv")
+    per = slots.value // groups
+    rows = stats[:slots.value * 2 * cout].view(groups, per, 2, cout).double().cpu()
+    assert torch.isfinite(rows).all()                                 # every row of every group was written
+    for k in range(groups):
+        r = ref[k * gimg:(k + 1) * gimg].double()
+        G.check(rows[k, :, 0].sum(0), r.sum((0, 2, 3)), 2e-3, f"sum, group {k}")
+        G.check(rows[k, :, 1].sum(0), (r * r).sum((0, 2, 3)), 2e-3, f"sum of squares, group {k}")
