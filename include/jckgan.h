@@ -279,6 +279,12 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
  * [fake | penalty] as one 2B forward behind it; everything else (heads, losses, the 3B backward) is unchanged, so results
  * are bitwise those of the plain order.  Returns JCK_E_ARG when the engine's schedule has no such split (CGAN, per-pass). */
 #define JCK_PHASE_D_REAL_FWD 7
+/* PHASE_D_LOSS = PHASE_D_LOSS_A + PHASE_D_LOSS_B (DCGAN, batched schedule; data parallel).  After _A the tail of D's gradient
+ * arena [jck_engine_grad_tail() .. end) - conv4.weight, norm4.*, conv5.weight, 76 % of its bytes - is final in stream order:
+ * the caller starts its all-reduce, issues _B (the remaining ~0.5 ms of the backward pass), then all-reduces the head of the
+ * arena.  Same kernels in the same order on every tensor: bitwise the results of PHASE_D_LOSS. */
+#define JCK_PHASE_D_LOSS_A 8
+#define JCK_PHASE_D_LOSS_B 9
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */
@@ -305,6 +311,8 @@ int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* st
  * that slice on `stream`; returns 0 when the step has no early bucket.  (The all-reduce the reference would need before
  * optimizer_d.step(), train/dcgan_trainer.py:180, under DistributedDataParallel.) */
 int jck_engine_grad_bucket(jck_engine*, int net, void* stream, long long* offset, long long* numel);
+/* first element of the gradient-arena tail that PHASE_D_LOSS_A finalises (net 1 = D); -1 when the schedule has no such split */
+long long jck_engine_grad_tail(const jck_engine*, int net);
 const float* jck_engine_scalars(const jck_engine*);
 const float* jck_engine_scalars_at(const jck_engine*, int step);   /* buffer of the given (1-based) step's parity */
 /* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */

@@ -623,8 +623,11 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
 // Backward of the conv stack for G groups whose gradients w.r.t. a4 are in bset.g[3]: BatchNorm backward grouped, ONE dgrad
 // launch per layer over all groups, ONE weight-gradient launch per layer over the first gw groups (on `side` when given),
 // and - xgrad_last - the gradient w.r.t. the input image of the LAST group -> dset[0].gx.  Joins `side` before returning.
+// part 0: the whole pass.  part 1 / 2 (data parallel, PHASE_D_LOSS_A / _B): up to and including the weight gradient of the LAST
+// layer (joined into `st`: the tail of D's gradient arena - conv4.weight, norm4.*, conv5.weight - is then final in `st` order and
+// its all-reduce can start) / everything after it.
 static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int gw, bool xgrad_last, hipStream_t st, hipStream_t side,
-                              bool with_gp_norm = false) {
+                              bool with_gp_norm = false, int part = 0) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
@@ -632,7 +635,9 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
   for (int i = TT.NS - 1; i >= 0; --i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    if (i < TT.NS - 1 && e->fuse_bnbwd)
+    const bool resume = part == 2 && i == TT.NS - 1;      // part 2 starts at this layer's dgrad
+    if (resume) {
+    } else if (i < TT.NS - 1 && e->fuse_bnbwd)
       JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
                                 e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
     else
@@ -640,9 +645,15 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
                                      e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
+    if (!resume) {
     if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
-    if (i == TT.NS - 1 && e->family == 0 && G == 3) {
+    }
+    if (part == 1) {
+      if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+      return JCK_OK;
+    }
+    if (!resume && i == TT.NS - 1 && e->family == 0 && G == 3) {
       // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
       // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
       // (jck_engine_grad_bucket)
@@ -670,10 +681,11 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
 // (targets / accumulator slots given per group) and contribute weight gradients; the LAST group is the penalty pass (head
 // mode 1, gradient w.r.t. its input image -> dset[0].gx, norms -> dset[0].norms).  Weight gradients run on `side`.
 static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pass0, const float* targets, const int* slot_loss,
-                          const int* slot_p, hipStream_t st, hipStream_t side, bool forward_done = false) {
+                          const int* slot_p, hipStream_t st, hipStream_t side, bool forward_done = false, int part = 0) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   const int gw = G - 1;
+  if (part == 2) return d_batched_backward(e, x_in, B, G, gw, true, st, side, true, 2);
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   if (!forward_done) JCK_TRY(d_batched_forward(e, x_in, B, 0, G, pass0, st));
   {
@@ -688,7 +700,7 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]), e->head_ws, st));
   JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[TT.NS - 1], (size_t)gw * B * TT.FEAT), B, TT.G_C1,
                             at(S.g[TT.NS - 1], (size_t)gw * B * TT.FEAT), nullptr, nullptr, st));
-  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true));
+  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part));
   return JCK_OK;
 }
 
@@ -885,7 +897,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   DSet& D1 = e->dset[1];
   DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
   e->parity = in->step & 1;
-  if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL) e->bucket_ready = false;
+  if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL || phase == JCK_PHASE_D_LOSS_A) e->bucket_ready = false;
   // eager callers that did not call jck_engine_set_step: the step's scalars / Philox words are written by its first phase
   if (e->hp_step[e->parity] != in->step && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
@@ -914,6 +926,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     return JCK_OK;
   };
   switch (phase) {
+    case JCK_PHASE_D_LOSS_A:
+    case JCK_PHASE_D_LOSS_B:
+      if (cg || e->batched != 3 || e->capturing) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS_A / _B: only with the batched DCGAN schedule, outside a capture");
+      [[fallthrough]];
     case JCK_PHASE_D_LOSS:
       if (cg && e->batched) {
         // CGAN: the real, fake and penalty passes (:181-203) share D's weights -> their conv stacks run as ONE 3B pass with
@@ -981,6 +997,14 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         return JCK_OK;
       }
       if (!cg && e->batched == 3) {                   // [real | fake | penalty] as one 3B pass after G's forward
+        const float tgB[2] = {0.9f, 0.1f};
+        const int slB[2] = {0, 1}, spB[2] = {3, 4};
+        if (phase == JCK_PHASE_D_LOSS_B) {            // second half of a split pass (after the early all-reduce has started)
+          JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tgB, slB, spB, st, sA, true, 2));
+          e->gp_done = true;
+          return JCK_OK;
+        }
+        const int part = phase == JCK_PHASE_D_LOSS_A ? 1 : 0;
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         // D(real)'s forward of this step may already have run under the previous step's G all-reduce (PHASE_D_REAL_FWD)
         const bool pre = e->real_fwd_step == (long long)in->step;
@@ -994,10 +1018,11 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
         if (pre) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                          // :173, 118 as one 2B forward
-        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, pre));              // :162-176, 178
-        e->gp_done = true;
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, pre, part));        // :162-176, 178
+        if (part == 0) e->gp_done = true;
         return JCK_OK;
       }
+      if (phase != JCK_PHASE_D_LOSS) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS_A / _B: only with the batched DCGAN schedule");
       [[fallthrough]];
     case JCK_PHASE_D_REAL:
     case JCK_PHASE_D_FAKE: {
@@ -1215,6 +1240,11 @@ extern "C" int jck_engine_grad_bucket(jck_engine* e, int net, void* stream, long
     e->bucket_ready = false;
   }
   return 1;
+}
+
+extern "C" long long jck_engine_grad_tail(const jck_engine* e, int net) {
+  if (!e || !e->bound || net != 1 || e->family != 0 || e->batched != 3) return -1;
+  return (long long)find(e->LD, CWN[e->T.NS - 1])->offset;
 }
 
 extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }

@@ -101,6 +101,7 @@ PROTOS = {
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
     "jck_engine_grad_bucket": (i32, [vp, i32, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "jck_engine_grad_tail": (i64, [vp, i32]),
     "jck_engine_scalars": (vp, [vp]),
     "jck_engine_scalars_at": (vp, [vp, i32]),
     "jck_engine_sample": (i32, [vp, vp, vp, i32, vp, vp]),

@@ -12,7 +12,8 @@ import torch
 
 from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, load_library
 
-PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD = range(8)
+(PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD, PHASE_D_LOSS_A,
+ PHASE_D_LOSS_B) = range(10)
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
@@ -543,6 +544,7 @@ class DcganEngine:
         main = torch.cuda.current_stream()
         st = main.cuda_stream
         h = self._h
+        split_done = False
         if pipeline:
             gs = self._g_stream()
             lib.jck_engine_phase(h, PHASE_D_REAL, C.byref(si), st)     # beside the previous step's G phase
@@ -550,8 +552,26 @@ class DcganEngine:
             lib.jck_engine_phase(h, PHASE_D_FAKE, C.byref(si), st)
         else:
             self.join()
-            lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
-        if self.family == 0:
+            tail = int(lib.jck_engine_grad_tail(h, 1)) if (reduce_d and self.family == 0 and os.environ.get("JCK_DDP_SPLIT", "1") == "1") else -1
+            if tail > 0:
+                # data parallel, batched schedule: the tail of D's gradient arena (conv4.weight .. conv5.weight, 76 % of its
+                # bytes) is final after the first weight-gradient product of the backward pass - its all-reduce is started
+                # there, in plain stream order, and runs under the remaining ~0.5 ms of the pass; the head follows at the end
+                flat = self.arenas["d_grads"]
+                lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
+                w_tail = reduce_d(flat[tail:])
+                lib.jck_engine_phase(h, PHASE_D_LOSS_B, C.byref(si), st)
+                w_head = reduce_d(flat[:tail])
+                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
+                for w in (w_tail, w_head):
+                    if w is not None:
+                        w()
+                split_done = True
+            else:
+                lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
+        if split_done:
+            handle = None
+        elif self.family == 0:
             handle = self._reduce_d(reduce_d) if reduce_d else None
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
         else:                                                      # CGAN back-propagates the penalty: reduce after it

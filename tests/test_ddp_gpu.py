@@ -207,7 +207,8 @@ def test_rccl_world1_reduce_paths_leave_every_bit_unchanged(tmp_path):
 @pytest.mark.parametrize("prec,explicit", [("bf16", False), ("f32", True)])
 def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
     """step_async(next_real=...) moves the forward half of the next step's D(real) pass in front of this step's G optimiser
-    phase (PHASE_D_REAL_FWD - the work that hides G's gradient all-reduce when data parallel).  Same kernels on the same data
+    phase (PHASE_D_REAL_FWD - the work that hides G's gradient all-reduce when data parallel), and with a reducer the D pass is
+    issued as PHASE_D_LOSS_A / _B with the all-reduce of the gradient arena's tail started in between.  Same kernels on the same data
     in the same per-tensor order: every weight, Adam moment, BatchNorm statistic and logged scalar must be bit-identical to
     the plain order, with in-kernel instance noise and with explicit noise tensors."""
     sys.path.insert(0, os.path.join(ROOT, "jck-generation_amd"))
@@ -217,7 +218,8 @@ def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
     B, steps = 16, 4
     imgs = synth_images(B * steps).cuda()
     res = []
-    for announce in (False, True):
+    for announce, split in ((False, "0"), (True, "1")):      # plain order and one all-reduce per net  vs  everything that overlaps
+        os.environ["JCK_DDP_SPLIT"] = split                  # PHASE_D_LOSS_A / _B: D's arena tail is reduced under the rest of the backward
         torch.manual_seed(12345)
         g, d = build_params("dcgan")
         eng = DcganEngine(batch=B, prec=prec, device="cuda:0")
@@ -234,12 +236,13 @@ def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
             kw = dict(next_real=imgs[(s + 1) * B:(s + 2) * B], next_noise=nn) if (announce and s + 1 < steps) else {}
             eng.step_async(imgs[s * B:(s + 1) * B], nz, 2e-4, reduce_d=red, reduce_g=red, generator=gen, **kw)
             scal.append(eng.scalars())
-        assert len(waits) == 2 * steps
+        assert len(waits) == (3 if split == "1" else 2) * steps
         if announce:
             assert getattr(eng, "_prefetch_ok", True)
         gs, ds = eng.state_dicts()
         res.append((scal, {k: v.clone() for k, v in gs.items()}, {k: v.clone() for k, v in ds.items()},
                     {t: {k: v.clone() for k, v in eng.named_views(t, w).items()} for t in "gd" for w in ("m",)}))
+    os.environ.pop("JCK_DDP_SPLIT", None)
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2]), (res[0][3]["g"], res[1][3]["g"]), (res[0][3]["d"], res[1][3]["d"])):
         for k in a:
