@@ -619,8 +619,10 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
 // the logical tiles L = blockIdx.x, blockIdx.x + gridDim.x, ...  The loader waves run two k-steps ahead ACROSS tile borders:
 // while the consumer waves store a tile (epilogue: 2-5 us of NHWC stores and BatchNorm partials), the first two stages of the
 // workgroup's next tile are already in flight, and no workgroup launch / LDS allocation sits between two tiles of a CU.
-// Same tiles, same k order, same epilogue as igemm_dma_kernel<.., WS = true> - bitwise the same results.  Both roles
-// execute exactly (tiles of this workgroup) x (K / 64) barriers.
+// Same tiles and k order as igemm_dma_kernel<.., WS = true>, the output channels of a 32-row block permuted between LDS row and
+// MFMA row so that the epilogue stores 16 bytes per lane (igemm_epilogue_perm) - the same products in the same order: bitwise
+// the same results.  Statistics (forward: p.stat_accum; BatchNorm backward: BNB) are accumulated per workgroup and group.
+// Both roles execute exactly (tiles of this workgroup) x (K / 64) barriers.
 // ------------------------------------------------------------------------------------------------------------------
 template <int BCH, int BPIX, bool BNB, int NCW>
 __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const IgemmParams p) {
