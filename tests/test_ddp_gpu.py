@@ -247,3 +247,27 @@ def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
     for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2]), (res[0][3]["g"], res[1][3]["g"]), (res[0][3]["d"], res[1][3]["d"])):
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_split_d_pass_is_offered_only_where_it_exists():
+    """jck_engine_grad_tail: the arena offset PHASE_D_LOSS_A finalises - DCGAN with the batched schedule only; CGAN (gradients keep
+    arriving until the penalty's double backward) and the per-pass schedule (batch % 8 != 0) answer -1 and refuse the phases."""
+    sys.path.insert(0, os.path.join(ROOT, "jck-generation_amd"))
+    import ctypes
+    from hipgan import JckError
+    from hipgan._lib import lib
+    from hipgan.engine import CganEngine, DcganEngine, PHASE_D_LOSS_A, StepInputs
+    eng = DcganEngine(batch=16, prec="bf16", device="cuda:0")
+    tail = lib.jck_engine_grad_tail(eng._h, 1)
+    views = eng.named_views("d", "grads")
+    names = list(views.keys())
+    first = views[names[names.index("conv4.weight")]]
+    assert tail == (first.data_ptr() - eng.arenas["d_grads"].data_ptr()) // 4 and tail > 0
+    assert lib.jck_engine_grad_tail(eng._h, 0) == -1                                  # G has no such split
+    for other in (DcganEngine(batch=4, prec="bf16", device="cuda:0"), CganEngine(batch=16, prec="bf16", device="cuda:0")):
+        assert lib.jck_engine_grad_tail(other._h, 1) == -1
+        si = StepInputs()
+        si.step = 1
+        si.labels = torch.zeros(16, 100, dtype=torch.int64, device="cuda").data_ptr()
+        with pytest.raises(JckError):
+            lib.jck_engine_phase(other._h, PHASE_D_LOSS_A, ctypes.byref(si), None)
