@@ -312,12 +312,12 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
 // stage 1: partial[blk][0..C) = sum g_z,  partial[blk][C..2C) = sum g_z * xhat over this workgroup's rows,
 // g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics:
 // the summation order per (thread, channel) is fixed by the launch geometry alone, so the result is bitwise reproducible.
-// Geometry (measured in the step, round 2): <= 256 workgroups per group and one row per thread and pass.  A variant with
-// 1024 workgroups and 4 rows in flight per thread (8x the bytes in flight) was SLOWER in the step (29.3 vs 22.1 us average):
-// the kernel runs beside the weight-gradient product of the previous layer on the second stream and both are bound by the
-// same memory system, so more loads in flight here only take bandwidth from there.
+// Geometry (measured in the step, round 2): <= 256 workgroups per group.  A variant with 1024 workgroups and 4 rows in flight per
+// thread (8x the bytes in flight) was SLOWER in the step (29.3 vs 22.1 us average): the kernel runs beside the weight-gradient
+// product of the previous layer on the second stream and both are bound by the same memory system.  Two rows in flight at the
+// same 256 workgroups (UNR = 2, the default; same summation order, same bits) is the optimum: step 1.867 -> 1.837 ms, UNR 4: 1.853.
 #define BN_BWD_MAX_BLOCKS 256
-template <typename T>
+template <typename T, int UNR = 1>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
                                                             float* __restrict__ partial, long long rows, int C,
@@ -334,16 +334,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     sc[k] = aux[c + k]; sh[k] = aux[C + c + k]; mu[k] = aux[2 * C + c + k]; is[k] = aux[3 * C + c + k];
     s1[k] = 0.f; s2[k] = 0.f;
   }
-  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
-    float vg[8], vy[8];
-    ld8(ga + r * C + c, vg);
-    ld8(y + r * C + c, vy);
+  // UNR rows of this thread's sequence are loaded together and accumulated in sequence order: the same sums, bit for bit,
+  // with UNR times the bytes in flight
+  const long long stride = (long long)gridDim.x * rstep;
+  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += stride * UNR) {
+    float vg[UNR][8], vy[UNR][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float z = vy[k] * sc[k] + sh[k];
-      const float gz = z > 0.f ? vg[k] : slope * vg[k];
-      s1[k] += gz;
-      s2[k] += gz * ((vy[k] - mu[k]) * is[k]);
+    for (int u = 0; u < UNR; ++u) {
+      const long long ru = r + u * stride;
+      if (ru < rows) { ld8(ga + ru * C + c, vg[u]); ld8(y + ru * C + c, vy[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (r + u * stride >= rows) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = vy[u][k] * sc[k] + sh[k];
+        const float gz = z > 0.f ? vg[u][k] : slope * vg[u][k];
+        s1[k] += gz;
+        s2[k] += gz * ((vy[u][k] - mu[k]) * is[k]);
+      }
     }
   }
 #pragma unroll
@@ -1071,20 +1081,29 @@ __global__ __launch_bounds__(256) void bn2_reduce_kernel(const T* __restrict__ a
 #pragma unroll
     for (int q = 0; q < NA; ++q) acc[q][k] = 0.f;
   }
-  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += (long long)gridDim.x * rstep) {
-    float va[8], vb[8], vc[8];
-    ld8(a + r * C + ch, va);
-    ld8(b + r * C + ch, vb);
-    ld8(c + r * C + ch, vc);
+  // two rows of this thread's sequence in flight, accumulated in sequence order (same sums, bit for bit; see bn_bwd_reduce_kernel)
+  constexpr int UNR = 2;
+  const long long stride = (long long)gridDim.x * rstep;
+  for (long long r = (long long)blockIdx.x * rstep + r0; r < rows; r += stride * UNR) {
+    float va[UNR][8], vb[UNR][8], vc[UNR][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (vb[k] - mu[k]) * is[k];
-      if (MODE == 1) {
-        acc[0][k] += va[k]; acc[1][k] += va[k] * xh; acc[2][k] += va[k] * vc[k];
-      } else {
-        const float z = vb[k] * sc[k] + sh[k];
-        const float uz = z > 0.f ? va[k] : slope * va[k];
-        acc[0][k] += uz; acc[1][k] += uz * xh; acc[2][k] += vc[k]; acc[NA - 1][k] += vc[k] * xh;
+    for (int q = 0; q < UNR; ++q) {
+      const long long rq = r + q * stride;
+      if (rq < rows) { ld8(a + rq * C + ch, va[q]); ld8(b + rq * C + ch, vb[q]); ld8(c + rq * C + ch, vc[q]); }
+    }
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      if (r + q * stride >= rows) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (vb[q][k] - mu[k]) * is[k];
+        if (MODE == 1) {
+          acc[0][k] += va[q][k]; acc[1][k] += va[q][k] * xh; acc[2][k] += va[q][k] * vc[q][k];
+        } else {
+          const float z = vb[q][k] * sc[k] + sh[k];
+          const float uz = z > 0.f ? va[q][k] : slope * va[q][k];
+          acc[0][k] += uz; acc[1][k] += uz * xh; acc[2][k] += vc[q][k]; acc[NA - 1][k] += vc[q][k] * xh;
+        }
       }
     }
   }

@@ -27,6 +27,7 @@ static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised
 static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
 static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wave-specialised gather-GEMMs (igemm.hpp); bit 0: 128x256, 1: 128x64, 2: 64x128 tiles
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
+static int g_bn_unr = env_int("JCK_BN_UNR", 2);                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
 static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
@@ -36,7 +37,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"stat_accum", &g_stat_accum},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -752,8 +753,12 @@ extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const fl
   // stage 1: per-workgroup partial sums -> sums[2C + blk*2C ..];  stage 2: reduce to sums[0..2C) (+ dgamma/dbeta)
   const int blocks = bn_bwd_blocks(rows, rstep, 1);
   float* partial = sums + 2 * C;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C));
+  if (g_bn_unr >= 4) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
+  else if (g_bn_unr == 2) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
+  else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C);
   HIPCHK(hipGetLastError());
@@ -796,8 +801,12 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
   const int blocks = bn_bwd_blocks(rows, rstep, groups);
   const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
   float* partial = sums + 2 * C;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride));
+  if (g_bn_unr >= 4) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride)); }
+  else if (g_bn_unr == 2) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride)); }
+  else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride)); }
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C,
                      gstride, groups, grad_groups);
