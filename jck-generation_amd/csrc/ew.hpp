@@ -623,20 +623,37 @@ static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, f
     }
   }
 }
+__device__ __forceinline__ void adam_one(float& pi, float gi_raw, float& mi_io, float& vi_io, float w1, float beta2, float omb2,
+                                         float eps, float step_size, float bc2_sqrt, float grad_scale) {
+  const float gi = gi_raw * grad_scale;
+  // exp_avg.lerp_(grad, 1-beta1): weight 0.5 takes ATen's "end - (end-start)*(1-w)" branch when w >= 0.5
+  const float mi = (w1 < 0.5f) ? mi_io + w1 * (gi - mi_io) : gi - (gi - mi_io) * (1.f - w1);
+  const float vi = vi_io * beta2 + (omb2 * gi) * gi;
+  mi_io = mi;
+  vi_io = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  pi = pi - step_size * (mi / denom);
+}
+// four elements per thread (16-byte loads and stores: the arenas are 16-byte aligned); the last n % 4 elements one by one
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float w1 /*1-beta1*/, float beta2, float omb2 /*1-beta2*/,
-                            float eps, float step_size, float bc2_sqrt, float grad_scale, const float* __restrict__ hp = nullptr) {
+                            float eps, float step_size, float bc2_sqrt, float grad_scale, const float* __restrict__ hp = nullptr,
+                            int vec = 1) {
   if (hp) { step_size = hp[0]; bc2_sqrt = hp[1]; }
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * grad_scale;
-    // exp_avg.lerp_(grad, 1-beta1): weight 0.5 takes ATen's "end - (end-start)*(1-w)" branch when w >= 0.5
-    const float mi = (w1 < 0.5f) ? m[i] + w1 * (gi - m[i]) : gi - (gi - m[i]) * (1.f - w1);
-    const float vi = v[i] * beta2 + (omb2 * gi) * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+  const long long n4 = vec ? (n >> 2) : 0;                 // vec = 0: a pointer is not 16-byte aligned -> element by element
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = pv[k], mk = mv[k], vk = vv[k];
+      adam_one(pk, gv[k], mk, vk, w1, beta2, omb2, eps, step_size, bc2_sqrt, grad_scale);
+      pv[k] = pk; mv[k] = mk; vv[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv; reinterpret_cast<f32x4*>(m)[i] = mv; reinterpret_cast<f32x4*>(v)[i] = vv;
   }
+  for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    adam_one(p[i], g[i], m[i], v[i], w1, beta2, omb2, eps, step_size, bc2_sqrt, grad_scale);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -991,8 +991,9 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
   // scalar preparation in double exactly as torch.optim.Adam does it in Python, then one cast to float
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
   const float step_size = (float)(lr / bc1), bc2s = (float)std::sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2s, grad_scale, (const float*)nullptr);
+  const int vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2s, grad_scale, (const float*)nullptr, vec);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1019,8 +1020,9 @@ extern "C" int jck_step_rng(float* hp, int step, unsigned long long seed, float*
 }
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st) {
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp);
+  const int vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp, vec);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

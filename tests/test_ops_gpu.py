@@ -317,18 +317,22 @@ def test_head_clamp(G):
     assert float(ds.abs().max()) == 0.0
 
 
-def test_adam(G):
+@pytest.mark.parametrize("off", [0, 1])
+def test_adam(G, off):
+    """off = 0: 16-byte aligned arenas (four elements per thread + a scalar tail, n % 4 = 3); off = 1: views that start one
+    element into their buffers (the element-by-element path)."""
     g = torch.Generator().manual_seed(7)
     n = 10007
     p0 = torch.randn(n, generator=g)
     p = p0.clone().requires_grad_(True)
     opt = torch.optim.Adam([p], lr=2e-4, betas=[0.5, 0.999])
-    pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    buf = lambda t: torch.cat([torch.zeros(off), t]).cuda()[off:]
+    pd, m, v = buf(p0.clone()), buf(torch.zeros(n)), buf(torch.zeros(n))
     for step in range(1, 6):
         gr = torch.randn(n, generator=g) * (10.0 ** (step - 3))
         p.grad = gr.clone()
         opt.step()
-        G.lib.jck_adam(pd, gr.cuda(), m, v, n, 2e-4, 0.5, 0.999, 1e-8, step, 1.0, G.cur_stream())
+        G.lib.jck_adam(pd, buf(gr), m, v, n, 2e-4, 0.5, 0.999, 1e-8, step, 1.0, G.cur_stream())
         torch.cuda.synchronize()
         assert (pd.cpu() - p.detach()).abs().max().item() < 3e-7, step
 
