@@ -123,6 +123,65 @@ int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux
                       int slots_per_group, float* sums, void* g_y, float* dgamma, float* dbeta, long long rows_per_group, int C,
                       int groups, int grad_groups, void* stream);
 
+/* ---- BatchNorm statistics accumulated by the launch that writes the tensor, finalised by the one that reads it ------------
+ * (csrc/bnstat.hpp, round 3).  The `_x` producers are the conv / dgrad / reduction launches above with the statistics in their
+ * second form: per-channel sums kept exactly (three integer limbs per sum, integer atomics - the total does not depend on the
+ * arrival order, two runs give the same bits) in `xbuf`.  The `_x` consumers (jck_bn_act_fwd_x, jck_bn_bwd_apply_x) turn the
+ * sums into coefficients in their prologue and leave the tables later launches read.  No jck_bn_finalize / bn_bwd_sums launch,
+ * no slot rows, and - backward - no separate reduction pass over (g_a, y).
+ *   xbuf: jck_bnx_bytes(C, groups) bytes, ZEROED by the caller before the producer launch (hipMemsetAsync on the same stream;
+ *         the engine zeroes a whole pass's accumulators with one memset).
+ *   forward  (producers jck_conv_down_x / jck_conv_up_x / jck_g1_fwd_x read xbuf, groups, group_images; consumer
+ *         jck_bn_act_fwd_x; replaces aten::native_batch_norm, model/DCGAN.py:30-33,62-65): a = act(scale*y + shift), fills
+ *         aux[groups][4C] = scale | shift | mean | invstd, rec[groups][2C] = mean | unbiased var (optional; the deferred
+ *         running-stat record), or - groups == 1 - updates running_mean / running_var / num_batches_tracked in place (optional).
+ *   backward (producers jck_conv_up_bnx / jck_conv_down_bnx = dgrad whose epilogue reads the saved conv output bn_y of the
+ *         layer its output is the gradient of, and that layer's aux; jck_bn_bwd_reduce_x = the reduction pass alone, for a
+ *         layer whose gradient comes from elsewhere; consumer jck_bn_bwd_apply_x): g_y = scale*(g_z - s1/n - xhat*s2/n), fills
+ *         sums[groups][sums_stride] (first 2C floats of a group: sum g_z | sum g_z*xhat), adds the groups < grad_groups to
+ *         dgamma / dbeta (optional).  Together: aten::native_batch_norm_backward + leaky_relu_backward / threshold_backward
+ *         under train/dcgan_trainer.py:164,175,187 with ONE pass over (g_a, y) instead of two. */
+typedef struct jck_bn_job {
+  void* xbuf;                 /* accumulators, zeroed by the caller before the producer launch */
+  int groups;                 /* BatchNorm batches stored back to back in the tensor (>= 1) */
+  int group_images;           /* images per group (N = groups * group_images) */
+  /* forward */
+  const float* gamma;
+  const float* beta;
+  float eps, momentum;
+  float* aux;                 /* forward: out [groups][4C]; backward: in */
+  float* rec;                 /* [groups][2C] or NULL */
+  float* running_mean;        /* [C] or NULL (groups == 1) */
+  float* running_var;
+  int64_t* num_batches_tracked;
+  /* backward */
+  const void* bn_y;           /* saved conv output of the normalised layer, layout of the launch's output */
+  float slope;                /* LeakyReLU slope (0 = ReLU) */
+  float* sums;
+  long long sums_stride;      /* floats between two groups' rows (>= 2C) */
+  float* dgamma;
+  float* dbeta;
+  int grad_groups;
+} jck_bn_job;
+size_t jck_bnx_bytes(int C, int groups);
+int jck_conv_down_x(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
+                    const jck_bn_job* job, void* stream);
+int jck_conv_up_x(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
+                  const jck_bn_job* job, void* stream);
+int jck_g1_fwd_x(int prec, const void* z, const void* w, void* out, int B, int CiPad, int Co, const jck_bn_job* job, void* stream);
+int jck_conv_up_bnx(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
+                    const jck_bn_job* job, void* stream);
+int jck_conv_down_bnx(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
+                      const jck_bn_job* job, void* stream);
+int jck_bn_bwd_reduce_x(int prec, const void* g_a, const void* y, long long rows_per_group, int C, const jck_bn_job* job,
+                        void* stream);
+int jck_bn_act_fwd_x(int prec, const void* y, float slope, void* a, long long rows_per_group, int C, const jck_bn_job* job,
+                     void* stream);
+int jck_bn_bwd_apply_x(int prec, const void* g_a, const void* y, void* g_y, long long rows_per_group, int C, const jck_bn_job* job,
+                       void* stream);
+int jck_bn_bwd_apply(int prec, const void* g_a, const void* y, const float* aux, const float* sums, long long sums_stride,
+                     float slope, void* g_y, long long rows_per_group, int C, int groups, void* stream);
+
 /* ---- images, noise, heads, loss ----------------------------------------------------------------------------- */
 /* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */
 int jck_img_prep(int prec, const float* img_nchw, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,

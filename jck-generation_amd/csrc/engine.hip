@@ -117,7 +117,8 @@ struct Carver {
   }
 };
 
-struct BnBuf { float *stats, *sums, *aux; int slots; };
+struct BnBuf { float *stats, *sums, *aux; int slots; void *xf, *xb; };     // xf / xb: exact-sum accumulators, forward / backward (bnstat.hpp)
+struct XsRegion { unsigned char* base = nullptr; size_t bytes = 0; };     // a pass's accumulators, zeroed with ONE memset before the pass
 
 }  // namespace
 
@@ -137,13 +138,14 @@ struct jck_engine {
   float *d_head_wp, *d_head_dwp;
   void *g1_w, *g_up[JCK_MAX_STAGES], *g_down[JCK_MAX_STAGES];
   // activations: three B-image D sets for the per-pass schedules (each pass that may run concurrently has its own)
-  struct DSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES], *gx; BnBuf bn[JCK_MAX_STAGES]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
+  struct DSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES], *gx; BnBuf bn[JCK_MAX_STAGES]; float *prob, *ds, *norms; XsRegion xr; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
   void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
   void*& d_gx = dset[0].gx;
   BnBuf* d_bn = dset[0].bn;
   float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
   // batched D passes (DCGAN): up to 3 batches that share D's weights go through ONE launch per layer, BatchNorm grouped
-  struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds; } bset;
+  struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds;
+                void *xf[JCK_MAX_STAGES], *xb[JCK_MAX_STAGES], *xf_pre[JCK_MAX_STAGES]; XsRegion xr, xr_pre; } bset;
   int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
   bool gp_done = false;
   long long real_fwd_step = -1;         // step whose D(real) forward already ran (PHASE_D_REAL_FWD), -1: none
@@ -156,6 +158,8 @@ struct jck_engine {
   hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr, evBucket = nullptr;
   bool bucket_ready = false;            // evBucket was recorded in this step's PHASE_D_LOSS (gradients of conv4.weight .. conv5.weight final)
   bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
+  bool bn2 = false;                     // exact-sum statistics accumulated by the producing launch (bnstat.hpp); JCK_BN2=1
+  XsRegion g_xr;
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
@@ -269,6 +273,36 @@ struct jck_engine {
     // which is on that stream): its own split-K workspace, because the side stream may still be using wg_ws
     g1_ws_bytes = jck_g1_wgrad_ws_bytes(B, z_pad(family), TT.G_C1);
     g1_ws = c.take<float>(g1_ws_bytes / 4);
+    // exact-sum accumulators (bnstat.hpp): forward + backward of every BatchNorm layer, one contiguous region per pass
+    {
+      auto region = [&](XsRegion& r, auto&& fill) {
+        const size_t start = c.off;
+        fill();
+        r.base = base ? base + start : nullptr; r.bytes = c.off - start;
+      };
+      for (int sI = 0; sI < 3; ++sI)
+        region(dset[sI].xr, [&] {
+          for (int i = 0; i < TT.NS; ++i) {
+            dset[sI].bn[i].xf = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1));
+            dset[sI].bn[i].xb = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1));
+          }
+        });
+      region(g_xr, [&] {
+        for (int i = 0; i < TT.NS; ++i) {
+          g_bn[i].xf = c.take<unsigned char>(jck_bnx_bytes(TT.G_C1 >> i, 1));
+          g_bn[i].xb = c.take<unsigned char>(jck_bnx_bytes(TT.G_C1 >> i, 1));
+        }
+      });
+      if (batched) {
+        region(bset.xr, [&] {
+          for (int i = 0; i < TT.NS; ++i) {
+            bset.xf[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 3));
+            bset.xb[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 3));
+          }
+        });
+        region(bset.xr_pre, [&] { for (int i = 0; i < TT.NS; ++i) bset.xf_pre[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1)); });
+      }
+    }
     if (family == 1) {
       l1_w = c.take<unsigned char>(bytes((size_t)L1_OUT * L1_KPAD)); l1_wT = c.take<unsigned char>(bytes((size_t)L1_KPAD * L1_OUT));
       // head buffers: HR batches of rows - the batched schedule runs the label / Linear / Dropout head of the real | fake |
@@ -326,6 +360,11 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   // BatchNorm-backward statistics in the dgrad epilogue (jck_conv_*_bnbwd): correct and tested, but measured 4 % SLOWER than
   // the separate reduction pass at B=256 (the extra epilogue work lengthens every workgroup's tail) - opt-in
   e->fuse_bnbwd = getenv("JCK_FUSE_BNBWD") && atoi(getenv("JCK_FUSE_BNBWD")) != 0;
+  // Exact-sum statistics accumulated by the producing launch and finalised in the consumer's prologue (bnstat.hpp; no
+  // bn_finalize / bn_bwd_reduce / bn_bwd_sums launches: 93 instead of 126 per DCGAN step).  Correct, deterministic and tested,
+  // but measured 4-6 % SLOWER at batch 256 (1.97-1.99 vs 1.85-1.89 ms): opt-in, JCK_BN2=1.
+  e->bn2 = getenv("JCK_BN2") && atoi(getenv("JCK_BN2")) != 0;
+  if (e->bn2) e->fuse_bnbwd = false;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
@@ -461,15 +500,44 @@ static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
 typedef jck_engine::DSet DSet;
 
+// jobs of the exact-sum statistics (include/jckgan.h: jck_bn_job)
+static jck_bn_job bn_fwd_job(void* xbuf, int groups, int group_images, const float* gamma, const float* beta, float* aux, float* rec,
+                             float* rm = nullptr, float* rv = nullptr, int64_t* nbt = nullptr) {
+  jck_bn_job j = {};
+  j.xbuf = xbuf; j.groups = groups; j.group_images = group_images; j.gamma = gamma; j.beta = beta; j.eps = 1e-5f; j.momentum = 0.1f;
+  j.aux = aux; j.rec = rec; j.running_mean = rm; j.running_var = rv; j.num_batches_tracked = nbt;
+  return j;
+}
+static jck_bn_job bn_bwd_job(void* xbuf, int groups, int group_images, const void* y, float* aux, float slope, float* sums, int C,
+                             float* dgamma, float* dbeta, int grad_groups) {
+  jck_bn_job j = {};
+  j.xbuf = xbuf; j.groups = groups; j.group_images = group_images; j.bn_y = y; j.aux = aux; j.slope = slope; j.sums = sums;
+  j.sums_stride = (long long)jck_bn_bwd_ws_floats(C); j.dgamma = dgamma; j.dbeta = dbeta; j.grad_groups = grad_groups;
+  return j;
+}
+static int zero_region(const XsRegion& r, hipStream_t st) {
+  if (r.base && r.bytes) HIPCHK(hipMemsetAsync(r.base, 0, r.bytes, st));
+  return JCK_OK;
+}
+
 // conv stack of D on activation set `D`; BatchNorm running statistics are NOT touched here: (mean, unbiased var) go to the
 // deferred record of `pass` (0 real, 1 fake, 2 penalty, 3 G phase) and are applied in that order at the end of the step,
 // which keeps the result bitwise independent of how the passes overlap on streams.
 static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st) {
   const void* in = x_in;
+  if (e->bn2) JCK_TRY(zero_region(D.xr, st));              // forward and backward accumulators of this pass
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
-    JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
+    if (e->bn2) {       // the conv launch accumulates the statistics, the activation launch finalises them (no bn_finalize launch)
+      const jck_bn_job job = bn_fwd_job(D.bn[i].xf, 1, B, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), D.bn[i].aux,
+                                        e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
+      JCK_TRY(jck_conv_down_x(e->prec, in, e->d_down[i], D.y[i], B, hb, hb, TT.D_CB[i], cs, &job, st));
+      JCK_TRY(jck_bn_act_fwd_x(e->prec, D.y[i], LRELU, D.a[i], rows, cs, &job, st));
+      in = D.a[i];
+      continue;
+    }
+    JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
@@ -567,6 +635,16 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     float* dgam = want_wgrad ? e->P(e->LD, e->dg, NWN[i]) : nullptr;
     float* dbet = want_wgrad ? e->P(e->LD, e->dg, NBN[i]) : nullptr;
+    if (e->bn2) {
+      // s1 | s2, dgamma, dbeta of layer i were left by the dgrad launch of layer i+1 (previous iteration); the top layer's
+      // gradient comes from the head: one reduction launch.  Then ONE pass over (g, y) writes g_y.
+      if (i == TT.NS - 1) {
+        const jck_bn_job job = bn_bwd_job(D.bn[i].xb, 1, B, D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, cs, dgam, dbet, 1);
+        JCK_TRY(jck_bn_bwd_reduce_x(e->prec, D.g[i], D.y[i], rows, cs, &job, st));
+      }
+      const jck_bn_job aj = bn_bwd_job(D.bn[i].xb, 1, B, D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, cs, dgam, dbet, 1);
+      JCK_TRY(jck_bn_bwd_apply_x(e->prec, D.g[i], D.y[i], D.g[i], rows, cs, &aj, st));
+    } else
     if (i < TT.NS - 1 && e->fuse_bnbwd)      // the dgrad launch below (previous iteration) already left sum g_z, sum g_z*xhat in the slots
       JCK_TRY(jck_bn_bwd_finish(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].stats, D.bn[i].slots, D.bn[i].sums, D.g[i], dgam,
                                 dbet, rows, cs, 1, 1, st));
@@ -578,6 +656,12 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
       if (par) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
       JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, ws));
     }
+    if (i > 0 && e->bn2) {
+      const int cl = TT.D_CS[i - 1];
+      const jck_bn_job job = bn_bwd_job(D.bn[i - 1].xb, 1, B, D.y[i - 1], D.bn[i - 1].aux, LRELU, D.bn[i - 1].sums, cl,
+                                        want_wgrad ? e->P(e->LD, e->dg, NWN[i - 1]) : nullptr, want_wgrad ? e->P(e->LD, e->dg, NBN[i - 1]) : nullptr, 1);
+      JCK_TRY(jck_conv_up_bnx(e->prec, D.g[i], e->d_up[i], D.g[i - 1], B, hb / 2, hb / 2, cs, cb, &job, st));
+    } else
     if (i > 0 && e->fuse_bnbwd)
       JCK_TRY(jck_conv_up_bnbwd(e->prec, D.g[i], e->d_up[i], D.g[i - 1], D.bn[i - 1].stats, &D.bn[i - 1].slots, B, hb / 2, hb / 2, cs, cb,
                                 D.y[i - 1], D.bn[i - 1].aux, LRELU, 0, st));
@@ -603,12 +687,23 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   const void* in = x_in;
+  if (e->bn2) JCK_TRY(zero_region((g0 == 0 && n == 1) ? S.xr_pre : S.xr, st));
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // statistic slots of group g0 start at the g0/3 point of the buffer (sized for 3B pixels at one slot per 32 pixels)
     float* stats = S.stats[i] + (size_t)g0 * (jck_stats_floats((long long)3 * B * (hb / 2) * (hb / 2), cs, 1) / 3 / (2 * cs)) * (2 * cs);
     int slots = 0;
+    if (e->bn2) {
+      // (g0, n) = (0, 3) or (1, 2): the pass's own accumulators; (0, 1) = D(real) ahead of its pass: a set of its own
+      void* xbuf = (g0 == 0 && n == 1) ? S.xf_pre[i] : S.xf[i];
+      const jck_bn_job job = bn_fwd_job(xbuf, n, B, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), S.aux[i] + (size_t)g0 * 4 * cs,
+                                        e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs);
+      JCK_TRY(jck_conv_down_x(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), n * B, hb, hb, TT.D_CB[i], cs, &job, st));
+      JCK_TRY(jck_bn_act_fwd_x(e->prec, at(S.y[i], (size_t)g0 * rows * cs), LRELU, at(S.a[i], (size_t)g0 * rows * cs), rows, cs, &job, st));
+      in = at(S.a[i], (size_t)g0 * rows * cs);
+      continue;
+    }
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, B, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
@@ -637,6 +732,13 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     const bool resume = part == 2 && i == TT.NS - 1;      // part 2 starts at this layer's dgrad
     if (resume) {
+    } else if (e->bn2) {
+      if (i == TT.NS - 1) {            // the top layer's gradient comes from the head: one reduction launch over all groups
+        const jck_bn_job job = bn_bwd_job(S.xb[i], G, B, S.y[i], S.aux[i], LRELU, S.sums[i], cs, e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), gw);
+        JCK_TRY(jck_bn_bwd_reduce_x(e->prec, S.g[i], S.y[i], rows, cs, &job, st));
+      }
+      const jck_bn_job aj = bn_bwd_job(S.xb[i], G, B, S.y[i], S.aux[i], LRELU, S.sums[i], cs, e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), gw);
+      JCK_TRY(jck_bn_bwd_apply_x(e->prec, S.g[i], S.y[i], S.g[i], rows, cs, &aj, st));
     } else if (i < TT.NS - 1 && e->fuse_bnbwd)
       JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
                                 e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
@@ -660,7 +762,12 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
       HIPCHK(hipEventRecord(e->evBucket, ws));
       e->bucket_ready = true;
     }
-    if (i > 0 && e->fuse_bnbwd) {
+    if (i > 0 && e->bn2) {
+      const int cl = TT.D_CS[i - 1];
+      const jck_bn_job job = bn_bwd_job(S.xb[i - 1], G, B, S.y[i - 1], S.aux[i - 1], LRELU, S.sums[i - 1], cl, e->P(e->LD, e->dg, NWN[i - 1]),
+                                        e->P(e->LD, e->dg, NBN[i - 1]), gw);
+      JCK_TRY(jck_conv_up_bnx(e->prec, S.g[i], e->d_up[i], S.g[i - 1], G * B, hb / 2, hb / 2, cs, cb, &job, st));
+    } else if (i > 0 && e->fuse_bnbwd) {
       JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
                                 S.y[i - 1], S.aux[i - 1], LRELU, B, st));
       if (bslots[i - 1] % G) JCK_FAIL(JCK_E_ARG, "batched D pass: backward statistic slots do not split by group");
@@ -811,6 +918,29 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
     if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, 100, zp, e->g_z, st); else launch_pad_rows<float>(z, B, 100, zp, e->g_z, st);
     HIPCHK(hipGetLastError());
   }
+  if (e->bn2) {
+    // statistics, scale / shift and the running statistics of layer i come out of the launch that writes its input
+    JCK_TRY(zero_region(e->g_xr, st));
+    auto job_of = [&](int i) {
+      return bn_fwd_job(e->g_bn[i].xf, 1, B, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]), e->g_bn[i].aux, nullptr,
+                        e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset, e->gnbt + i);
+    };
+    const jck_bn_job j0 = job_of(0);
+    JCK_TRY(jck_g1_fwd_x(e->prec, e->g_z, e->g1_w, e->g_y[0], B, zp, TT.G_C1, &j0, st));
+    for (int i = 0; i < TT.NS; ++i) {
+      const int h = 4 << i, C = TT.G_C1 >> i;
+      const long long rows = (long long)B * h * h;
+      const jck_bn_job jc = job_of(i);
+      JCK_TRY(jck_bn_act_fwd_x(e->prec, e->g_y[i], 0.f, e->g_a[i], rows, C, &jc, st));
+      if (i < TT.NS - 1) {
+        const jck_bn_job ji = job_of(i + 1);
+        JCK_TRY(jck_conv_up_x(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], B, h, h, TT.G_CS[i], TT.G_CB[i], &ji, st));
+      } else {
+        JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
+      }
+    }
+    return JCK_OK;
+  }
   JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, zp, TT.G_C1, st));
   for (int i = 0; i < TT.NS; ++i) {
     const int h = 4 << i, C = TT.G_C1 >> i;
@@ -838,7 +968,12 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
     const long long rows = (long long)B * hs * hs;
-    if (e->fuse_bnbwd) {
+    if (e->bn2) {
+      const jck_bn_job job = bn_bwd_job(e->g_bn[i].xb, 1, B, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, cs, e->P(e->LG, e->gg, NWN[i]),
+                                        e->P(e->LG, e->gg, NBN[i]), 1);
+      JCK_TRY(jck_conv_down_bnx(e->prec, gbig, e->g_down[i], e->g_gr[i], B, 2 * hs, 2 * hs, cb, cs, &job, st));
+      JCK_TRY(jck_bn_bwd_apply_x(e->prec, e->g_gr[i], e->g_y[i], e->g_gr[i], rows, cs, &job, st));
+    } else if (e->fuse_bnbwd) {
       JCK_TRY(jck_conv_down_bnbwd(e->prec, gbig, e->g_down[i], e->g_gr[i], e->g_bn[i].stats, &e->g_bn[i].slots, B, 2 * hs, 2 * hs, cb, cs,
                                   e->g_y[i], e->g_bn[i].aux, 0.f, 0, st));
       JCK_TRY(jck_bn_bwd_finish(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].stats, e->g_bn[i].slots, e->g_bn[i].sums,

@@ -19,6 +19,7 @@
 // per-(tile, wave) slot that jck_bn_finalize sums - and tanh.
 #pragma once
 #include "common.hpp"
+#include "bnstat.hpp"
 
 struct IgemmParams {
   const void* act;        // gathered NHWC tensor, element type T
@@ -62,6 +63,10 @@ struct IgemmParams {
   // forward statistics accumulated per workgroup and BatchNorm group by the persistent kernels (rows [group][rank][2][cstat],
   // group = pixel row / bn_group_rows) instead of one row per (tile, wave); set by the launcher for the *_grouped entry points
   int stat_accum;
+  // second form of the statistics (bnstat.hpp): exact sums by integer atomics, finalised by the launch's last workgroup.
+  // bnj.xs != nullptr switches every statistics path of this file to it (forward: bnj.mode 1; with bn_y: mode 2, the second
+  // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
+  BnStatJob bnj;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -131,18 +136,21 @@ __device__ __forceinline__ void igemm_bn_prefetch(const IgemmParams& p, int lane
 // Shared epilogue: optional BatchNorm partial statistics, bias, tanh, NHWC store of 4 consecutive channels per lane.
 template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN, bool BNB>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z, int zraw,
-                                               int bidx, int bidy, int m0, int ch0, typename BnRaw<P>::R (&ypre)[BNB ? FM : 1][BNB ? FN : 1]) {
+                                               int bidx, int bidy, int m0, int ch0, typename BnRaw<P>::R (&ypre)[BNB ? FM : 1][BNB ? FN : 1],
+                                               float* x2scr = nullptr) {
   typedef typename P::T T;
   // ---- epilogue --------------------------------------------------------------------------------------
   long long poff[FN];                                               // output offset of this lane's pixel in tile column j (-1: past M)
   igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
-  if (p.stats) {
+  const bool x2 = p.bnj.xs != nullptr;                              // exact sums by atomics (bnstat.hpp) instead of slot rows
+  if (p.stats || x2) {
     // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
     // pixel tile slowest, so that the slots of consecutive pixel ranges (BatchNorm groups) are consecutive too
     const long long slot = (((long long)bidx * p.gz + zraw) * nyrep + yrep) * WPIXN + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
-    const float* aux = p.bn_aux + (p.bn_group_rows > 0 ? (long long)(m0 / p.bn_group_rows) * 4 * p.cstat : 0);
+    const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
+    const float* aux = p.bn_aux + (long long)grp * 4 * p.cstat;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
@@ -166,7 +174,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             const float zz = yv[r] * sc[r] + sh[r];
             const float gz = zz > 0.f ? v : p.bn_slope * v;
             s[r] += gz;
-            q[r] += gz * ((yv[r] - mu[r]) * is[r]);
+            q[r] += x2 ? gz * (yv[r] - mu[r]) : gz * ((yv[r] - mu[r]) * is[r]);
           }
         }
       } else {
@@ -178,8 +186,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
       if ((lane & 15) == 0 && chok) {
-        *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
-        *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
+        if (!x2) {
+          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
+          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
+        }
+      }
+      if (x2 && (lane & 15) == 0) {     // this wave's partial of its FM * 16 channels -> LDS (igemm_stats_tail adds the waves' rows)
+        float* sr = x2scr + ((wch * WPIXN + wpix) * 2) * (FM * 16) + i * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<f32x4*>(sr) = chok ? f32x4{s[0], s[1], s[2], s[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sr + FM * 16) = chok ? f32x4{q[0], q[1], q[2], q[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
@@ -207,6 +222,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
       else st4(outp + off + ch, v);
     }
   }
+}
+
+// exact-sum statistics of a one-tile workgroup (bnstat.hpp): the waves' partial rows (written to LDS by igemm_epilogue) are added
+// per channel and go out as one atomic add per (channel, statistic); the consumer kernel finalises.  Called by every
+// thread that ran the epilogue (nthr of them: the whole workgroup, or the consumer waves once the loader waves have returned).
+template <int BCH, int CHW, int WPIXN>
+__device__ __forceinline__ void igemm_stats_tail(const IgemmParams& p, const float* scr, unsigned* flag, int tid, int nthr, int m0, int ch0) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
+  bn_wg_partials_add<BCH, CHW, WPIXN>(p.bnj, scr, tid, nthr, (int)(blockIdx.x % (unsigned)p.bnj.reps), grp, ch0, p.NchStore, p.cstat);
+  (void)flag;
 }
 
 template <class P, int BCH, int BPIX, int NSUB, int NST = 2, bool BNB = false>
@@ -390,7 +417,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
+  // the k-loop ended on a barrier: the LDS tiles are free for the statistics' partial rows (behind the dead tap tables)
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre, reinterpret_cast<float*>(lds));
+  if (p.bnj.xs)
+    igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds), reinterpret_cast<unsigned*>(smem_raw), tid, 256, m0, ch0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -535,7 +565,11 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
       compute(slot);
       slot = slot == 2 ? 0 : slot + 1;
     }
-    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
+    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre,
+                                                       reinterpret_cast<float*>(lds + NSTG * STG_BYTES + 64));
+    if (p.bnj.xs)
+      igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds + NSTG * STG_BYTES + 64),
+                                              reinterpret_cast<unsigned*>(lds + NSTG * STG_BYTES), tid, NCW * 64, m0, ch0);
     return;
   }
   if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);   // older than every DMA: done by the first wait
@@ -559,7 +593,11 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
     st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dead tail loads before the epilogue reuses nothing of LDS
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre);
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre,
+                                                     reinterpret_cast<float*>(lds + NSTG * STG_BYTES + 64));
+  if (p.bnj.xs)
+    igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds + NSTG * STG_BYTES + 64),
+                                            reinterpret_cast<unsigned*>(lds + NSTG * STG_BYTES), tid, 256, m0, ch0);
 }
 
 // Epilogue of the persistent kernel: 16-byte stores.  The loader fills LDS weight row r of every 32-row block with output
@@ -728,18 +766,23 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
   const int sw = ((lane & 15) >> 1) & 7;
   int slot = 0;
-  // BNB: BatchNorm-backward statistics of the tensor this launch's output is the gradient of (sum g_z, sum g_z*xhat per
-  // channel and BatchNorm group), accumulated per LANE over all tiles of the workgroup and reduced over the 16 pixel lanes only
-  // when the group changes (a workgroup's tiles come in increasing pixel order and keep their channel tile): the launch writes
-  // rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with its channel tile - a few
-  // hundred rows instead of one per (tile, wave), and no separate pass over g and y (bn_bwd_reduce_kernel) afterwards.
-  // Forward statistics (sum y, sum y^2) take the same route when the launcher asks for it (p.stat_accum).
+  // Statistics are accumulated per LANE over the tiles of the workgroup that share a (BatchNorm group, channel tile) and leave
+  // the lanes only when that pair changes and at the end (a workgroup's tiles come in increasing pixel order):
+  //   x2 (p.bnj.xs, bnstat.hpp): reduced over the 16 pixel lanes and added to the exact per-channel sums by integer atomics;
+  //      the launch's last workgroup finalises.  Forward (sum y, sum y^2) or - BNB - the BatchNorm-backward sums of the tensor
+  //      this launch's output is the gradient of (sum g_z, sum g_z (y - mean)): no separate pass over g and y afterwards.
+  //   legacy forward rows (p.stats && p.stat_accum, round 2): rows [group][rank * WPIX + wpix][2][cstat], rank = position of
+  //      this workgroup among those with its channel tile; needs the launcher's divisibility conditions.
   constexpr int NPAIR = FM / 2;
   float S1[NPAIR][8], S2[NPAIR][8];
-  int cur_group = -1, next_row_group = 0;
-  const bool acc_stats = BNB || (p.stats && p.stat_accum);
+  int cur_group = -1, cur_ch0 = -1, next_row_group = 0;
+  const bool x2 = p.bnj.xs != nullptr;
+  const bool rows_stats = !x2 && !BNB && p.stats && p.stat_accum;
+  const bool acc_stats = x2 || rows_stats;
   const int ngroups = acc_stats ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
+  const int rep = x2 ? (int)(blockIdx.x % (unsigned)p.bnj.reps) : 0;
   int rank = 0, rows_per_group = 0;
+  if (x2 && tid == 0) *reinterpret_cast<unsigned*>(lds + 3 * STG_BYTES + 16) = 0u;      // flush counter (first used behind >= K/64 barriers)
   if (acc_stats) {
     locate(blockIdx.x);
     // first-tile wgid = base(xcd) + idx with base % gy == 0 (launcher): channel tile = idx % gy, rank = xcd * (G/8/gy) + idx / gy
@@ -751,7 +794,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
 #pragma unroll
       for (int c = 0; c < 8; ++c) { S1[k][c] = 0.f; S2[k][c] = 0.f; }
   }
-  auto bnb_write = [&](int grp, bool zero) __attribute__((always_inline)) {
+  auto rows_write = [&](int grp, bool zero) __attribute__((always_inline)) {
     float* row = p.stats + ((long long)grp * rows_per_group + rank * C::WPIX + wpix) * 2 * p.cstat;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
@@ -768,11 +811,47 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
     }
   };
-  auto bnb_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
-    if (cur_group >= 0) { bnb_write(cur_group, false); next_row_group = cur_group + 1; }
-    for (int gq = next_row_group; gq < grp; ++gq) bnb_write(gq, true);       // groups this workgroup has no tile in
-    if (grp > next_row_group) next_row_group = grp;
+  // x2: the sums of (group grp, channel tile chb) leave the lanes.  Every consumer wave puts its row into LDS and counts itself
+  // in; the wave that arrives last adds the WPIX rows of each channel in wave order and issues the atomics - one partial per
+  // (workgroup, channel, statistic), 64 consecutive channels per instruction.  No barrier (the loader waves are mid-pipeline): the
+  // next flush of any wave lies behind at least one k-loop, whose barriers the last arriver only reaches after it has read the rows.
+  // Two row buffers, alternated per flush: a workgroup's LAST flush may follow the one before it with no k-loop in between (its
+  // last tile opened a new group), but flush n + 2 is always a whole k-loop behind flush n.
+  constexpr int CHW = FM * 16;
+  unsigned* const xcnt = reinterpret_cast<unsigned*>(lds + 3 * STG_BYTES + 16);
+  int nflush = 0;
+  auto x2_flush = [&](int grp, int chb) __attribute__((always_inline)) {
+    float* const xscr = reinterpret_cast<float*>(lds + 3 * STG_BYTES + 64) + (nflush & 1) * (NCW * 2 * CHW);     // [NCW][2][CHW]
+    ++nflush;
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+      float a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] = row16_sum(S1[k][c]); b[c] = row16_sum(S2[k][c]); }
+      if ((lane & 15) == 0) {
+        float* sr = xscr + (wave * 2) * CHW + k * 32 + 8 * (lane >> 4);
+        *reinterpret_cast<f32x4*>(sr) = f32x4{a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f32x4*>(sr + 4) = f32x4{a[4], a[5], a[6], a[7]};
+        *reinterpret_cast<f32x4*>(sr + CHW) = f32x4{b[0], b[1], b[2], b[3]};
+        *reinterpret_cast<f32x4*>(sr + CHW + 4) = f32x4{b[4], b[5], b[6], b[7]};
+      }
+    }
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // behind this wave's LDS stores (in order)
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if ((old + 1u) % (unsigned)NCW == 0u)
+      bn_wg_partials_add<BCH, CHW, C::WPIX>(p.bnj, xscr, lane, 64, rep, grp, chb, p.NchStore, p.cstat);
+  };
+  auto stat_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
+    if (x2) {
+      if (cur_group >= 0) x2_flush(cur_group, cur_ch0);
+    } else {
+      if (cur_group >= 0) { rows_write(cur_group, false); next_row_group = cur_group + 1; }
+      for (int gq = next_row_group; gq < grp; ++gq) rows_write(gq, true);       // groups this workgroup has no tile in
+      if (grp > next_row_group) next_row_group = grp;
+    }
     cur_group = grp;
+    cur_ch0 = ch0;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k)
 #pragma unroll
@@ -805,11 +884,11 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
       slot = slot == 2 ? 0 : slot + 1;
     }
+    const int grp = (acc_stats && p.bn_group_rows > 0) ? m0 / p.bn_group_rows : 0;
+    if (acc_stats && (grp != cur_group || (x2 && ch0 != cur_ch0))) stat_switch(grp);
     if constexpr (!BNB) {
       igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats);
       if (acc_stats) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
-        const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
-        if (grp != cur_group) bnb_switch(grp);
 #pragma unroll
         for (int k = 0; k < NPAIR; ++k)
 #pragma unroll
@@ -822,77 +901,59 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
             }
       }
     } else {
+      // BatchNorm-backward statistics (x2 only): one fragment pair at a time - its saved conv outputs y (16 bytes per pixel
+      // column) first, the gradient stores next, then the arithmetic with the pair's 24 table values; nothing of a pair
+      // outlives its iteration (the round-2 form kept four column chunks and four tables alive and went to scratch)
       long long poff[FN];
       igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
       const int g = lane >> 4;
       const bf16_t* by = reinterpret_cast<const bf16_t*>(p.bn_y);
       bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-      const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
-      if (grp != cur_group) bnb_switch(grp);
       const float* aux = p.bn_aux + (long long)grp * 4 * p.cstat;
-      // per chunk of JC pixel columns: the saved conv output y of this lane's 8 channels first (loads), the gradient stores next,
-      // the arithmetic last (JC = 4 keeps the 128 x 256 tile under its register budget)
-      constexpr int JC = FN < 4 ? FN : 4;
 #pragma unroll
-      for (int j0 = 0; j0 < FN; j0 += JC) {
-        u32x4 yr[NPAIR][JC];
+      for (int k = 0; k < NPAIR; ++k) {
+        const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+        const bool chok = ch < p.NchStore;
+        const int cc = ch & (p.cstat - 1);
+        u32x4 yr[FN];
 #pragma unroll
-        for (int k = 0; k < NPAIR; ++k) {
-          const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-#pragma unroll
-          for (int jj = 0; jj < JC; ++jj) {
-            yr[k][jj] = u32x4{0u, 0u, 0u, 0u};
-            if (poff[j0 + jj] >= 0 && ch < p.NchStore) yr[k][jj] = *reinterpret_cast<const u32x4*>(by + poff[j0 + jj] + p.obase[z] + ch);
-          }
+        for (int j = 0; j < FN; ++j) {
+          yr[j] = u32x4{0u, 0u, 0u, 0u};
+          if (poff[j] >= 0 && chok) yr[j] = *reinterpret_cast<const u32x4*>(by + poff[j] + p.obase[z] + ch);
         }
 #pragma unroll
-        for (int jj = 0; jj < JC; ++jj) {
-          const int j = j0 + jj;
-          if (poff[j] < 0) continue;
-#pragma unroll
-          for (int k = 0; k < NPAIR; ++k) {
-            const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-            if (ch >= p.NchStore) continue;
-            const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
-                                acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
-            st8(outp + poff[j] + p.obase[z] + ch, v);
-          }
+        for (int j = 0; j < FN; ++j) {
+          if (poff[j] < 0 || !chok) continue;
+          const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
+                              acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
+          st8(outp + poff[j] + p.obase[z] + ch, v);
         }
-#pragma unroll
-        for (int k = 0; k < NPAIR; ++k) {
-          const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-          if (ch >= p.NchStore) continue;
-          const int cc = ch & (p.cstat - 1);
-          float sc[8], sh[8], mu[8], is[8];
+        if (chok) {
+          float sc[8], sh[8], mu[8];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(aux + cc + 4 * h), a1 = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc + 4 * h);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h), a3 = *reinterpret_cast<const f32x4*>(aux + 3 * p.cstat + cc + 4 * h);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[4 * h + r] = a0[r]; sh[4 * h + r] = a1[r]; mu[4 * h + r] = a2[r]; is[4 * h + r] = a3[r]; }
+            for (int r = 0; r < 4; ++r) { sc[4 * h + r] = a0[r]; sh[4 * h + r] = a1[r]; mu[4 * h + r] = a2[r]; }
           }
 #pragma unroll
-          for (int jj = 0; jj < JC; ++jj) {
-            const int j = j0 + jj;
+          for (int j = 0; j < FN; ++j) {
             if (poff[j] < 0) continue;
-            float yv[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              yv[2 * r] = __uint_as_float(yr[k][jj][r] << 16);
-              yv[2 * r + 1] = __uint_as_float(yr[k][jj][r] & 0xffff0000u);
-            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+              const float yv = (c & 1) ? __uint_as_float(yr[j][c >> 1] & 0xffff0000u) : __uint_as_float(yr[j][c >> 1] << 16);
               const float v = acc[2 * k + (c >> 2)][j][c & 3];
-              const float zz = yv[c] * sc[c] + sh[c];
+              const float zz = yv * sc[c] + sh[c];
               const float gz = zz > 0.f ? v : p.bn_slope * v;
               S1[k][c] += gz;
-              S2[k][c] += gz * ((yv[c] - mu[c]) * is[c]);
+              S2[k][c] += gz * (yv - mu[c]);
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);       // keep the pairs apart: the next pair's loads must not be hoisted over this one
       }
     }
   }
-  if (acc_stats) bnb_switch(ngroups);
+  if (acc_stats) stat_switch(ngroups);
 }

@@ -139,7 +139,7 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
 
 template <int BCH, int BPIX, int NSTG, bool WS = false, int NCW = 4>
 static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
+  constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2 + 64 + 4096;     // + arrival flag and partial rows of bnstat.hpp
   constexpr int variant = BPIX == 256 ? 20 : BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
   ProfScope prof(variant, p.flops, st);
   auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true, WS, NCW> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>;
@@ -166,7 +166,7 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
 // persistent wave-specialised form: at most `cap` workgroups (what the chip holds at this tile's LDS footprint) walk the tiles
 template <int BCH, int BPIX, int NCW>
 static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2;
+  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2 + 64 + 8 * NCW * BCH;   // + arrival flag, flush counter and 2 x [NCW][2][BCH / 2] partial rows of bnstat.hpp
   constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
   ProfScope prof(variant, p.flops, st);
   auto kern = p.bn_y ? igemm_dma_persist_kernel<BCH, BPIX, true, NCW> : igemm_dma_persist_kernel<BCH, BPIX, false, NCW>;
@@ -184,6 +184,7 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   const int ntiles = (int)(grid.x * grid.y * grid.z);
   const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
   const int nwg = std::min(ntiles, cap);
+  if (q.bnj.xs) q.stat_accum = 0;                                    // exact sums by atomics: no row bookkeeping at all
   if (q.stats && !q.bn_y && q.stat_accum) {
     // accumulated rows need several tiles of ONE channel tile per workgroup and tiles inside one group (igemm.hpp)
     const int gyy = (int)grid.y;
@@ -191,11 +192,11 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
           (q.bn_group_rows == 0 || q.bn_group_rows % BPIX == 0)))
       q.stat_accum = 0;
   }
-  if (q.stats && !q.bn_y && !q.stat_accum) {
+  if (q.stats && !q.bn_y && !q.stat_accum && !q.bnj.xs) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
   }
-  if (q.bn_y || (q.stats && q.stat_accum)) {     // accumulated BatchNorm-backward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
+  if (!q.bnj.xs && q.stats && q.stat_accum) {    // accumulated forward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
     const int groups = q.bn_group_rows > 0 ? (q.M + q.bn_group_rows - 1) / q.bn_group_rows : 1;
     if (slots) *slots = groups * (nwg / (int)grid.y) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX;
   }
@@ -223,18 +224,15 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
     // persistent kernels: plain bf16 conv / dgrad launches only (their epilogue has no bias, tanh, fp32 or split-K output)
     int persist = (p.bias || p.epi || p.out_f32 || p.rows_are_phases || p.out_split_stride) ? 0 : g_igemm_persist;
-    if (p.bn_y) {
-      // BatchNorm-backward statistics ride on the persistent form only when every workgroup takes several tiles of ONE channel
-      // tile (accumulation per workgroup: ntiles >= the resident workgroups, tile counts divisible as the row ranks assume)
-      const long long t256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases, t64 = (long long)cdiv(p.M, 64) * (nch_pad / 128) * phases;
-      const int gy = nch_pad / 128;
-      auto ok = [&](long long nt, int capw) { return nt >= capw && nt % 8 == 0 && (nt / 8) % gy == 0 && (capw / 8) % gy == 0 && p.cstat == nch_pad; };
-      if (!ok(t256, 256)) persist &= ~1;
-      if (!ok(t64, 512)) persist &= ~2;
-    }
-    // forward statistics: a tile must not straddle two BatchNorm groups (groups are multiples of 8 images: 8 * OH*OW % 256 == 0);
-    // backward statistics carry their group size
-    const bool groups_ok = !p.stats || (p.bn_y ? (p.bn_group_rows == 0 || p.bn_group_rows % 256 == 0) : p.logOHW >= 5);
+    const bool x2 = p.bnj.xs != nullptr;
+    // BatchNorm-backward statistics on the persistent kernels: the exact-sum form only (bnstat.hpp); the slot-row form of the
+    // per-op entry points (jck_conv_*_bnbwd) runs on the one-tile-per-workgroup kernels
+    if (p.bn_y && !x2) persist = 0;
+    // a tile must not straddle two BatchNorm groups: slot rows - groups are multiples of 8 images (8 * OH*OW % 256 == 0), backward
+    // statistics carry their group size; exact sums - the group size in pixel rows is given either way
+    auto grp_ok = [&](int bpix) { return p.bn_group_rows == 0 || p.bn_group_rows % bpix == 0; };
+    if (x2 && !grp_ok(64)) persist &= ~2;
+    const bool groups_ok = x2 ? grp_ok(256) : (!p.stats || (p.bn_y ? (p.bn_group_rows == 0 || p.bn_group_rows % 256 == 0) : p.logOHW >= 5));
     if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0)
       return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
                            : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
@@ -253,7 +251,7 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   if (nch_pad == 64) {
     if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
       const long long t128 = (long long)cdiv(p.M, 128) * phases;
-      const bool bnb_ok = !p.bn_y || (t128 >= 512 && t128 % 8 == 0 && p.cstat == nch_pad);
+      const bool bnb_ok = p.bnj.xs ? (p.bn_group_rows == 0 || p.bn_group_rows % 128 == 0) : !p.bn_y;
       if ((g_igemm_persist & 4) && !p.act_row_elems && !p.bias && !p.epi && !p.out_f32 && !p.rows_are_phases && !p.out_split_stride && bnb_ok)
         return launch_igemm_dma_persist<64, 128, 4>(p, nch_pad, phases, st, slots);
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
@@ -304,8 +302,9 @@ extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)e
 #define IMG_GPW 8
 static int launch_img_down(const void* x, const void* w, void* out, float* stats, int* slots, int N, int Hb, int Wb, double flops,
                            hipStream_t st, const void* bn_y = nullptr, const float* bn_aux = nullptr, float bn_slope = 0.f,
-                           int bn_group_images = 0) {
+                           int bn_group_images = 0, const BnStatJob* bnj = nullptr) {
   ImgDownParams q = {};
+  if (bnj) q.bnj = *bnj;
   q.bn_y = bn_y; q.bn_aux = bn_aux; q.bn_slope = bn_slope;
   q.bn_group_groups = bn_group_images > 0 ? bn_group_images * (Hb / 2) * (Wb / 2) / 16 : 0;
   const int OH = Hb / 2, OW = Wb / 2;
@@ -336,9 +335,9 @@ static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, 
 
 static int conv_down_impl(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                           int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float bn_slope,
-                          int bn_group_images, void* stream, int fwd_group_images = 0) {
+                          int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr) {
   const int cbp = jck_pad_chan(Cb);
-  if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
+  if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_down: shapes must be powers of two (Hb,Wb,Cb) and Cs % 4 == 0");
   if ((long long)N * Hb * Wb * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_down: tensor exceeds 2^31 elements");
@@ -354,10 +353,17 @@ static int conv_down_impl(int prec, const void* big, const void* w, void* small_
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
   p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * OH * OW : 0;
   if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * OH * OW; p.stat_accum = 1; }
+  if (bnj) {                                              // exact-sum statistics (bnstat.hpp): group size for either direction
+    p.bnj = *bnj;
+    const int gi = bn_y ? bn_group_images : fwd_group_images;
+    p.bn_group_rows = gi > 0 ? gi * OH * OW : 0;
+    if (!is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
+    bn_group_images = gi;
+  }
   if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH) &&
       (bn_group_images == 0 || (bn_group_images * OH * OW) % (16 * 4 * IMG_GPW) == 0))
     return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream, bn_y, bn_aux, bn_slope,
-                           bn_group_images);
+                           bn_group_images, bnj);
   return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
@@ -381,9 +387,9 @@ extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, voi
 
 static int conv_up_impl(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                         int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float bn_slope,
-                        int bn_group_images, void* stream, int fwd_group_images = 0) {
+                        int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr) {
   const int cbp = jck_pad_chan(Cb);
-  if (bn_y && (!stats || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
+  if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_up: shapes must be powers of two (Hs,Ws,Cs>=16)");
   if ((long long)N * Hs * Ws * 4 * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_up: tensor exceeds 2^31 elements");
@@ -395,7 +401,7 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
     // 3/4-channel output: one launch, the four output parities are the 16 MFMA rows, 9 input offsets as taps; every
     // workgroup then writes whole contiguous output rows instead of interleaved 8-byte pixels
     if (Cs % 64) JCK_FAIL(JCK_E_ARG, "conv_up: Cs % 64 != 0 for a <=4-channel output");
-    if (stats) JCK_FAIL(JCK_E_ARG, "conv_up: statistics are not provided for <=4-channel outputs");
+    if (stats || bnj) JCK_FAIL(JCK_E_ARG, "conv_up: statistics are not provided for <=4-channel outputs");
     p.ntaps = 9; p.K = 9 * Cs; p.NchStore = 16; p.rows_are_phases = 1;
     for (int t = 0; t < 9; ++t) { p.dy[0][t] = (signed char)(t / 3 - 1); p.dx[0][t] = (signed char)(t % 3 - 1); }
     for (int ph = 0; ph < 2; ++ph)
@@ -423,6 +429,12 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
   p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * Hs * Ws : 0;
   if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * Hs * Ws; p.stat_accum = 1; }
+  if (bnj) {
+    p.bnj = *bnj;
+    const int gi = bn_y ? bn_group_images : fwd_group_images;
+    p.bn_group_rows = gi > 0 ? gi * Hs * Ws : 0;
+    if (!is_pow2(cbp)) JCK_FAIL(JCK_E_ARG, "conv_up: BN statistics need a power-of-two channel count");
+  }
   return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
@@ -442,8 +454,8 @@ extern "C" int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, 
   return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, bn_y, bn_aux, slope, group_images, stream);
 }
 
-extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
-                          int CiPad, int Co, void* stream) {
+static int g1_fwd_impl(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
+                       int CiPad, int Co, void* stream, const BnStatJob* bnj) {
   if (!is_pow2(CiPad) || CiPad < 64 || !is_pow2(Co) || (16 * Co) % 128 != 0)
     JCK_FAIL(JCK_E_ARG, "g1_fwd: CiPad must be a power of two >= 64, Co a power of two");
   IgemmParams p = {};
@@ -455,7 +467,84 @@ extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, flo
   p.cstat = Co; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
   if (Co < 128) JCK_FAIL(JCK_E_ARG, "g1_fwd: Co must be >= 128");
   p.flops = 2.0 * B * 16.0 * Co * CiPad;
+  if (bnj) p.bnj = *bnj;
   return launch_igemm(prec, p, 16 * Co, 1, 1, (hipStream_t)stream, stats_slots);
+}
+extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
+                          int CiPad, int Co, void* stream) {
+  return g1_fwd_impl(prec, z, w, out, stats, stats_slots, B, CiPad, Co, stream, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// statistics produced and finalised by the launch itself (bnstat.hpp)
+// ---------------------------------------------------------------------------------------------------------
+static int bnx_reps(int C) { return std::max(1, std::min(4, 256 / std::max(1, C))); }      // <= 4 (bnstat.hpp: xsum_read)
+extern "C" size_t jck_bnx_bytes(int C, int groups) {
+  return 64 + (size_t)bnx_reps(C) * (size_t)std::max(1, groups) * 2 * 3 * (size_t)C * 8;     // flags + [reps][groups][2][3 limbs][C] u64
+}
+// mode 0: a producer launch (accumulates only); 1 / 2: the forward / backward consumer.  count = rows per group
+static int make_bnj(const jck_bn_job* j, int C, float count, int mode, BnStatJob* out) {
+  if (!j || !j->xbuf) JCK_FAIL(JCK_E_ARG, "bn job: NULL job / xbuf");
+  if (j->groups < 1 || !is_pow2(C) || C < 8) JCK_FAIL(JCK_E_ARG, "bn job: groups >= 1 and a power-of-two channel count >= 8");
+  if (((uintptr_t)j->xbuf) % 16) JCK_FAIL(JCK_E_ARG, "bn job: xbuf must be 16-byte aligned");
+  BnStatJob b = {};
+  b.flags = reinterpret_cast<unsigned*>(j->xbuf);
+  b.xs = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(j->xbuf) + 64);
+  b.reps = bnx_reps(C); b.groups = j->groups; b.C = C; b.mode = mode; b.count = count;
+  if (mode == 0) {            // producer: accumulates only
+  } else if (mode == 1) {
+    if (!j->gamma || !j->beta || !j->aux) JCK_FAIL(JCK_E_ARG, "bn job (forward): gamma, beta and aux are required");
+    if (j->groups > 1 && j->running_mean) JCK_FAIL(JCK_E_ARG, "bn job (forward): in-place running statistics need groups == 1");
+    b.gamma = j->gamma; b.beta = j->beta; b.eps = j->eps; b.momentum = j->momentum; b.aux = j->aux; b.rec = j->rec;
+    b.running_mean = j->running_mean; b.running_var = j->running_var; b.nbt = (long long*)j->num_batches_tracked;
+  } else {
+    if (!j->aux || !j->sums || j->sums_stride < 2 * C) JCK_FAIL(JCK_E_ARG, "bn job (backward): aux, sums and sums_stride >= 2C are required");
+    b.aux = j->aux; b.sums = j->sums; b.sums_stride = j->sums_stride; b.dgamma = j->dgamma; b.dbeta = j->dbeta;
+    b.grad_groups = j->grad_groups;
+  }
+  *out = b;
+  return JCK_OK;
+}
+extern "C" int jck_conv_down_x(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
+                               const jck_bn_job* job, void* stream) {
+  if (!job || job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_down_x: N must be groups * group_images");
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, Cs, (float)((long long)job->group_images * (Hb / 2) * (Wb / 2)), 0, &b));
+  return conv_down_impl(prec, big, w, small_out, nullptr, nullptr, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, job->group_images, &b);
+}
+extern "C" int jck_conv_up_x(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
+                             const jck_bn_job* job, void* stream) {
+  if (!job || job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_up_x: N must be groups * group_images");
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, jck_pad_chan(Cb), (float)((long long)job->group_images * 4 * Hs * Ws), 0, &b));
+  return conv_up_impl(prec, small_in, w, big_out, nullptr, nullptr, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, job->group_images, &b);
+}
+extern "C" int jck_g1_fwd_x(int prec, const void* z, const void* w, void* out, int B, int CiPad, int Co, const jck_bn_job* job, void* stream) {
+  if (!job || job->groups != 1) JCK_FAIL(JCK_E_ARG, "g1_fwd_x: one BatchNorm group");
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, Co, (float)((long long)B * 16), 0, &b));
+  return g1_fwd_impl(prec, z, w, out, nullptr, nullptr, B, CiPad, Co, stream, &b);
+}
+extern "C" int jck_conv_up_bnx(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
+                               const jck_bn_job* job, void* stream) {
+  if (!job || !job->bn_y) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: bn_y is NULL");
+  if (job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: N must be groups * group_images");
+  if (jck_pad_chan(Cb) == 4) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: not available for <=4-channel outputs");
+  BnStatJob b;
+  if (!job->aux) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: aux (the forward table of the normalised layer) is NULL");
+  JCK_TRY(make_bnj(job, jck_pad_chan(Cb), (float)((long long)job->group_images * 4 * Hs * Ws), 0, &b));
+  return conv_up_impl(prec, small_in, w, big_out, nullptr, nullptr, 0, N, Hs, Ws, Cs, Cb, job->bn_y, job->aux, job->slope,
+                      job->group_images, stream, 0, &b);
+}
+extern "C" int jck_conv_down_bnx(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
+                                 const jck_bn_job* job, void* stream) {
+  if (!job || !job->bn_y) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: bn_y is NULL");
+  if (job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: N must be groups * group_images");
+  BnStatJob b;
+  if (!job->aux) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: aux (the forward table of the normalised layer) is NULL");
+  JCK_TRY(make_bnj(job, Cs, (float)((long long)job->group_images * (Hb / 2) * (Wb / 2)), 0, &b));
+  return conv_down_impl(prec, big, w, small_out, nullptr, nullptr, N, Hb, Wb, Cb, Cs, job->bn_y, job->aux, job->slope,
+                        job->group_images, stream, 0, &b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -832,6 +921,63 @@ extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
                                       gstride));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// The reduction pass of the BatchNorm backward in the exact-sum form (bnstat.hpp): one launch leaves s1 | s2, dgamma, dbeta -
+// for a layer whose incoming gradient was not produced by a dgrad launch of this library (the top layer of a stack)
+extern "C" int jck_bn_bwd_reduce_x(int prec, const void* g_a, const void* y, long long rows_per_group, int C, const jck_bn_job* job,
+                                   void* stream) {
+  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: C must be a power of two in [8, 2048]");
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 0, &b));
+  if (!job->aux) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: aux (the forward table of the layer) is NULL");
+  b.aux = job->aux;
+  const int rstep = 256 / (C / 8);
+  if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: C too large");
+  const int blocks = bn_bwd_blocks(rows_per_group, rstep, b.groups);
+  if (g_bn_unr >= 2) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(blocks, b.groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, (const float*)b.aux, job->slope, (float*)nullptr, rows_per_group, C, 0ll, b)); }
+  else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks, b.groups), dim3(256), 2 * C * rstep * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, (const float*)b.aux, job->slope, (float*)nullptr, rows_per_group, C, 0ll, b)); }
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+// consumers of the exact sums: the kernel's prologue finalises (ew.hpp), workgroup 0 of a group leaves the tables
+// one round of resident workgroups (8 x 256 threads per CU): every workgroup pays the prologue, so none queues behind another's
+static unsigned x_grid(long long total8, int groups) {
+  return (unsigned)std::max<long long>(1, std::min<long long>((total8 + 511) / 512, 2048 / std::max(1, groups)));
+}
+extern "C" int jck_bn_act_fwd_x(int prec, const void* y, float slope, void* a, long long rows_per_group, int C, const jck_bn_job* job,
+                                void* stream) {
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 1, &b));
+  const long long total8 = rows_per_group * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_x_kernel<T>, dim3(x_grid(total8, b.groups), b.groups), dim3(256), 2 * C * sizeof(float),
+                                      (hipStream_t)stream, (const T*)y, b, slope, (T*)a, total8));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+extern "C" int jck_bn_bwd_apply_x(int prec, const void* g_a, const void* y, void* g_y, long long rows_per_group, int C,
+                                  const jck_bn_job* job, void* stream) {
+  BnStatJob b;
+  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 2, &b));
+  const long long total8 = rows_per_group * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_x_kernel<T>, dim3(x_grid(total8, b.groups), b.groups), dim3(256), 6 * C * sizeof(float),
+                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, b, job->slope, 1.0f / (float)rows_per_group, (T*)g_y,
+                                      total8));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+// g_y = scale * (g_z - s1/n - xhat * s2/n) per group from the s1 | s2 rows (g_y may alias g_a)
+extern "C" int jck_bn_bwd_apply(int prec, const void* g_a, const void* y, const float* aux, const float* sums, long long sums_stride,
+                                float slope, void* g_y, long long rows_per_group, int C, int groups, void* stream) {
+  if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_apply: bad shape");
+  const long long total8 = rows_per_group * C / 8;
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
+                                      sums_stride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

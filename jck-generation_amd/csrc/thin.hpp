@@ -12,6 +12,7 @@
 // fp32 parity path keeps the generic kernel.  Same k order as the tile kernel, so the products are bitwise the same.
 #pragma once
 #include "common.hpp"
+#include "bnstat.hpp"
 
 struct ImgDownParams {
   const void* x;        // [N, H, W, 4] bf16
@@ -27,6 +28,7 @@ struct ImgDownParams {
   const float* bn_aux;
   float bn_slope;
   int bn_group_groups;       // 16-pixel groups per BatchNorm group (0: one group)
+  BnStatJob bnj;             // exact sums by atomics instead of the stats rows (bnstat.hpp): forward, or - with bn_y - backward
 };
 
 template <int GPW>
@@ -104,7 +106,7 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
         const float zz = yv[k] * aux[c] + aux[64 + c];
         const float gz = zz > 0.f ? v : p.bn_slope * v;
         ssum[k] += gz;
-        ssq[k] += gz * ((yv[k] - aux[128 + c]) * aux[192 + c]);
+        ssq[k] += p.bnj.xs ? gz * (yv[k] - aux[128 + c]) : gz * ((yv[k] - aux[128 + c]) * aux[192 + c]);
       }
     } else {
 #pragma unroll
@@ -123,7 +125,7 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
       *reinterpret_cast<u32x4*>(d + 32) = o1;
     }
   }
-  if (!p.stats) return;
+  if (!p.stats && !p.bnj.xs) return;
 #pragma unroll
   for (int k = 0; k < 16; ++k) { ssum[k] = row16_sum(ssum[k]); ssq[k] = row16_sum(ssq[k]); }
   if (pcol == 0) {
@@ -134,9 +136,15 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
     }
   }
   __syncthreads();
-  if (threadIdx.x < 128)
-    p.stats[(long long)blockIdx.x * 128 + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 128) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (p.bnj.xs) {     // a workgroup's 4 * GPW groups lie in one BatchNorm group (launcher)
+      const int grp = p.bn_group_groups > 0 ? (int)(blockIdx.x * 4 * GPW) / p.bn_group_groups : 0;
+      xsum_add(p.bnj, (int)(blockIdx.x % (unsigned)p.bnj.reps), grp, threadIdx.x >> 6, threadIdx.x & 63, t);
+    } else {
+      p.stats[(long long)blockIdx.x * 128 + threadIdx.x] = t;
+    }
+  }
 }
 
 struct ImgUpParams {

@@ -17,6 +17,13 @@ class StepInputs(C.Structure):
                 ("real_u8", vp), ("real_idx", vp)]
 
 
+class BnJob(C.Structure):
+    """jck_bn_job (include/jckgan.h): statistics produced and finalised by the launch that writes the tensor."""
+    _fields_ = [("xbuf", vp), ("groups", i32), ("group_images", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("momentum", f32),
+                ("aux", vp), ("rec", vp), ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
+                ("bn_y", vp), ("slope", f32), ("sums", vp), ("sums_stride", i64), ("dgamma", vp), ("dbeta", vp), ("grad_groups", i32)]
+
+
 # name -> (restype, argtypes)      (keep in sync with include/jckgan.h; tests/test_abi.py checks the symbol list)
 PROTOS = {
     "jck_last_error": (C.c_char_p, []),
@@ -48,6 +55,16 @@ PROTOS = {
     "jck_conv_down_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
     "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "jck_bnx_bytes": (sz, [i32, i32]),
+    "jck_conv_down_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
+    "jck_conv_up_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
+    "jck_g1_fwd_x": (i32, [i32, vp, vp, vp, i32, i32, i32, C.POINTER(BnJob), vp]),
+    "jck_conv_up_bnx": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
+    "jck_conv_down_bnx": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
+    "jck_bn_bwd_reduce_x": (i32, [i32, vp, vp, i64, i32, C.POINTER(BnJob), vp]),
+    "jck_bn_act_fwd_x": (i32, [i32, vp, f32, vp, i64, i32, C.POINTER(BnJob), vp]),
+    "jck_bn_bwd_apply_x": (i32, [i32, vp, vp, vp, i64, i32, C.POINTER(BnJob), vp]),
+    "jck_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, i64, f32, vp, i64, i32, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_resize_norm": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp]),
     "jck_img_prep_u8": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
