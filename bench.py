@@ -175,22 +175,79 @@ def measure(a, model, world, rank, dev, dist):
     # CGAN: 10-class synthetic labels as one-hot int64 [B,100] (classes 0-9 of the reference's 100-wide encoding)
     labels = [torch.nn.functional.one_hot(torch.randint(0, 10, (B,), device=dev, generator=gen), 100).to(torch.int64)
               for _ in range(4)] if cgan else None
-    red = GradReducer(world) if world > 1 else None
+    # JCK_BENCH_FORCE_DDP=1 (test hook, tests/test_bench_multirank_gpu.py): the data-parallel control flow with ONE rank over a
+    # real RCCL communicator - everything of the N > 1 path except a second device
+    force_ddp = world == 1 and os.environ.get("JCK_BENCH_FORCE_DDP") == "1" and dist is not None
+    red = GradReducer(world, force=force_ddp) if (world > 1 or force_ddp) else None
+    overlap = {"on": os.environ.get("JCK_BENCH_DDP_OVERLAP", "1") != "0"}      # D split + D(real) prefetch
+    exposed = {"d": [], "g": [], "on": False}
+
+    def reducer(tag):
+        """red.start whose wait is bracketed by HIP events while `exposed` is on: the time the compute stream is blocked before
+        Adam(D) / Adam(G) = the part of the all-reduce that no compute hid."""
+        def start(flat, **kw_):
+            w = red.start(flat, **kw_)
+            if w is None or not exposed["on"]:
+                return w
+
+            def wait():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w()
+                e1.record()
+                exposed[tag].append((e0, e1))
+            return wait
+        return start
 
     count = [0]
+    use_red = {"on": True}
 
     def one_step(_i):
         # device-side RNG inside the step like the reference: noise=None draws n1 | z | n2, alpha (and the dropout masks)
         i = count[0]
         count[0] += 1
         kw = {}
-        if red:     # data parallel: SUM all-reduce of both gradient arenas; the next batch is announced so that the forward half
-            #         of its D(real) pass runs under G's all-reduce
-            kw = dict(reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world, next_real=None if cgan else batches[(i + 1) % 4])
+        if red and use_red["on"]:
+            # data parallel: SUM all-reduce of both gradient arenas; the next batch is announced so that the forward half
+            # of its D(real) pass runs under G's all-reduce (DESIGN.md section 6)
+            kw = dict(reduce_d=reducer("d"), reduce_g=reducer("g"), grad_scale=1.0 / world,
+                      next_real=None if (cgan or not overlap["on"]) else batches[(i + 1) % 4])
         eng.step_async(batches[i % 4], None, 2e-4, generator=gen, labels=labels[i % 4] if cgan else None, **kw)
 
+    def replicas_in_sync():
+        """every rank holds the same parameters (the all-reduced gradients went through the same Adam): max == min of a checksum"""
+        if not dist or world == 1:
+            return True
+        torch.cuda.synchronize()
+        c = torch.stack([eng.arenas["d_params"].double().sum(), eng.arenas["g_params"].double().sum(),
+                         eng.arenas["d_params"].double().abs().sum(), eng.arenas["g_params"].double().abs().sum()])
+        hi, lo = c.clone(), c.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        return bool(torch.equal(hi, lo))
+
+    ddp = {}
+    if not overlap["on"]:
+        os.environ["JCK_DDP_SPLIT"] = "0"
     for i in range(a.warmup):
         one_step(i)
+    torch.cuda.synchronize()
+    if red:
+        ddp["mode"] = ("D all-reduce in two pieces under D's own backward + G all-reduce under the next batch's D(real) forward"
+                       if overlap["on"] and not cgan else "one all-reduce per network, waited for before its Adam")
+        ddp["replicas_in_sync_after_warmup"] = replicas_in_sync()
+        if not ddp["replicas_in_sync_after_warmup"] and overlap["on"]:
+            # the overlapped schedule has only ever run against one device (tests): if the first multi-device run disagrees,
+            # measure the plain schedule instead of a wrong one - and say so
+            overlap["on"] = False
+            os.environ["JCK_DDP_SPLIT"] = "0"
+            for key in ("g_params", "d_params", "g_m", "g_v", "d_m", "d_v"):
+                dist.broadcast(eng.arenas[key], src=0)
+            eng.mark_weights_changed()
+            for i in range(max(2, a.warmup)):
+                one_step(i)
+            ddp["mode"] = "one all-reduce per network, waited for before its Adam (overlapped schedule failed the replica check)"
+            ddp["replicas_in_sync_after_fallback"] = replicas_in_sync()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -221,6 +278,41 @@ def measure(a, model, world, rank, dev, dist):
            "losses_last_step": {k: round(v, 5) for k, v in scal.items() if k in ("loss_d", "loss_g", "gp")},
            "step_mfma": {"flops_per_step": fl, "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                          "frac_of_peak": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}}
+    if red:
+        # what the collectives cost (every rank runs these legs; after the timed region, which stays exactly K steps):
+        #   comm_exposed_ms   HIP events around the waits in front of Adam(D) / Adam(G), mean over 5 steps and max over ranks
+        #   n1_equivalent_ms  the same step with the reducers off (what one GPU of this node does alone); DESIGN.md section 6's
+        #                     efficiency estimate is n1_equivalent_ms / ms_per_step
+        exposed["on"] = True
+        for i in range(5):
+            one_step(i)
+        torch.cuda.synchronize()
+        exposed["on"] = False
+        ce = torch.tensor([sum(e0.elapsed_time(e1) for e0, e1 in exposed[t]) / 5.0 for t in ("d", "g")], device=dev, dtype=torch.float64)
+        if dist and world > 1:
+            dist.all_reduce(ce, op=dist.ReduceOp.MAX)
+        ddp["comm_exposed_ms"] = {"d": round(float(ce[0]), 4), "g": round(float(ce[1]), 4)}
+        ddp["replicas_in_sync_at_end"] = replicas_in_sync()
+        use_red["on"] = False
+        for i in range(2):
+            one_step(i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(10):
+            one_step(i)
+        torch.cuda.synchronize()
+        tn1 = torch.tensor([(time.perf_counter() - t1) / 10 * 1e3], device=dev, dtype=torch.float64)
+        if dist and world > 1:
+            dist.all_reduce(tn1, op=dist.ReduceOp.MAX)
+        use_red["on"] = True
+        ddp["n1_equivalent_ms"] = round(float(tn1[0]), 4)
+        ddp["rccl_world"] = dist.get_world_size() if dist else 1
+        ddp["backend"] = dist.get_backend() if dist else None
+        ddp["message_bytes"] = {"d": int(eng.arenas["d_grads"].numel()) * 4, "g": int(eng.arenas["g_grads"].numel()) * 4}
+        res["ddp"] = ddp
     if not a.no_roofline:
         # every rank runs the three extra steps (they contain the gradient all-reduce); rank 0 times its launches with HIP
         # events on the launch streams - which needs every launch to come from the host, so these steps are not replayed
@@ -291,9 +383,10 @@ def main():
     backend = os.environ.get("JCK_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("JCK_BENCH_FORCE_DDP") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:

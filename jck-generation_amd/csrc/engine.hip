@@ -173,7 +173,9 @@ struct jck_engine {
   float* hp2;                           // [2 parities][8]: {step_size, bc2_sqrt, -, -, noise seed lo, hi, step, 0} of the step in flight (jck_engine_set_step)
   unsigned long long noise_seed = 0x6a636b67616e0001ull;      // in-kernel instance noise (jck_engine_set_noise_seed)
   float *rz[2] = {nullptr, nullptr}, *ralpha[2] = {nullptr, nullptr}, *rmask[2] = {nullptr, nullptr};
-  int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases)
+  int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases) ...
+  float hp_lr[2] = {-1.f, -1.f};        // ... and at which learning rate they were computed (a scheduler may change it between steps)
+  bool hp_holds(int step, float lr) const { return hp_step[step & 1] == step && hp_lr[step & 1] == lr; }
   bool capturing = false;
   float* g1_ws = nullptr; size_t g1_ws_bytes = 0;
   float* wg_ws; size_t wg_ws_bytes;
@@ -1034,7 +1036,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->parity = in->step & 1;
   if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL || phase == JCK_PHASE_D_LOSS_A) e->bucket_ready = false;
   // eager callers that did not call jck_engine_set_step: the step's scalars / Philox words are written by its first phase
-  if (e->hp_step[e->parity] != in->step && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+  if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
@@ -1046,9 +1048,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
   static const bool cgan_side = getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) != 0;
   // Under a stream capture everything stays on the capturing stream: a hipGraph with parallel branches makes the ROCm 7.2
-  // runtime keep per-graph side streams (hip::Graph::UpdateStreams), which costs ~7 us of host time per node at launch, ran
-  // slower than the linear graph for CGAN, and crashed inside hipGraphLaunch after a few dozen such graphs had been
-  // instantiated in one process.  Same kernels, same order per stream as the eager schedule - bitwise the same results.
+  // runtime keep per-graph side streams, costs ~7 us of host time per node at launch, ran slower than the linear graph for
+  // CGAN, and its hipGraphLaunch reads past the end of the graph's stream pool whenever two of those streams share the launch
+  // stream's hardware queue (hip::Graph::UpdateStreams; cause and frame in DESIGN.md section 5.6; jck_engine_capture_end refuses
+  // any non-linear graph).  Same kernels, same order per stream as the eager schedule - bitwise the same results.
   const bool par = e->overlap && !e->capturing;
   hipStream_t sA = (par && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
   const bool ov_g = par, ov_gp = par && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
@@ -1247,7 +1250,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_D_STEP: {                                                                      // :180
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
-      if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));   // (eager callers)
+      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));   // (eager callers)
       JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       return jck_engine_repack(e, 1, st);
     }
@@ -1261,7 +1264,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       return JCK_OK;
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
-      if (e->hp_step[e->parity] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
       JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
       {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
@@ -1295,6 +1298,7 @@ extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stre
   JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream, e->rz[q], (long long)e->B * 100,
                             e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f));
   e->hp_step[step & 1] = step;
+  e->hp_lr[step & 1] = lr;
   return JCK_OK;
 }
 // Seed of the in-kernel instance noise (steps whose jck_step_inputs carry no noise tensors draw 0.1*N(0,1) inside the image
@@ -1303,6 +1307,7 @@ extern "C" int jck_engine_set_noise_seed(jck_engine* e, unsigned long long seed)
   if (!e) JCK_FAIL(JCK_E_ARG, "null engine");
   e->noise_seed = seed;
   e->hp_step[0] = e->hp_step[1] = 0;      // the next step rewrites the device copy
+  e->hp_lr[0] = e->hp_lr[1] = -1.f;
   return JCK_OK;
 }
 
@@ -1326,6 +1331,31 @@ extern "C" int jck_engine_capture_end(jck_engine* e, void* stream, void** graph_
   e->capturing = false;
   hipGraph_t g = nullptr;
   HIPCHK(hipStreamEndCapture((hipStream_t)stream, &g));
+  // Only LINEAR graphs are instantiated (every node at most one successor, one root).  ROCm 7.2's hip::GraphExec creates
+  // max_streams_ internal streams for a graph with parallel branches and hip::Graph::UpdateStreams (called by every
+  // hipGraphLaunch of such a graph) skips each of them that shares the launch stream's HARDWARE queue - with no bound on the
+  // index: when two or more of the internal streams sit on the launch stream's queue (streams are dealt onto a small pool of
+  // hardware queues, so this depends on every stream the process ever created) it reads past the end of the vector and
+  // dereferences garbage - the SIGSEGV of round 2.  A graph whose width is 1 never enters that code.
+  {
+    size_t nn = 0, ne = 0;
+    hipError_t q = hipGraphGetNodes(g, nullptr, &nn);
+    if (q == hipSuccess) q = hipGraphGetEdges(g, nullptr, nullptr, &ne);
+    bool linear = q == hipSuccess && nn > 0 && ne == nn - 1;
+    if (linear && ne > 0) {
+      std::vector<hipGraphNode_t> from(ne), to(ne);
+      q = hipGraphGetEdges(g, from.data(), to.data(), &ne);
+      linear = q == hipSuccess;
+      for (size_t i = 0; linear && i < ne; ++i)
+        for (size_t k = i + 1; k < ne; ++k)
+          if (from[i] == from[k] || to[i] == to[k]) { linear = false; break; }       // a fork or a join
+    }
+    if (!linear) {
+      (void)hipGraphDestroy(g);
+      JCK_FAIL(JCK_E_ARG, "captured graph has parallel branches (" + std::to_string(nn) + " nodes, " + std::to_string(ne) +
+                              " edges): not instantiated on this runtime - see DESIGN.md section 5.6");
+    }
+  }
   hipGraphExec_t ge = nullptr;
   hipError_t rc = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
@@ -1348,6 +1378,15 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
       *pp = nullptr;
       HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
     }
+    // ... and so may the events recorded inside it
+    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
+    for (auto p : ev) {
+      if (*p) (void)hipEventDestroy(*p);
+      *p = nullptr;
+      HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
+    }
+    e->bucket_ready = false; e->gp_inflight = false;
     (void)hipGetLastError();
   }
   return JCK_OK;

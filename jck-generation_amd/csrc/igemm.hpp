@@ -67,6 +67,7 @@ struct IgemmParams {
   // bnj.xs != nullptr switches every statistics path of this file to it (forward: bnj.mode 1; with bn_y: mode 2, the second
   // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
   BnStatJob bnj;
+  int dma_buf;            // persistent kernels: issue the LDS-DMA as buffer loads (descriptor + 32-bit offset) instead of global loads
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -493,13 +494,18 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int nk = p.K / IG_BK;
   // k-steps past the end re-load the last tile into a stage nobody reads: no predicate, no branch, exact vmcnt arithmetic
+  // p.dma_buf: buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see igemm_dma_persist_kernel
+  const auto rs_a = make_rsrc(p.act, p.act_bytes);
+  const auto rs_wt = make_rsrc(p.w, p.w_bytes);
+  const bool dbuf = p.dma_buf != 0;
   auto issue = [&](int kc, int stage) {
     const int kbase = min(kc, nk - 1) * IG_BK;
     unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);     // this wave's 8 rows of each 32-row pass
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps) {
-      const unsigned char* src = wb + (wrowoff[ps] + (unsigned)kbase * 2u + src_chunk);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
+      const unsigned off = wrowoff[ps] + (unsigned)kbase * 2u + src_chunk;
+      if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16, (int)off, 0, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t)(wb + off), (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
     }
     const int t = __builtin_amdgcn_readfirstlane(p.act_row_elems ? 0 : (kbase >> p.logC));
     const int tp = p.tap[z][t];
@@ -509,8 +515,13 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
 #pragma unroll
     for (int ps = 0; ps < C::APASS; ++ps) {
       const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
-      const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+      if (dbuf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
+                                                 (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
+      } else {
+        const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+      }
     }
   };
 
@@ -720,13 +731,20 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page);
+    // p.dma_buf: the same pieces as buffer loads - a wave-uniform descriptor in SGPRs plus ONE 32-bit offset VGPR per lane
+    // (instead of a 64-bit address pair); an offset past the descriptor's size (JCK_OOB) returns zeros, which replaces the
+    // zero page for out-of-image taps and rows past M
+    const auto rs_a = make_rsrc(p.act, p.act_bytes);
+    const auto rs_wt = make_rsrc(p.w, p.w_bytes);
+    const bool dbuf = p.dma_buf != 0;
     auto issue = [&](int kc, int stage) {
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
 #pragma unroll
       for (int ps = 0; ps < C::WPASS; ++ps) {
-        const unsigned char* src = wb + (wrowoff[ps] + (unsigned)kbase * 2u + src_chunk);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
+        const unsigned off = wrowoff[ps] + (unsigned)kbase * 2u + src_chunk;
+        if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16, (int)off, 0, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(wb + off), (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
       }
       const int t = __builtin_amdgcn_readfirstlane(kbase >> p.logC);
       const int tp = p.tap[z][t];
@@ -735,8 +753,13 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
-        const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+        if (dbuf) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
+                                                   (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
+        } else {
+          const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
+        }
       }
     };
     // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads

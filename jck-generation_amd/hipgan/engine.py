@@ -139,6 +139,8 @@ class DcganEngine:
         lib.jck_engine_bind(h, self.workspace, self.ws_bytes, a["g_params"], a["g_grads"], a["g_m"], a["g_v"], a["g_bn"],
                             a["g_nbt"], a["d_params"], a["d_grads"], a["d_m"], a["d_v"], a["d_bn"], a["d_nbt"])
         self.layout = {"g": _layout(h, 0), "d": _layout(h, 1)}
+        # the step's own draws (Philox: z, alpha, instance noise, dropout masks) follow torch's seed unless the caller sets one
+        self.set_noise_seed(int(torch.initial_seed()) + 0x6a636b67)
         # BN running_var starts at 1 (nn.BatchNorm2d)
         for tag in ("g", "d"):
             for name, kind, off, numel, shp in self.layout[tag]:
@@ -433,6 +435,7 @@ class DcganEngine:
             if gs is not None:
                 est.wait_stream(gs)
             real_s, nz = self._fill_static(real, noise, generator, labels)
+            self._fallback_inputs = (real_s, nz)        # an eager retry must not draw a second time
             # The caller's tensors were read by copies on THIS stream: the caller's stream waits for those copies, so memory
             # it frees and reuses afterwards cannot be overwritten under them.  (Tensor.record_stream would do the same, but
             # the caching allocator then records an event on this stream whenever such a tensor is freed - also in the
@@ -532,12 +535,16 @@ class DcganEngine:
             use_graph = False                       # D(real)'s forward of this step is already enqueued
         if use_graph:
             try:
+                self._fallback_inputs = None
                 return self._step_graph(real, noise, lr, reduce_d, reduce_g, grad_scale, generator, labels)
             except _GraphUnavailable as e:
                 import warnings
                 warnings.warn(f"hipGraph replay disabled for this engine ({e}); running the step eagerly")
                 self.graphs = False
                 torch.cuda.current_stream().wait_stream(self._e_stream())
+                if self._fallback_inputs is not None:      # this step's inputs are already drawn / copied into the static buffers
+                    real, noise = self._fallback_inputs
+                    self._fallback_inputs = None
         self._eager_steps += 1
         noise = noise if noise is not None else self.draw_noise(generator, labels=labels, fast=self.fast_noise)
         si, keep = self._inputs(real, noise, lr, grad_scale)

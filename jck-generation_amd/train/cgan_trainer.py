@@ -61,7 +61,9 @@ class CGANTrainer(DCGANTrainer):
             from change_randomseed import RANDOMSEED
             self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
             self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
-            self.engine.set_noise_seed(RANDOMSEED + 1 + self.rank)
+        from change_randomseed import RANDOMSEED as _SEED     # one GPU too: the seed governs the step's own draws (see DCGANTrainer)
+        self._noise_seed = (int(torch.initial_seed()) ^ (_SEED << 20)) + 1 + self.rank
+        self.engine.set_noise_seed(self._noise_seed)
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.criterion = nn.BCELoss()
@@ -74,9 +76,7 @@ class CGANTrainer(DCGANTrainer):
             return self.engine
         if b not in self._tail_engines:
             self._tail_engines[b] = CganEngine(batch=b, share=self.engine)
-            if self.world > 1:
-                from change_randomseed import RANDOMSEED
-                self._tail_engines[b].set_noise_seed(RANDOMSEED + 1 + self.rank)
+            self._tail_engines[b].set_noise_seed(self._noise_seed)
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------

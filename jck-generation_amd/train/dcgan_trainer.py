@@ -136,7 +136,12 @@ class DCGANTrainer(Trainer):
             from change_randomseed import RANDOMSEED
             self.noise_gen = torch.Generator(device=self.device).manual_seed(RANDOMSEED + 1 + self.rank)
             self.host_gen = torch.Generator().manual_seed(RANDOMSEED + 1 + self.rank)
-            self.engine.set_noise_seed(RANDOMSEED + 1 + self.rank)       # the in-kernel instance noise, per rank too
+        # The step's own draws (z, alpha, instance noise, CGAN's dropout masks: Philox keyed by this seed and the step) follow the
+        # run's seed on ONE GPU too: in the reference change_randomseed.RANDOMSEED / torch.manual_seed govern all of it
+        # (main.py:31-37), so a different seed must give a different noise sequence here as well.
+        from change_randomseed import RANDOMSEED as _SEED
+        self._noise_seed = (int(torch.initial_seed()) ^ (_SEED << 20)) + 1 + self.rank
+        self.engine.set_noise_seed(self._noise_seed)
 
         self.optimizer_g = EngineAdam(self.engine, "g", self.model_g.named_parameters(), self.max_lr, betas=[0.5, 0.999])
         self.optimizer_d = EngineAdam(self.engine, "d", self.model_d.named_parameters(), self.max_lr, betas=[0.5, 0.999])
@@ -161,9 +166,7 @@ class DCGANTrainer(Trainer):
             return self.engine
         if b not in self._tail_engines:
             self._tail_engines[b] = DcganEngine(batch=b, share=self.engine)
-            if self.world > 1:
-                from change_randomseed import RANDOMSEED
-                self._tail_engines[b].set_noise_seed(RANDOMSEED + 1 + self.rank)
+            self._tail_engines[b].set_noise_seed(self._noise_seed)
         return self._tail_engines[b]
 
     # ------------------------------------------------------------------------------------------------------

@@ -29,6 +29,30 @@ def test_two_rank_bench_terminates_and_reports_whole_job_rate():
     # at batch 16 the dominant kernel runs at a fraction of a TFLOP/s: frac (4 decimals) may round to 0
     assert out["roofline"]["bound"] == "mfma" and out["roofline"]["achieved"] > 0 and 0 <= out["roofline"]["frac"] < 1
     assert "cpu_baseline" not in out                              # N = 1 only
+    d = out["ddp"]                                                # what the first real multi-GPU run is read by
+    assert d["rccl_world"] == 2 and d["replicas_in_sync_after_warmup"] and d["replicas_in_sync_at_end"], d
+    assert "comm_exposed_ms" in d and d["n1_equivalent_ms"] > 0
     for k in ("loss_d", "loss_g", "gp"):
         v = out["losses_last_step"][k]
         assert v == v and abs(v) < 1e3
+
+
+def test_one_rank_rccl_bench_reports_the_data_parallel_keys():
+    """The nccl branch of bench.py with ONE rank (JCK_BENCH_FORCE_DDP=1): a real RCCL communicator, the overlapped schedule
+    (D's all-reduce in two pieces, G's under the next batch's D(real) forward), and the keys the first multi-GPU run will be
+    read by - rccl_world, comm_exposed_ms (HIP events around the waits in front of Adam(D) / Adam(G)), n1_equivalent_ms (the same
+    step with the reducers off; DESIGN.md section 6's efficiency estimate is n1_equivalent_ms / ms_per_step)."""
+    env = dict(os.environ, JCK_BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--batch", "16",
+           "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = out["ddp"]
+    assert d["rccl_world"] == 1 and d["backend"] == "nccl"
+    assert d["replicas_in_sync_after_warmup"] and d["replicas_in_sync_at_end"]
+    assert d["comm_exposed_ms"]["d"] >= 0 and d["comm_exposed_ms"]["g"] >= 0
+    assert 0 < d["n1_equivalent_ms"] < 50 and d["message_bytes"]["d"] > 1e7 and d["message_bytes"]["g"] > 1e7
+    assert "two pieces" in d["mode"]

@@ -1,11 +1,15 @@
-"""The bf16 fast path (the one bench.py times) held to MEASURED error, not to a guessed tolerance.
+"""The bf16 fast path (the one bench.py times) held to the ORACLE, not to numbers recorded from itself.
 
-* per step: every gradient tensor and logged scalar of one teacher-forced step is within 2x the distance recorded in
-  tests/golden/bf16_error_table.json (made on a MI355X by tests/golden/make_bf16_error_table.py; table in
-  profiles/r02_bf16_error_table.md) - against the fp32 oracle (pinned to the reference) AND against the oracle with bf16
-  storage emulation (oracle/bf16_emu.py), which removes the storage format from the comparison;
-* envelope: the distance hip <-> fp32 oracle is explained by bf16 storage: it stays within 2x the distance emulation <->
-  fp32 oracle measured in the same test, per tensor and along a 30-step free-running trajectory;
+* per step (teacher-forced, identical state): three runs - hip (engine, bf16), ref (fp32 CPU oracle, pinned to the reference)
+  and emu (the same oracle with a rounding to bf16 wherever the HIP path stores bf16, oracle/bf16_emu.py).  Gated:
+    - hip vs emu, per gradient tensor (relative L2) and per logged scalar: stated limits below.  With the storage format
+      matched, what is left is summation order amplified by bf16 rounding-boundary flips (a 1e-6 relative perturbation of the
+      EMULATION's own conv outputs moves its D gradients by ~2e-2, measured with the CPU oracle alone);
+    - hip vs ref <= 1.25 x emu vs ref per tensor: the fast path's distance from the reference IS the storage format's;
+    - CGAN (no emulation of its double backward): hip vs ref against stated limits.
+  (Round 2 gated every tensor at 2x a table recorded from the HIP path - a regression gate, not parity; the table is still
+  produced by tests/golden/make_bf16_error_table.py as a report, profiles/r03_bf16_error_table.md, and gates nothing.)
+* envelope along a 30-step free-running trajectory: within 2x the emulation's own divergence from the fp32 oracle;
 * determinism: no float atomics on the path - two runs of the same steps give bitwise identical weights and scalars."""
 import pytest
 import torch
@@ -14,39 +18,32 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("dcgan", 8, 2), ("dcgan", 64, 2), ("dcgan", 256, 1), ("cgan", 8, 2), ("cgan", 64, 2), ("cgan", 256, 1)]
 FLOOR = {"scalars": 2e-4, "d_grads": 1e-3, "g_grads": 1e-3}      # absolute slack under which a distance is rounding noise
-
-
-def _table(family, B):
-    from util import load_golden
-    return load_golden("bf16_error_table")["cases"][f"{family}_B{B}"]
-
-
-def limit(family, B, group, key, metric="hip_vs_ref"):
-    """2x the recorded distance (+ a floor for distances that are rounding noise)."""
-    return 2.0 * _table(family, B)[group][key][metric] + FLOOR[group]
+# hip vs emu (DCGAN): relative L2 per gradient tensor / relative per scalar.  The flips thin out as the batch grows.
+LIM_EMU = {8: {"d_grads": 0.11, "g_grads": 0.16, "scalars": 3.0e-2},
+           64: {"d_grads": 0.08, "g_grads": 0.14, "scalars": 2.0e-2},
+           256: {"d_grads": 0.05, "g_grads": 0.12, "scalars": 5.0e-3}}
+# hip vs ref (CGAN, whose penalty is back-propagated: no storage emulation of the double backward exists)
+LIM_REF_CGAN = {8: {"d_grads": 0.16, "g_grads": 0.26, "scalars": 3.0e-2},
+                64: {"d_grads": 0.12, "g_grads": 0.22, "scalars": 2.0e-2},
+                256: {"d_grads": 0.08, "g_grads": 0.20, "scalars": 1.0e-2}}
 
 
 @pytest.mark.parametrize("family,B,steps", CASES)
-def test_bf16_step_within_twice_the_measured_error(family, B, steps):
+def test_bf16_step_against_the_storage_emulation(family, B, steps):
     import bf16_error as be
     rows = be.measure(family, B, steps)
-    tab = _table(family, B)
     bad = []
+    metric, lim = ("hip_vs_emu", LIM_EMU[B]) if family == "dcgan" else ("hip_vs_ref", LIM_REF_CGAN[B])
     for group in ("scalars", "d_grads", "g_grads"):
         for k in rows[0][group]:
-            for m in ("hip_vs_ref", "hip_vs_emu"):
-                if m not in rows[0][group][k]:
-                    continue
-                got = max(r[group][k][m] for r in rows)
-                lim = 2.0 * tab[group][k][m] + FLOOR[group]
-                if not got <= lim:
-                    bad.append(f"{group}:{k}:{m}: {got:.3e} > 2 x {tab[group][k][m]:.3e}")
+            got = max(r[group][k][metric] for r in rows)
+            if not got <= lim[group] + FLOOR[group]:
+                bad.append(f"{group}:{k}:{metric}: {got:.3e} > {lim[group]:.3e}")
     assert not bad, "\n".join(bad)
     if family == "dcgan":
         # the storage format explains the distance from the fp32 oracle: tensor by tensor hip is no further from it than the
         # emulation is (measured: equal within a few %), and with the format matched hip and the emulation are closer to each
-        # other than either is to the fp32 oracle.  What is left between them is summation order: a 1e-6 relative perturbation
-        # of D's conv outputs moves the EMULATION's own gradients by ~2e-2 (bf16 rounding-boundary flips, DESIGN.md section 2).
+        # other than either is to the fp32 oracle
         for group in ("d_grads", "g_grads"):
             for k in rows[0][group]:
                 h = max(r[group][k]["hip_vs_ref"] for r in rows)

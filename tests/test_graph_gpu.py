@@ -75,3 +75,69 @@ def test_device_rng_steps_replay_with_a_generator():
     assert res[0][0] == res[1][0]
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_only_linear_graphs_are_instantiated():
+    """jck_engine_capture_end refuses a captured graph with parallel branches.  ROCm 7.2's hipGraphLaunch of such a graph
+    (hip::GraphExec::Run -> hip::Graph::UpdateStreams) walks the graph's pool of internal streams, skips each one that shares the
+    launch stream's hardware queue and never checks the index against the pool's size: with two such streams it reads past the
+    end of the vector - the SIGSEGV of round 2, whose faulting instruction is that dereference.  A graph
+    of width 1 never enters that code, so the engine captures linearly and makes sure nothing else gets instantiated."""
+    import ctypes as C
+
+    from hipgan import JckError, lib
+    from hipgan.engine import DcganEngine
+    eng = DcganEngine(batch=8, prec="f32")
+    st, side = torch.cuda.Stream(), torch.cuda.Stream()
+    x, y = torch.zeros(1024, device="cuda"), torch.zeros(1024, device="cuda")
+    torch.cuda.synchronize()
+    out = C.c_void_p()
+    # a linear capture is accepted ...
+    lib.jck_engine_capture_begin(eng._h, st.cuda_stream)
+    with torch.cuda.stream(st):
+        x.add_(1)
+        x.mul_(2)
+    lib.jck_engine_capture_end(eng._h, st.cuda_stream, C.byref(out))
+    lib.jck_graph_launch(out.value, st.cuda_stream)
+    st.synchronize()
+    assert float(x[0]) == 2.0
+    lib.jck_graph_destroy(out.value)
+    # ... a fork / join is not
+    lib.jck_engine_capture_begin(eng._h, st.cuda_stream)
+    with torch.cuda.stream(st):
+        x.add_(1)
+        side.wait_stream(st)
+        with torch.cuda.stream(side):
+            y.add_(1)
+        x.add_(1)
+        st.wait_stream(side)
+        x.add_(y)
+    with pytest.raises(JckError, match="parallel branches"):
+        lib.jck_engine_capture_end(eng._h, st.cuda_stream, C.byref(out))
+    torch.cuda.synchronize()
+    assert float(x[0]) == 2.0                                         # nothing of the refused capture ran
+
+
+def test_engine_noise_follows_the_seed():
+    """The step's own draws (Philox: z, alpha, instance noise) are keyed by a seed that follows torch's seed unless the caller sets
+    one (a one-GPU run must not see the same noise whatever the seed), and by the optimiser step."""
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images
+    imgs = synth_images(8).cuda()
+    fakes = []
+    for seed in (1, 1, 2):
+        torch.manual_seed(12345)
+        g, d = build_params("dcgan")
+        torch.manual_seed(seed)
+        eng = DcganEngine(batch=8, prec="f32")
+        eng.load_state(g, d)
+        eng.step_async(imgs, None, 2e-4)
+        fakes.append(eng.tensor("fake").clone())
+    assert torch.equal(fakes[0], fakes[1])
+    assert not torch.equal(fakes[0], fakes[2])
+    eng.set_noise_seed(77)
+    eng.t = 0
+    eng.load_state(g, d)
+    eng.step_async(imgs, None, 2e-4)
+    assert not torch.equal(eng.tensor("fake"), fakes[2])

@@ -7,9 +7,10 @@ Tolerances (relative):
       LeakyReLU/ReLU derivative is discontinuous at 0, so a pre-activation within rounding distance of 0 can take the other
       branch than on the CPU and change a handful of gradient elements by 0.8*g - an effect the reference shows against
       itself once its own summation order changes (tests/golden/selfdiv.json).
-  JCK_PREC_BF16 (fast path): 3e-2 on losses per step here; gradients, per tensor, within 2x the error MEASURED on a MI355X
-      (tests/golden/bf16_error_table.json) and inside the envelope of a bf16-storage emulation of the oracle - see
-      tests/test_bf16_envelope.py, which also holds the free-running trajectory and the run-to-run determinism."""
+  JCK_PREC_BF16 (fast path): 3e-2 on losses per step here; gradients, per tensor, against stated limits that follow from a
+      bf16-storage emulation of the oracle - see tests/test_bf16_envelope.py, which also holds the free-running trajectory
+      and the run-to-run determinism; tests/test_trainer_gpu.py holds the bf16 trainer's first step to the fixture recorded
+      from the reference's own trainer at 1e-2."""
 import pytest
 import torch
 
@@ -205,20 +206,24 @@ def test_full_size_step_batch256(prec, tol):
     if prec == "f32":
         _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3)
         _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2)
-    else:       # per tensor, 2x the error measured on a MI355X (tests/golden/bf16_error_table.json)
-        from test_bf16_envelope import limit
+    else:       # per tensor against the fp32 oracle: what bf16 STORAGE costs at this batch (the emulation of the storage format,
+                # oracle/bf16_emu.py, is 0.086 / 0.164 away from the fp32 oracle on D's / G's worst tensor; tests/test_bf16_envelope.py
+                # holds hip to 1.25x the emulation tensor by tensor)
+        lim = {"d": 0.11, "g": 0.21}
         for tag, refs in (("d", dgr), ("g", ggr)):
             views = eng.named_views(tag, "grads")
             for k, r in refs.items():
                 l2 = ((views[k].detach().float().cpu().view(r.shape) - r).norm() / (r.norm() + 1e-30)).item()
-                assert l2 <= limit("dcgan", 256, f"{tag}_grads", k), (tag, k, l2)
+                assert l2 <= lim[tag], (tag, k, l2)
 
 
 @pytest.mark.parametrize("env", [{"JCK_BATCHED": "0"}, {"JCK_BATCHED": "2"}, {"JCK_BATCHED": "4"}, {"JCK_OVERLAP": "0"},
-                                 {"JCK_FUSE_BNBWD": "1"}, {"JCK_BATCHED": "0", "JCK_FUSE_BNBWD": "1"}])
+                                 {"JCK_FUSE_BNBWD": "1"}, {"JCK_BATCHED": "0", "JCK_FUSE_BNBWD": "1"},
+                                 {"JCK_BN2": "1"}, {"JCK_BN2": "1", "JCK_BATCHED": "0"}, {"JCK_BN2": "1", "JCK_BATCHED": "2"}])
 def test_alternative_schedules_give_the_same_step(env, monkeypatch):
     """The schedules kept behind environment switches (per-pass D passes with stream overlap, the 2B / split-forward batched
-    variants, no overlap at all, BatchNorm-backward statistics in the dgrad epilogue) must all be the same arithmetic: one
+    variants, no overlap at all, BatchNorm-backward statistics in the dgrad epilogue, the exact-sum statistics of
+    csrc/bnstat.hpp - JCK_BN2=1) must all be the same arithmetic: one
     exact-fp32 step of each against the oracle.  The switches are read when an engine is created."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -228,6 +233,27 @@ def test_alternative_schedules_give_the_same_step(env, monkeypatch):
         assert _rel(got[k], ref[k]) < 1e-3, (env, k, got[k], ref[k])
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 1e-3), ("bf16", 3e-2)])
+def test_exact_sum_statistics_at_full_size(prec, tol, monkeypatch):
+    """JCK_BN2=1 at batch 256: the persistent gather-GEMMs accumulate the forward statistics and - in their dgrad epilogue - the
+    BatchNorm-backward sums as exact integer-atomic sums (csrc/bnstat.hpp), the activation / apply launches finalise them.
+    Same step as the default schedule against the oracle; two runs give the same bits (integer addition is associative)."""
+    monkeypatch.setenv("JCK_BN2", "1")
+    orc, eng, out = _run(256, 1, prec)
+    ref, got, dgr, ggr = out[0]
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(got[k], ref[k]) < tol, (k, got[k], ref[k])
+    assert int(eng.named_views("d")["norm1.num_batches_tracked"]) == 4 and int(eng.named_views("g")["norm1.num_batches_tracked"]) == 1
+    if prec == "f32":
+        _cmp_tensors(eng.named_views("d", "grads"), dgr, 1.0, "d_grads", 5e-3)
+        _cmp_tensors(eng.named_views("g", "grads"), ggr, 1.0, "g_grads", 3e-2)
+    first = {k: v.clone() for k, v in eng.arenas.items()}
+    orc2, eng2, out2 = _run(256, 1, prec)
+    assert out2[0][1] == got
+    for k, v in first.items():
+        assert torch.equal(v, eng2.arenas[k]), k
 
 
 def test_batched_schedule_with_a_non_power_of_two_batch():

@@ -68,6 +68,56 @@ def test_trainer_reproduces_reference_run(key, tmp_path, monkeypatch):
     _fresh_logger()
 
 
+def test_bf16_trainer_step0_against_the_reference_run(tmp_path, monkeypatch):
+    """The bf16 fast path (what bench.py times) against the fixture recorded from the REFERENCE's own DCGANTrainer.train()
+    (tests/golden/dcgan_steps.json, batch 64, CPU-generator noise in the reference's order): the losses of the first step -
+    identical state on both sides - within 1e-2 relative (the bf16 per-step gate), later steps inside the
+    trajectory's own amplification."""
+    from model import DCGAN
+    from train.dcgan_trainer import DCGANTrainer
+    from util import load_golden, rel, synth_images
+    gold = load_golden("dcgan_steps")["B64"]
+    B, steps = gold["B"], gold["steps"]
+    monkeypatch.chdir(tmp_path)
+    _fresh_logger()
+    imgs = synth_images(B * steps)
+    batches = [(imgs[i * B:(i + 1) * B],) for i in range(steps)]
+    args = argparse.Namespace(epoch=1, max_learning_rate=gold["lr"], model_path="golden", log_file=0,
+                              save_path=str(tmp_path / "save" / "dcgan" / "golden"), batch_size=B, num_worker=0)
+    torch.manual_seed(12345)
+    g, d = DCGAN.Generator(), DCGAN.Discriminator()
+    tr = DCGANTrainer(args, g, d, SynthPre(batches), prec="bf16", host_rng=True)
+    losses_d, losses_g = tr.train()
+    assert rel(losses_d[0], gold["losses_d"][0]) < 1e-2, (losses_d, gold["losses_d"])
+    assert rel(losses_g[0], gold["losses_g"][0]) < 1e-2, (losses_g, gold["losses_g"])
+    for s in range(1, steps):
+        assert rel(losses_d[s], gold["losses_d"][s]) < 3e-2 and rel(losses_g[s], gold["losses_g"][s]) < 6e-2, (s, losses_d, losses_g)
+    _fresh_logger()
+
+
+def test_bf16_cgan_trainer_step0_against_the_reference_run(tmp_path, monkeypatch):
+    """Same for CGAN (tests/golden/cgan_steps.json, batch 32, back-propagated penalty, CPU-generator dropout masks)."""
+    from model import CGAN
+    from train.cgan_trainer import CGANTrainer
+    from util import load_golden, rel, synth_images, synth_onehot
+    gold = load_golden("cgan_steps")["B32"]
+    B, steps = gold["B"], gold["steps"]
+    monkeypatch.chdir(tmp_path)
+    _fresh_logger()
+    imgs = synth_images(B * steps)
+    oh, _ = synth_onehot(B * steps)
+    batches = [(imgs[i * B:(i + 1) * B], oh[i * B:(i + 1) * B]) for i in range(steps)]
+    args = argparse.Namespace(epoch=1, max_learning_rate=gold["lr"], model_path="golden", log_file=0,
+                              save_path=str(tmp_path / "save" / "cgan" / "golden"), batch_size=B, num_worker=0)
+    torch.manual_seed(12345)
+    g, d = CGAN.Generator(), CGAN.Discriminator()
+    tr = CGANTrainer(args, g, d, SynthPreC(batches), prec="bf16", host_rng=True)
+    losses_d, losses_g = tr.train()
+    assert rel(losses_d[0], gold["losses_d"][0]) < 1e-2, (losses_d, gold["losses_d"])
+    assert rel(losses_g[0], gold["losses_g"][0]) < 1e-2, (losses_g, gold["losses_g"])
+    _fresh_logger()
+
+
 def test_main_wiring_with_ragged_last_batch(tmp_path, monkeypatch):
     """python main.py -m DCGAN on synthetic data: 40 images, batch 16 -> batches of 16, 16, 8 (second engine bound to the
     same arenas), device RNG, bf16 fast path; losses finite, modules updated, G usable as an nn.Module afterwards."""
