@@ -67,7 +67,6 @@ struct IgemmParams {
   // bnj.xs != nullptr switches every statistics path of this file to it (forward: bnj.mode 1; with bn_y: mode 2, the second
   // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
   BnStatJob bnj;
-  int dma_buf;            // persistent kernels: issue the LDS-DMA as buffer loads (descriptor + 32-bit offset) instead of global loads
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -488,25 +487,21 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
     wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + lrow) * p.K) * 2);
   const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
   const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
-  const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page);
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int nk = p.K / IG_BK;
   // k-steps past the end re-load the last tile into a stage nobody reads: no predicate, no branch, exact vmcnt arithmetic
-  // p.dma_buf: buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see igemm_dma_persist_kernel
+  // buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see igemm_dma_persist_kernel
   const auto rs_a = make_rsrc(p.act, p.act_bytes);
   const auto rs_wt = make_rsrc(p.w, p.w_bytes);
-  const bool dbuf = p.dma_buf != 0;
   auto issue = [&](int kc, int stage) {
     const int kbase = min(kc, nk - 1) * IG_BK;
     unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);     // this wave's 8 rows of each 32-row pass
 #pragma unroll
-    for (int ps = 0; ps < C::WPASS; ++ps) {
-      const unsigned off = wrowoff[ps] + (unsigned)kbase * 2u + src_chunk;
-      if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16, (int)off, 0, 0, 0);
-      else __builtin_amdgcn_global_load_lds((gptr_t)(wb + off), (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
-    }
+    for (int ps = 0; ps < C::WPASS; ++ps)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16,
+                                               (int)(wrowoff[ps] + (unsigned)kbase * 2u + src_chunk), 0, 0, 0);
     const int t = __builtin_amdgcn_readfirstlane(p.act_row_elems ? 0 : (kbase >> p.logC));
     const int tp = p.tap[z][t];
     const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
@@ -515,13 +510,8 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
 #pragma unroll
     for (int ps = 0; ps < C::APASS; ++ps) {
       const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
-      if (dbuf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
-                                                 (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
-      } else {
-        const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
+                                               (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
     }
   };
 
@@ -728,24 +718,19 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       for (int ps = 0; ps < C::WPASS; ++ps)          // LDS row ps*32 + lrow <- output channel ch0 + ps*32 + pi(lrow) (igemm_epilogue_perm)
         wrowoff[ps] = (unsigned)(((long long)z * p.w_phase_stride + (long long)(ch0 + ps * 32 + igemm_perm_row(lrow)) * p.K) * 2);
     };
-    const unsigned char* actb = reinterpret_cast<const unsigned char*>(p.act);
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page);
-    // p.dma_buf: the same pieces as buffer loads - a wave-uniform descriptor in SGPRs plus ONE 32-bit offset VGPR per lane
-    // (instead of a 64-bit address pair); an offset past the descriptor's size (JCK_OOB) returns zeros, which replaces the
-    // zero page for out-of-image taps and rows past M
+    // The pieces are BUFFER loads: a wave-uniform descriptor in SGPRs plus ONE 32-bit offset VGPR per lane instead of a 64-bit
+    // address pair (round 3: the same bytes into the same LDS slots, bit-identical results, the gather-GEMMs 3-18 % faster -
+    // the loader waves spend most of their time in the ISSUE of these pieces).  An offset past the descriptor's size (JCK_OOB)
+    // returns zeros, which replaces the zero page for out-of-image taps and rows past M.
     const auto rs_a = make_rsrc(p.act, p.act_bytes);
     const auto rs_wt = make_rsrc(p.w, p.w_bytes);
-    const bool dbuf = p.dma_buf != 0;
     auto issue = [&](int kc, int stage) {
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
 #pragma unroll
-      for (int ps = 0; ps < C::WPASS; ++ps) {
-        const unsigned off = wrowoff[ps] + (unsigned)kbase * 2u + src_chunk;
-        if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16, (int)off, 0, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr_t)(wb + off), (lptr_t)(sb + ps * (32 * LD * 2)), 16, 0, 0);
-      }
+      for (int ps = 0; ps < C::WPASS; ++ps)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lptr_t)(sb + ps * (32 * LD * 2)), 16,
+                                                 (int)(wrowoff[ps] + (unsigned)kbase * 2u + src_chunk), 0, 0, 0);
       const int t = __builtin_amdgcn_readfirstlane(kbase >> p.logC);
       const int tp = p.tap[z][t];
       const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
@@ -753,13 +738,8 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
-        if (dbuf) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
-                                                   (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
-        } else {
-          const unsigned char* src = ok ? actb + (rowoff[ps] + toffb + src_chunk) : zp;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16, 0, 0);
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
+                                                 (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
       }
     };
     // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads

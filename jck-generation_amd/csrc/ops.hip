@@ -26,11 +26,6 @@ static int g_igemm_dma = env_int("JCK_IGEMM_DMA", 1);        // LDS-DMA gather-G
 static int g_igemm_ws = env_int("JCK_IGEMM_WS", 1);          // wave-specialised 128x64 tiles when < 512 tiles of 128x128
 static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number of 128x256 tiles to take that kernel (0: never)
 static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wave-specialised gather-GEMMs (igemm.hpp); bit 0: 128x256, 1: 128x64, 2: 64x128 tiles
-// LDS-DMA issued as buffer loads (wave-uniform descriptor + one 32-bit offset VGPR per lane) instead of global loads with a 64-bit
-// address pair per lane: the same bytes into the same LDS slots, bit-identical results, 3-18 % faster per gather-GEMM
-// (tests/_mb2.py igemm_dmabuf 0 1 ..., round 3) - the loader waves spend most of their time in the ISSUE of these pieces
-static int g_igemm_dmabuf = env_int("JCK_IGEMM_DMABUF", 1);
-static int g_wgrad_dmabuf = env_int("JCK_WGRAD_DMABUF", 1);
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
@@ -42,7 +37,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dmabuf", &g_igemm_dmabuf}, {"wgrad_dmabuf", &g_wgrad_dmabuf}, {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -159,7 +154,6 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
   IgemmParams q = p;
   q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
-  q.dma_buf = g_igemm_dmabuf;
   if (q.stats) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
@@ -187,7 +181,6 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
   IgemmParams q = p;
   q.gx = grid.x; q.gy = grid.y; q.gz = grid.z;
-  q.dma_buf = g_igemm_dmabuf;
   const int ntiles = (int)(grid.x * grid.y * grid.z);
   const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
   const int nwg = std::min(ntiles, cap);
@@ -617,7 +610,6 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
   ProfScope prof(pl.BG == 256 ? 21 : 10, p.flops, st);
   WgradParams q = p;
   q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
-  q.dma_buf = g_wgrad_dmabuf && q.big_bytes && q.s_bytes;
   const int grid = pl.gx * pl.gy * pl.Z;
   const int stamp = g_wgrad_stamp, wsp = g_wgrad_ws;
   if (pl.BG == 256) return launch_wgrad_dma_t<3, false, true, 2>(q, grid, st);
@@ -628,7 +620,7 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
 template <class P>
 static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, hipStream_t st) {
   const int use_dma = g_wgrad_dma;
-  if (use_dma && !P::IS_F32 && (pl.BG == 128 || pl.BG == 256) && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
+  if (use_dma && p.big_bytes && p.s_bytes && !P::IS_F32 && (pl.BG == 128 || pl.BG == 256) && pl.BS == 128 && nsub == 1 && !p.big_row_elems && p.logCb >= 6 && p.logCb < 30 &&
       pl.mchunk % WGD_BKP == 0 && p.logOW <= 6 &&
       ((1 << p.logOHW) <= WGD_BKP || p.H == p.sy * ((1 << p.logOHW) >> p.logOW)))     // constant 64-pixel address step (wgrad.hpp)
     return launch_wgrad_dma(p, pl, st);
@@ -677,7 +669,6 @@ static int launch_wgrad_halo(const WgradParams& p, const WgradPlan& pl, float* w
   WgradParams q = p;
   q.part = ws; q.CsRows = pl.CsRows; q.ncols = pl.ncols; q.mchunk = pl.mchunk;
   q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
-  q.dma_buf = g_wgrad_dmabuf && q.big_bytes && q.s_bytes;
   const int grid = pl.gx * pl.gy * pl.Z;
   switch (q.logOW) {
     case 2: return launch_wgrad_halo_t<2>(q, grid, st);
@@ -746,7 +737,7 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
   // tap-reuse kernel where it measured faster than the per-tap gather (tests/_mb2.py wgrad_halo 0 1 ...): >= 32 k-steps per
   // workgroup (the 2B-image products of the D phase: +4..12 %; 16 k-steps: -5..-12 %, the 128 KB fp32 tile each workgroup
   // writes into its split-K slab is then a third of its time).  JCK_WGRAD_HALO=2 forces it for every admissible shape.
-  bool halo = g_wgrad_halo && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs, N);
+  bool halo = g_wgrad_halo && p.big_bytes && p.s_bytes && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs, N);
   if (halo && g_wgrad_halo != 2 && plan_wgrad_halo(p.Mtot, cbp, Cs).mchunk < 32 * 64) halo = false;
   const WgradPlan pl = halo ? plan_wgrad_halo(p.Mtot, cbp, Cs) : plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
   int rc = halo ? launch_wgrad_halo(p, pl, ws, ws_bytes, (hipStream_t)stream)

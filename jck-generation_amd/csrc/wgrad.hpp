@@ -36,8 +36,7 @@ struct WgradParams {
   int mchunk;             // pixel rows per blockIdx.z (multiple of WG_BKP)
   int big_row_elems;      // > 0: the gathered side is a plain [Mtot][big_row_elems] matrix (Linear layers), 1 tap
   int gx, gy, gz;         // logical grid of the LDS-DMA kernel (launched 1-D): column tiles, row tiles, pixel chunks
-  unsigned big_bytes, s_bytes;   // sizes of the two operands (buffer descriptors of the LDS-DMA kernels)
-  int dma_buf;            // LDS-DMA kernels: issue the pieces as buffer loads (descriptor + 32-bit offset; round 3: 3-18 % faster)
+  unsigned big_bytes, s_bytes;   // sizes of the two operands (buffer descriptors of the LDS-DMA kernels; 0: use the register-staged kernel)
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -343,7 +342,6 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
   const int mz1 = min(mz0 + p.mchunk, p.Mtot);
   const unsigned char* bigb = reinterpret_cast<const unsigned char*>(p.big);
   const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(p.sside);
-  const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page_w);
   const int Cb = 1 << p.logCb;
 
   // this lane's place inside a wave-instruction: 4 rows x 16 chunks
@@ -392,11 +390,10 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
     soff[q] = (unsigned)((m * p.CsStride + s0 + lc * 8) * 2);
     sokc[q] = s0 + lc * 8 < p.CsStride;
   }
-  // p.dma_buf: buffer loads (wave-uniform descriptor + one 32-bit offset VGPR per lane; an offset past the operand returns
-  // zeros - no zero page): the issue of a piece costs less than with a 64-bit address pair per lane
+  // The pieces are buffer loads (wave-uniform descriptor + one 32-bit offset VGPR per lane; an offset past the operand returns
+  // zeros - no zero page): the issue of a piece costs less than with a 64-bit address pair per lane (round 3: +4-14 %)
   const auto rs_big = make_rsrc(p.big, p.big_bytes);
   const auto rs_s = make_rsrc(p.sside, p.s_bytes);
-  const bool dbuf = p.dma_buf != 0;
   auto issue = [&](int stage) {
     unsigned char* gt = lds + stage * STG_BYTES;
     unsigned char* st = gt + GT * TILE_BYTES;
@@ -406,14 +403,12 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
 #pragma unroll
       for (int g = 0; g < GT; ++g) {
         const bool ok = rok && bokx[g][q] && (unsigned)(oyq[q] * p.sy + dyq[g][q]) < (unsigned)p.H;
-        lptr_t dst = (lptr_t)(gt + g * TILE_BYTES + (q * (4 * NW) + wave * 4) * ROWB);
-        if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, dst, 16, (int)(ok ? boff[g][q] : JCK_OOB), 0, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr_t)(ok ? bigb + boff[g][q] : zp), dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, (lptr_t)(gt + g * TILE_BYTES + (q * (4 * NW) + wave * 4) * ROWB), 16,
+                                                 (int)(ok ? boff[g][q] : JCK_OOB), 0, 0, 0);
         boff[g][q] += binc;
       }
-      lptr_t sdst = (lptr_t)(st + (q * (4 * NW) + wave * 4) * ROWB);
-      if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, sdst, 16, (int)((rok && sokc[q]) ? soff[q] : JCK_OOB), 0, 0, 0);
-      else __builtin_amdgcn_global_load_lds((gptr_t)((rok && sokc[q]) ? sb_ + soff[q] : zp), sdst, 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(st + (q * (4 * NW) + wave * 4) * ROWB), 16,
+                                               (int)((rok && sokc[q]) ? soff[q] : JCK_OOB), 0, 0, 0);
       soff[q] += sinc; mq[q] += WGD_BKP;
       oyq[q] = (oyq[q] + doy) & (OH - 1);
     }

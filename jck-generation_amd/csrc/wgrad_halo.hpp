@@ -69,7 +69,6 @@ static __global__ __launch_bounds__(768) void wgrad_halo_kernel(const WgradParam
     const int wave = wave_raw - 8;
     const unsigned char* bigb = reinterpret_cast<const unsigned char*>(p.big);
     const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(p.sside);
-    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_jck_zero_page_w);
     const int OH = p.H >> 1, nimg = p.Mtot >> p.logOHW;
     // S pieces (i = 0, 1): piece j = 4i + wave = tile rows 8j .. 8j+7, 128 bytes each
     unsigned soff[2];
@@ -100,10 +99,9 @@ static __global__ __launch_bounds__(768) void wgrad_halo_kernel(const WgradParam
     }
     const long long binc = G::WHOLE ? ((long long)(G::NI * p.H * p.W) << p.logCb) * 2 : ((long long)(2 * R * p.W) << p.logCb) * 2;
 
-    // p.dma_buf: buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see wgrad_dma_kernel
+    // buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see wgrad_dma_kernel
     const auto rs_big = make_rsrc(p.big, p.big_bytes);
     const auto rs_s = make_rsrc(p.sside, p.s_bytes);
-    const bool dbuf = p.dma_buf != 0;
     auto issue = [&](int k, int stage) {
       unsigned char* sb = lds + stage * STG;
       const bool live = k < nk;
@@ -111,12 +109,10 @@ static __global__ __launch_bounds__(768) void wgrad_halo_kernel(const WgradParam
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const bool sok = live && srow[i] < p.Mtot;
-        if (dbuf) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(sb + (i * 4 + wave) * 1024), 16, (int)(sok ? soff[i] : JCK_OOB), 0, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr_t)(sok ? sb_ + soff[i] : zp), (lptr_t)(sb + (i * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(sb + (i * 4 + wave) * 1024), 16, (int)(sok ? soff[i] : JCK_OOB), 0, 0, 0);
         soff[i] += sinc; srow[i] += 64;
       }
-      const long long cgoff = (long long)cg * binc;                     // wave-uniform; a patch may start one row above it (prel < 0)
-      const unsigned char* base = bigb + cgoff;
+      const unsigned cgoff = (unsigned)((long long)cg * binc);          // wave-uniform; a patch may start one row above it (prel < 0)
       const int oy0 = (cg << LOGR) & (OH - 1);
       const bool top = oy0 == 0, bot = oy0 + R == OH;
 #pragma unroll
@@ -124,13 +120,8 @@ static __global__ __launch_bounds__(768) void wgrad_halo_kernel(const WgradParam
         bool ok = live && (pflag[i] & 1);
         if (G::WHOLE) ok = ok && (cg * G::NI + (pflag[i] >> 4)) < nimg;
         else ok = ok && !((pflag[i] & 2) && top) && !((pflag[i] & 4) && bot);
-        if (dbuf) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, (lptr_t)(sb + 8192 + (i * 4 + wave) * 1024), 16,
-                                                   (int)(ok ? (unsigned)(cgoff + prel[i]) : JCK_OOB), 0, 0, 0);
-        } else {
-          const unsigned char* src = ok ? base + prel[i] : zp;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + 8192 + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, (lptr_t)(sb + 8192 + (i * 4 + wave) * 1024), 16,
+                                                 (int)(ok ? cgoff + (unsigned)prel[i] : JCK_OOB), 0, 0, 0);
       }
     };
 
