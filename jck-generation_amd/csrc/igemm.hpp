@@ -67,6 +67,7 @@ struct IgemmParams {
   // bnj.xs != nullptr switches every statistics path of this file to it (forward: bnj.mode 1; with bn_y: mode 2, the second
   // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
   BnStatJob bnj;
+  int loader_prio;        // persistent kernels: s_setprio of the loader waves (jck_tune "igemm_prio")
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -698,6 +699,9 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   if (loader) {
+    // the loader waves are the younger half of the workgroup and lose the issue arbitration at equal priority (MI355X guide, "Two
+    // waves per SIMD", item 4); the kernel is bound by how fast they issue their pieces: +0.3..3 % per launch alone, neutral in the step
+    if (p.loader_prio) __builtin_amdgcn_s_setprio(1);
     const int lrow = (tid & 255) >> 3, unit = tid & 7;
     const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;
     unsigned rowoff[C::APASS], wrowoff[C::WPASS];

@@ -37,6 +37,7 @@ struct WgradParams {
   int big_row_elems;      // > 0: the gathered side is a plain [Mtot][big_row_elems] matrix (Linear layers), 1 tap
   int gx, gy, gz;         // logical grid of the LDS-DMA kernel (launched 1-D): column tiles, row tiles, pixel chunks
   unsigned big_bytes, s_bytes;   // sizes of the two operands (buffer descriptors of the LDS-DMA kernels; 0: use the register-staged kernel)
+  int loader_prio;        // wave-specialised kernels: s_setprio of the loader waves (jck_tune "wgrad_prio")
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -462,6 +463,7 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
   if constexpr (STAMP) tk0 = __builtin_amdgcn_s_memtime();
   if constexpr (WS) {
     if (loader) {
+      if (p.loader_prio) __builtin_amdgcn_s_setprio(1);
       issue(0); issue(1);                                             // stages 0, 1 in flight
       int slot = 2;
       for (int k = 0; k < nk; ++k) {

@@ -66,6 +66,7 @@ static __global__ __launch_bounds__(768) void wgrad_halo_kernel(const WgradParam
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   if (loader) {
+    if (p.loader_prio) __builtin_amdgcn_s_setprio(1);
     const int wave = wave_raw - 8;
     const unsigned char* bigb = reinterpret_cast<const unsigned char*>(p.big);
     const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(p.sside);
