@@ -14,6 +14,8 @@
 // rate - accuracy, not speed, is what a metric network needs): 64 pixels x 64 channels per workgroup, k = (kh, kw, ci) in
 // steps of 16; the activation tile is gathered with ci fastest across lanes (64-byte runs), the weight tile [k][co] with co
 // fastest, both through padded LDS rows.
+#include <cstdlib>
+
 #include "ops_internal.hpp"
 
 namespace {
@@ -95,6 +97,98 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_f32_kernel(const ConvP p) {
     const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] * sc + sh;
+        if (p.relu) v = v > 0.f ? v : 0.f;
+        p.out[(long long)m * p.ocs + p.ocoff + co] = v;
+      }
+  }
+}
+
+// The same product for the layers whose input has a multiple of 16 channels (every convolution of Inception-v3 but the first):
+// a 16-deep k-step then lies inside ONE filter tap, so the tap and the channel offset are wave-uniform and the gather is two
+// 16-byte loads per thread and k-step (4 consecutive input channels of a pixel) instead of eight scalar loads behind an integer
+// division.  128 pixels x 64 channels per workgroup (each weight value is used by twice the pixels), register double buffering:
+// the loads of k-step i+1 are in flight while step i is multiplied, one barrier per step.  Same k order and the same exact-fp32
+// MFMA as the generic kernel above - the results are bitwise the same.  Measured (tests/_eval_prof.py, 64 images): see DESIGN.md.
+constexpr int CV_M = 128, CV_N = 64, CV_K = 16, CV_LDA = 20, CV_LDB = 80;
+__global__ __launch_bounds__(256) void conv2d_nhwc_f32_c16_kernel(const ConvP p) {
+  __shared__ __attribute__((aligned(16))) float As[2][CV_M][CV_LDA];       // [pixel][k]: 16-byte rows; (20 m + k) % 64 is conflict-free
+  __shared__ __attribute__((aligned(16))) float Bs[2][CV_K][CV_LDB];       // [k][co]: (80 k + co) % 64 is conflict-free
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * CV_M, n0 = blockIdx.y * CV_N;
+  // A loader: rows (tid >> 2) and + 64, k quad (tid & 3) * 4;  B loader: k row tid >> 4, channels (tid & 15) * 4
+  const int ar = tid >> 2, akq = (tid & 3) * 4;
+  long long abase[2];
+  int aiy[2], aix[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int m = m0 + ar + 64 * h;
+    if (m < p.M) {
+      const int ox = m % p.OW, t = m / p.OW, oy = t % p.OH, n = t / p.OH;
+      aiy[h] = oy * p.SH - p.PH; aix[h] = ox * p.SW - p.PW;
+      abase[h] = (((long long)n * p.H + aiy[h]) * p.W + aix[h]) * p.Cin + akq;
+    } else { aiy[h] = -(1 << 28); aix[h] = 0; abase[h] = 0; }
+  }
+  const int bk = tid >> 4, bco = n0 + (tid & 15) * 4;
+  const bool bok = bco < p.Cout;                                           // Cout % 4 == 0 (launcher)
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 32;                    // this wave's 64 x 32 part of the tile
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / CV_K;
+  int kh = 0, kw = 0, ci = 0;                                              // tap and channel offset of the k-step being LOADED
+  f32x4 ra[2], rb;
+  auto load = [&]() {
+    const long long toff = ((long long)kh * p.W + kw) * p.Cin + ci;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool ok = (unsigned)(aiy[h] + kh) < (unsigned)p.H && (unsigned)(aix[h] + kw) < (unsigned)p.W;
+      ra[h] = ok ? *reinterpret_cast<const f32x4*>(p.x + abase[h] + toff) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long long krow = ((long long)(kh * p.KW + kw) * p.Cin + ci + bk);
+    rb = bok ? *reinterpret_cast<const f32x4*>(p.w + krow * p.Cout + bco) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ci += CV_K;
+    if (ci == p.Cin) { ci = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+  };
+  auto store = [&](int st) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(&As[st][ar + 64 * h][akq]) = ra[h];
+    *reinterpret_cast<f32x4*>(&Bs[st][bk][(tid & 15) * 4]) = rb;
+  };
+  load();
+  store(0);
+  __syncthreads();
+  for (int k = 0; k < nk; ++k) {
+    const int st = k & 1;
+    if (k + 1 < nk) load();                                                // in flight under the products below
+#pragma unroll
+    for (int kk = 0; kk < CV_K; kk += 4) {
+      float a[4], b[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[st][wm + i * 16 + (lane & 15)][kk + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[st][kk + (lane >> 4)][wn + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (k + 1 < nk) store(st ^ 1);                                         // nobody reads stage st^1 during step k
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int co = n0 + wn + j * 16 + (lane & 15);
+    if (co >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
@@ -206,7 +300,11 @@ extern "C" int jck_conv2d_nhwc_f32(const float* x, const float* w_kc, const floa
   p.M = (int)M;
   if (out_cstride < out_coff + Cout || out_coff < 0) JCK_FAIL(JCK_E_ARG, "conv2d_nhwc_f32: output slice outside the channel stride");
   p.ocs = out_cstride; p.ocoff = out_coff; p.relu = relu;
-  hipLaunchKernelGGL(conv2d_nhwc_f32_kernel, dim3(cdiv(p.M, CB_M), cdiv(Cout, CB_N)), dim3(256), 0, (hipStream_t)stream, p);
+  static const bool c16 = !(getenv("JCK_INFER_C16") && atoi(getenv("JCK_INFER_C16")) == 0);
+  if (c16 && Cin % 16 == 0 && Cout % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_kc) & 15) == 0)
+    hipLaunchKernelGGL(conv2d_nhwc_f32_c16_kernel, dim3(cdiv(p.M, CV_M), cdiv(Cout, CV_N)), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv2d_nhwc_f32_kernel, dim3(cdiv(p.M, CB_M), cdiv(Cout, CB_N)), dim3(256), 0, (hipStream_t)stream, p);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
