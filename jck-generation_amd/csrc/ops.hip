@@ -40,7 +40,11 @@ static int g_wgrad_small_wgs = env_int("JCK_WGRAD_SMALL_WGS", 512);
 static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
 static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
-static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 1);    // tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers
+// tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers: 0 never, 1 where it measured faster ALONE (the 2B-image
+// products), 2 always.  Default 0 since round 3: with the LDS-DMA pieces issued as buffer loads the per-tap kernel caught up, and
+// in the step - where the weight gradients share the chip with the dgrad chain and the tap-reuse kernel writes twice the split-K
+// slabs - it is the faster one (1.82-1.83 vs 1.86 ms, tests/_ab.sh JCK_WGRAD_HALO=0 / 1, two rounds)
+static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 0);
 extern "C" int jck_tune(const char* key, int value) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},

@@ -115,7 +115,7 @@ def test_conv_wgrad(G, prec, shape, halo):
                          G.cur_stream())
     torch.cuda.synchronize()
     G.check(grad.cpu(), ref, 3e-6 if prec == 1 else 2e-3, "conv_wgrad(overwrite)")
-    G.lib.jck_tune(b"wgrad_halo", 1)
+    G.lib.jck_tune(b"wgrad_halo", 0)
 
 
 @pytest.mark.parametrize("prec", PRECS)
