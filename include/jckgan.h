@@ -117,6 +117,20 @@ int jck_conv_down_grouped(int prec, const void* big, const void* w, void* small_
                           int Wb, int Cb, int Cs, int group_images, void* stream);
 int jck_conv_up_grouped(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
                         int Ws, int Cs, int Cb, int group_images, void* stream);
+/* Convolutions that consume a BatchNorm'd, activated tensor WITHOUT that tensor being written ("fused BatchNorm2d + (Leaky)ReLU"
+ * on the consumer side; reference model/DCGAN.py:30-33,62-65 - the nn.BatchNorm2d + nn.LeakyReLU / nn.ReLU between two
+ * convolutions).  y_in / in_aux: the producer's raw conv output and its [groups][4 * C] tables (jck_bn_finalize*).  The launch
+ * computes the convolution of a = act(scale * y_in + shift), bit for bit the tensor jck_bn_act_fwd_grouped(y_in, in_aux, in_slope)
+ * writes, by transforming the gathered operand in LDS.  in_group_images: images per BatchNorm group of the INPUT (0: one group);
+ * output statistics per group of `group_images` images as jck_conv_*_grouped.  Shapes whose kernel has no such transform (fp32,
+ * < 64 gathered channels, the 3-channel image layers): a is written to a_buf (then required) by the stand-alone pass and the
+ * plain launch runs; *a_written (optional) says which happened (0 fused, 1 materialised). */
+int jck_conv_down_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
+                     int* a_written, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb, int Wb, int Cb,
+                     int Cs, int group_images, void* stream);
+int jck_conv_up_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf, int* a_written,
+                   const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs, int Ws, int Cs, int Cb,
+                   int group_images, void* stream);
 int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb,
                         int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
 int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,

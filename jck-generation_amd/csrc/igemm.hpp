@@ -68,6 +68,14 @@ struct IgemmParams {
   // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
   BnStatJob bnj;
   int loader_prio;        // persistent kernels: s_setprio of the loader waves (jck_tune "igemm_prio")
+  // Fused BatchNorm + (Leaky)ReLU on the GATHERED operand (persistent kernels, round 3): `act` is then the producer's raw conv
+  // output y, and the loader waves turn every piece they have brought into LDS into a = act(y * scale[c] + shift[c]), rounded to
+  // bf16 - the tensor the stand-alone bn_act_fwd pass would have written (same arithmetic, same bits) - before the consumer
+  // waves see it; out-of-image taps and rows past M stay zero.  in_aux: [in_groups][4 * C] tables as bn_finalize writes them
+  // (scale | shift | ..), group of image n = n / in_group_images (0: one group).
+  const float* in_aux;
+  int in_groups, in_group_images;
+  float in_slope;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -706,12 +714,15 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;
     unsigned rowoff[C::APASS], wrowoff[C::WPASS];
     int riy[C::APASS], rix[C::APASS];
+    const bool bnf = !BNB && p.in_aux != nullptr;     // (dgrad launches with backward statistics never carry it)
+    int tgoff[C::APASS];                              // bnf: this row's table (its image's BatchNorm group), in floats
     auto setup = [&](int L) {
       locate(L);
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const int m = m0 + ps * 32 + lrow;
         const int n = m >> p.logOHW;
+        tgoff[ps] = (bnf && p.in_group_images > 0) ? (n / p.in_group_images) * 2 * Cc : 0;
         const int rem = m & ((1 << p.logOHW) - 1);
         const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
         rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC)) * 2u;
@@ -728,6 +739,11 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     // returns zeros, which replaces the zero page for out-of-image taps and rows past M.
     const auto rs_a = make_rsrc(p.act, p.act_bytes);
     const auto rs_wt = make_rsrc(p.w, p.w_bytes);
+    // bnf: what the transform of a stage needs once its pieces have landed - which of this lane's pieces are inside the image
+    // (bit ps), the first channel of the k-step, the rows' tables, the stage; hist0 = the older of the two k-steps in flight
+    unsigned ok_new = 0u, ok0 = 0u, ok1 = 0u;
+    int cb_new = 0, cb0 = 0, cb1 = 0, st_new = 0, st0 = 0, st1 = 0;
+    int tg_new[C::APASS], tg0[C::APASS], tg1[C::APASS];
     auto issue = [&](int kc, int stage) {
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
@@ -739,11 +755,14 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       const int tp = p.tap[z][t];
       const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
       const unsigned toffb = (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
+      ok_new = 0u; cb_new = kbase & (Cc - 1); st_new = stage;
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
                                                  (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
+        ok_new |= (ok ? 1u : 0u) << ps;
+        tg_new[ps] = tgoff[ps];
       }
     };
     // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads
@@ -751,23 +770,83 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     if (my_tiles > 0) setup(Lq);
     auto next = [&]() {
       issue(kq, slot);
+      if (bnf) {
+        ok0 = ok1; cb0 = cb1; st0 = st1; ok1 = ok_new; cb1 = cb_new; st1 = st_new;
+#pragma unroll
+        for (int ps = 0; ps < C::APASS; ++ps) { tg0[ps] = tg1[ps]; tg1[ps] = tg_new[ps]; }
+      }
       slot = slot == 2 ? 0 : slot + 1;
       if (kq + 1 < nk) { ++kq; return; }
       if (Lq + (int)gridDim.x < ntiles) { Lq += gridDim.x; kq = 0; setup(Lq); }   // else: stay on the last k-step (dead re-loads)
     };
     if (my_tiles > 0) { next(); next(); }
     const int steps = my_tiles * nk;
-    for (int s = 0; s < steps; ++s) {
+    auto wait_older = [&]() {                                         // the older of the two k-steps in flight has landed
       if constexpr (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (NLD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else static_assert(NLD == 8 || NLD == 6 || NLD == 12, "add the vmcnt literal");
-      __builtin_amdgcn_s_barrier();                                   // consumers may read this step's stage; the one before is free
-      next();
+    };
+    if (!bnf) {
+      for (int s = 0; s < steps; ++s) {
+        wait_older();
+        __builtin_amdgcn_s_barrier();                                 // consumers may read this step's stage; the one before is free
+        next();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+    // ---- fused BatchNorm + activation on the gathered operand ----
+    // tables [in_groups][scale | shift][C] into LDS (in the scratch of the exact-sum statistics when those are not in use, else
+    // behind it: the usual launch keeps its LDS footprint and with it its workgroups per CU and its statistic rows), visible to
+    // the four loader waves after the one extra barrier both roles execute
+    float* const tab = reinterpret_cast<float*>(lds + 3 * STG_BYTES + 64 + (p.bnj.xs ? 8 * NCW * BCH : 0));
+    for (int i = tid; i < p.in_groups * 2 * Cc; i += 256) {
+      const int g = i / (2 * Cc);
+      tab[i] = p.in_aux[(long long)g * 4 * Cc + (i - g * 2 * Cc)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int chunk8 = (unit ^ ((lrow >> 1) & 7)) * 8;                // the channels (within the k-step's 64) this lane's LDS slot holds
+    const float slope = p.in_slope;
+    // every lane transforms the pieces IT brought in (its own vmcnt covers them), in place: the stage is not visible to the
+    // consumer waves before the barrier that follows
+    auto xform = [&]() {
+      unsigned char* sa = lds + st0 * STG_BYTES + (wave & 3) * (8 * LD * 2) + BCH * (LD * 2) + lane * 16;
+#pragma unroll
+      for (int ps = 0; ps < C::APASS; ++ps) {
+        if (!((ok0 >> ps) & 1u)) continue;
+        u32x4* pp = reinterpret_cast<u32x4*>(sa + ps * (32 * LD * 2));
+        const u32x4 r = *pp;
+        const float* tb = tab + tg0[ps] + cb0 + chunk8;
+        const f32x4 sA = *reinterpret_cast<const f32x4*>(tb), sB = *reinterpret_cast<const f32x4*>(tb + 4);
+        const f32x4 hA = *reinterpret_cast<const f32x4*>(tb + Cc), hB = *reinterpret_cast<const f32x4*>(tb + Cc + 4);
+        const float sc[8] = {sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3]};
+        const float sh[8] = {hA[0], hA[1], hA[2], hA[3], hB[0], hB[1], hB[2], hB[3]};
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float y0 = __uint_as_float(r[i] << 16), y1 = __uint_as_float(r[i] & 0xffff0000u);
+          const float z0 = y0 * sc[2 * i] + sh[2 * i], z1 = y1 * sc[2 * i + 1] + sh[2 * i + 1];
+          o[i] = pack2bf(z0 > 0.f ? z0 : slope * z0, z1 > 0.f ? z1 : slope * z1);
+        }
+        *pp = o;
+      }
+    };
+    wait_older();
+    xform();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int s = 0; s < steps; ++s) {
+      __builtin_amdgcn_s_barrier();                                   // consumers may read this step's (transformed) stage
+      next();                                                         // k-step s + 2 into the stage that became free
+      wait_older();                                                   // k-step s + 1 has landed:
+      xform();                                                        // ... transform it under the consumers' k-step s
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
+  if (!BNB && p.in_aux) __builtin_amdgcn_s_barrier();                 // (consumer side of the loaders' table barrier)
 
   const int wch = (C::WCH == 2) ? (wave / C::WPIX) : 0;
   const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
@@ -911,8 +990,13 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       // BatchNorm-backward statistics (x2 only): one fragment pair at a time - its saved conv outputs y (16 bytes per pixel
       // column) first, the gradient stores next, then the arithmetic with the pair's 24 table values; nothing of a pair
       // outlives its iteration (the round-2 form kept four column chunks and four tables alive and went to scratch)
-      long long poff[FN];
-      igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
+      int poff[FN];                      // element offsets fit 31 bits (launcher), -1: row past M
+      {
+        long long po64[FN];
+        igemm_pixel_offsets<FN>(p, lane, wpix, m0, po64);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) poff[j] = po64[j] < 0 ? -1 : (int)(po64[j] + p.obase[z]);
+      }
       const int g = lane >> 4;
       const bf16_t* by = reinterpret_cast<const bf16_t*>(p.bn_y);
       bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
@@ -926,35 +1010,33 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           yr[j] = u32x4{0u, 0u, 0u, 0u};
-          if (poff[j] >= 0 && chok) yr[j] = *reinterpret_cast<const u32x4*>(by + poff[j] + p.obase[z] + ch);
+          if (poff[j] >= 0 && chok) yr[j] = *reinterpret_cast<const u32x4*>(by + poff[j] + ch);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           if (poff[j] < 0 || !chok) continue;
           const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
                               acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
-          st8(outp + poff[j] + p.obase[z] + ch, v);
+          st8(outp + poff[j] + ch, v);
         }
         if (chok) {
-          float sc[8], sh[8], mu[8];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(aux + cc + 4 * h), a1 = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc + 4 * h);
-            const f32x4 a2 = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h);
+          for (int h = 0; h < 2; ++h) {        // the pair's two fragments one after the other: 12 table values alive, not 24
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + cc + 4 * h), sh = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc + 4 * h);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[4 * h + r] = a0[r]; sh[4 * h + r] = a1[r]; mu[4 * h + r] = a2[r]; }
-          }
+            for (int j = 0; j < FN; ++j) {
+              if (poff[j] < 0) continue;
 #pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            if (poff[j] < 0) continue;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const float yv = (c & 1) ? __uint_as_float(yr[j][c >> 1] & 0xffff0000u) : __uint_as_float(yr[j][c >> 1] << 16);
-              const float v = acc[2 * k + (c >> 2)][j][c & 3];
-              const float zz = yv * sc[c] + sh[c];
-              const float gz = zz > 0.f ? v : p.bn_slope * v;
-              S1[k][c] += gz;
-              S2[k][c] += gz * (yv - mu[c]);
+              for (int r = 0; r < 4; ++r) {
+                const int c = 4 * h + r;
+                const float yv = (c & 1) ? __uint_as_float(yr[j][c >> 1] & 0xffff0000u) : __uint_as_float(yr[j][c >> 1] << 16);
+                const float v = acc[2 * k + h][j][r];
+                const float zz = yv * sc[r] + sh[r];
+                const float gz = zz > 0.f ? v : p.bn_slope * v;
+                S1[k][c] += gz;
+                S2[k][c] += gz * (yv - mu[r]);
+              }
             }
           }
         }

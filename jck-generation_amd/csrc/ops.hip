@@ -31,6 +31,7 @@ static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wa
 // +0.3..3 % per gather-GEMM (tests/_mb2.py igemm_prio 0 1 ...)
 static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neutral (1.905 vs 1.907 ms)
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
+static int g_conv_in = env_int("JCK_CONV_IN", 1);                // 0: the jck_conv_*_in entry points always take the unfused route
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
@@ -46,7 +47,7 @@ static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 // slabs - it is the faster one (1.82-1.83 vs 1.86 ms, tests/_ab.sh JCK_WGRAD_HALO=0 / 1, two rounds)
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 0);
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"conv_in", &g_conv_in}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -119,9 +120,13 @@ extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, 
 // ---------------------------------------------------------------------------------------------------------
 // gather-GEMM dispatch
 // ---------------------------------------------------------------------------------------------------------
+// internal: the launch asked for the fused input transform (IgemmParams::in_aux) and the kernel the dispatch picked has none -
+// nothing was launched; the *_in entry points then materialise the activation and launch again without it
+#define JCK_UNFUSED 1000
 template <class P, int BCH, int BPIX, int NSUB>
 static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   typedef IgemmCfg<P, BCH, BPIX> C;
+  if (p.in_aux) return JCK_UNFUSED;
   constexpr int variant = (P::IS_F32 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
   ProfScope prof(variant, p.flops, st);
   auto kern = p.bn_y ? igemm_kernel<P, BCH, BPIX, NSUB, 2, true> : igemm_kernel<P, BCH, BPIX, NSUB, 2, false>;
@@ -150,11 +155,16 @@ template <int BCH, int BPIX, int NSTG, bool WS = false, int NCW = 4>
 static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2 + 64 + 4096;     // + arrival flag and partial rows of bnstat.hpp
   constexpr int variant = BPIX == 256 ? 20 : BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
+  if (p.in_aux) return JCK_UNFUSED;
   ProfScope prof(variant, p.flops, st);
-  auto kern = p.bn_y ? igemm_dma_kernel<BCH, BPIX, NSTG, true, WS, NCW> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>;
+  // the 256-pixel tile has no slot-row BatchNorm-backward form (its shared epilogue went to scratch, 5 VGPRs): the dispatch sends
+  // those launches to the 128-pixel tiles
+  constexpr bool HAS_BNB = BPIX != 256;
+  if (!HAS_BNB && p.bn_y) JCK_FAIL(JCK_E_ARG, "igemm: internal - BatchNorm-backward rows on the 256-pixel tile");
+  auto kern = (HAS_BNB && p.bn_y) ? igemm_dma_kernel<BCH, BPIX, NSTG, HAS_BNB, WS, NCW> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, true, WS, NCW>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, HAS_BNB, WS, NCW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
@@ -175,16 +185,21 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
 // persistent wave-specialised form: at most `cap` workgroups (what the chip holds at this tile's LDS footprint) walk the tiles
 template <int BCH, int BPIX, int NCW>
 static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2 + 64 + 8 * NCW * BCH;   // + arrival flag, flush counter and 2 x [NCW][2][BCH / 2] partial rows of bnstat.hpp
+  constexpr int LDSB0 = 3 * (BCH + BPIX) * IG_BK * 2 + 64 + 8 * NCW * BCH;   // + arrival flag, flush counter and 2 x [NCW][2][BCH / 2] partial rows of bnstat.hpp
   constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
+  // fused input transform: + the [groups][scale | shift][C] tables
+  // (they take the place of the exact-sum scratch when that is not in use: same footprint, same workgroups per CU, same rows)
+  const int tab_bytes = p.in_aux ? p.in_groups * 2 * (1 << p.logC) * 4 : 0;
+  const int LDSB = LDSB0 + std::max(0, tab_bytes - (p.bnj.xs ? 0 : 8 * NCW * BCH));
+  if (p.in_aux && (p.bn_y || p.act_row_elems || LDSB > 160 * 1024)) return JCK_UNFUSED;
   ProfScope prof(variant, p.flops, st);
   auto kern = p.bn_y ? igemm_dma_persist_kernel<BCH, BPIX, true, NCW> : igemm_dma_persist_kernel<BCH, BPIX, false, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, true, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, false, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -243,7 +258,7 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     auto grp_ok = [&](int bpix) { return p.bn_group_rows == 0 || p.bn_group_rows % bpix == 0; };
     if (x2 && !grp_ok(64)) persist &= ~2;
     const bool groups_ok = x2 ? grp_ok(256) : (!p.stats || (p.bn_y ? (p.bn_group_rows == 0 || p.bn_group_rows % 256 == 0) : p.logOHW >= 5));
-    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0)
+    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0 && (!p.bn_y || (persist & 1)))
       return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
                            : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
@@ -345,7 +360,8 @@ static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, 
 
 static int conv_down_impl(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                           int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float bn_slope,
-                          int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr) {
+                          int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr,
+                          const float* in_aux = nullptr, int in_group_images = 0, float in_slope = 0.f) {
   const int cbp = jck_pad_chan(Cb);
   if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
@@ -369,6 +385,11 @@ static int conv_down_impl(int prec, const void* big, const void* w, void* small_
     p.bn_group_rows = gi > 0 ? gi * OH * OW : 0;
     if (!is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
     bn_group_images = gi;
+  }
+  if (in_aux) {
+    if (cbp != Cb || Cb < 64) return JCK_UNFUSED;
+    p.in_aux = in_aux; p.in_slope = in_slope; p.in_group_images = in_group_images;
+    p.in_groups = in_group_images > 0 ? N / in_group_images : 1;
   }
   if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH) &&
       (bn_group_images == 0 || (bn_group_images * OH * OW) % (16 * 4 * IMG_GPW) == 0))
@@ -397,7 +418,8 @@ extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, voi
 
 static int conv_up_impl(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                         int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float bn_slope,
-                        int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr) {
+                        int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr,
+                        const float* in_aux = nullptr, int in_group_images = 0, float in_slope = 0.f) {
   const int cbp = jck_pad_chan(Cb);
   if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
@@ -407,6 +429,11 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   p.act = small_in; p.w = w; p.out = big_out; p.stats = stats;
   p.M = N * Hs * Ws; p.NchStore = cbp; p.logC = ilog2(Cs); p.K = 4 << p.logC;
   p.H = Hs; p.W = Ws; p.logOW = ilog2(Ws); p.logOHW = ilog2(Hs * Ws); p.sy = p.sx = 1; p.ntaps = 4;
+  if (in_aux) {
+    if (cbp == 4 || Cs < 64) return JCK_UNFUSED;
+    p.in_aux = in_aux; p.in_slope = in_slope; p.in_group_images = in_group_images;
+    p.in_groups = in_group_images > 0 ? N / in_group_images : 1;
+  }
   if (cbp == 4) {
     // 3/4-channel output: one launch, the four output parities are the 16 MFMA rows, 9 input offsets as taps; every
     // workgroup then writes whole contiguous output rows instead of interleaved 8-byte pixels
@@ -462,6 +489,53 @@ extern "C" int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, 
   if (!bn_y) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: bn_y is NULL");
   if (jck_pad_chan(Cb) == 4) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: not available for <=4-channel outputs");
   return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, bn_y, bn_aux, slope, group_images, stream);
+}
+
+// ---- convolutions that consume a BatchNorm'd, activated tensor WITHOUT that tensor being written (round 3) ----
+// y_in / in_aux: the producer's raw conv output and its [groups][4 * C] tables (jck_bn_finalize*); the launch computes the
+// convolution of a = act(scale * y_in + shift) - what jck_bn_act_fwd_grouped(y_in, in_aux, in_slope) would have written, bit for
+// bit - by transforming the operand in LDS (igemm.hpp, IgemmParams::in_aux).  in_group_images: images per BatchNorm group of the
+// INPUT (N % in_group_images == 0).  Output statistics per group of `group_images` images as in the *_grouped entry points.
+// When the kernel the dispatch picks for this shape has no such transform, a is written to a_buf (must then be non-NULL) by the
+// stand-alone pass and the plain launch runs; *a_written (optional) reports which of the two happened.
+template <class F>
+static int conv_in_fallback(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
+                            int* a_written, int N, long long rows_per_image, int C, void* stream, int rc, F&& plain) {
+  if (a_written) *a_written = 0;
+  if (rc != JCK_UNFUSED) return rc;
+  if (!a_buf) JCK_FAIL(JCK_E_ARG, "conv_*_in: this shape has no fused input transform and a_buf is NULL");
+  const int groups = in_group_images > 0 ? N / in_group_images : 1;
+  JCK_TRY(jck_bn_act_fwd_grouped(prec, y_in, in_aux, in_slope, a_buf, (long long)(N / groups) * rows_per_image, C, groups, stream));
+  if (a_written) *a_written = 1;
+  return plain();
+}
+extern "C" int jck_conv_down_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
+                                int* a_written, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb, int Wb,
+                                int Cb, int Cs, int group_images, void* stream) {
+  if (!y_in || !in_aux) JCK_FAIL(JCK_E_ARG, "conv_down_in: y_in / in_aux is NULL");
+  if (group_images < 1 || N % group_images || in_group_images < 0 || (in_group_images && N % in_group_images))
+    JCK_FAIL(JCK_E_ARG, "conv_down_in: N must be a multiple of both group sizes");
+  const int rc = (g_conv_in && prec == JCK_PREC_BF16)
+                     ? conv_down_impl(prec, y_in, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream,
+                                      group_images, nullptr, in_aux, in_group_images, in_slope)
+                     : JCK_UNFUSED;
+  return conv_in_fallback(prec, y_in, in_aux, in_group_images, in_slope, a_buf, a_written, N, (long long)Hb * Wb, Cb, stream, rc, [&]() {
+    return conv_down_impl(prec, a_buf, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, group_images);
+  });
+}
+extern "C" int jck_conv_up_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
+                              int* a_written, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs, int Ws,
+                              int Cs, int Cb, int group_images, void* stream) {
+  if (!y_in || !in_aux) JCK_FAIL(JCK_E_ARG, "conv_up_in: y_in / in_aux is NULL");
+  if (group_images < 1 || N % group_images || in_group_images < 0 || (in_group_images && N % in_group_images))
+    JCK_FAIL(JCK_E_ARG, "conv_up_in: N must be a multiple of both group sizes");
+  const int rc = (g_conv_in && prec == JCK_PREC_BF16)
+                     ? conv_up_impl(prec, y_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream,
+                                    group_images, nullptr, in_aux, in_group_images, in_slope)
+                     : JCK_UNFUSED;
+  return conv_in_fallback(prec, y_in, in_aux, in_group_images, in_slope, a_buf, a_written, N, (long long)Hs * Ws, Cs, stream, rc, [&]() {
+    return conv_up_impl(prec, a_buf, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, group_images);
+  });
 }
 
 static int g1_fwd_impl(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,

@@ -52,6 +52,8 @@ PROTOS = {
     "jck_conv_up_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
     "jck_conv_down_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jck_conv_up_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jck_conv_down_in": (i32, [i32, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "jck_conv_up_in": (i32, [i32, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jck_conv_down_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
     "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -477,6 +477,66 @@ def test_grouped_forward_statistics(G, cfg):
         G.check(rows[k, :, 1].sum(0), (r * r).sum((0, 2, 3)), 2e-3, f"sum of squares, group {k}")
 
 
+@pytest.mark.parametrize("cfg", [("down", 96, 32, 64, 128, 32, 0.2), ("down", 192, 16, 128, 256, 64, 0.2), ("down", 24, 8, 256, 512, 8, 0.2),
+                                 ("up", 96, 16, 256, 128, 32, 0.0), ("up", 48, 8, 512, 256, 48, 0.0), ("down", 768, 8, 256, 512, 256, 0.2),
+                                 ("down", 6, 16, 128, 256, 2, 0.2), ("up", 10, 4, 512, 256, 5, 0.0), ("down", 256, 32, 64, 128, 64, 0.2),
+                                 ("up", 48, 16, 128, 64, 16, 0.0), ("down", 24, 8, 256, 512, 8, -1.0)])
+def test_conv_with_fused_batchnorm_input(G, cfg):
+    """jck_conv_down_in / jck_conv_up_in (the nn.BatchNorm2d + activation between two convolutions applied to the gathered operand
+    in LDS, reference model/DCGAN.py:30-33,62-65): output and statistic rows must be BIT-identical to the unfused pair
+    jck_bn_act_fwd_grouped -> jck_conv_*_grouped, the activation must not have been written when the fused kernel ran, and the
+    output agrees with PyTorch's conv(act(scale * y + shift)).  Groups of the input (BatchNorm per batch of the batched D pass)
+    with their own tables; small shapes fall back to the stand-alone pass inside the call and say so."""
+    kind, n, hin, cin, cout, gimg, slope = cfg
+    prec = G.PREC_BF16
+    forced_fallback = slope < 0                       # (slope -1: the call's own unfused route, jck_tune "conv_in" 0)
+    slope = 0.2 if forced_fallback else slope
+    g = torch.Generator().manual_seed(33)
+    groups = n // gimg
+    y = G.rnd(torch.randn(n, cin, hin, hin, generator=g) * 1.5 + 0.3, prec)
+    aux = torch.zeros(groups, 4, cin)
+    aux[:, 0] = torch.rand(groups, cin, generator=g) + 0.5
+    aux[:, 1] = torch.randn(groups, cin, generator=g) * 0.5
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    wp = G.pack_up(w, prec) if kind == "up" else G.pack_down(w, prec)
+    y_d, aux_d = G.to_nhwc(y, prec), aux.cuda()
+    hout = hin * 2 if kind == "up" else hin // 2
+    fn_in = G.lib.jck_conv_up_in if kind == "up" else G.lib.jck_conv_down_in
+    fn_gr = G.lib.jck_conv_up_grouped if kind == "up" else G.lib.jck_conv_down_grouped
+    outs = []
+    for fused in (1, 0):
+        out = torch.empty(n, hout, hout, cout, dtype=torch.bfloat16, device="cuda")
+        stats, slots = G.stats_buf(n * hout * hout, cout)
+        stats.fill_(float("nan"))
+        a_buf = torch.full((n, hin, hin, cin), 7.0, dtype=torch.bfloat16, device="cuda")
+        if fused:
+            written = ctypes.c_int(-1)
+            G.lib.jck_tune(b"conv_in", 0 if forced_fallback else 1)
+            fn_in(prec, y_d, aux_d, gimg, slope, a_buf, ctypes.byref(written), wp, out, stats, ctypes.byref(slots), n, hin, hin, cin,
+                  cout, gimg, G.cur_stream())
+            G.lib.jck_tune(b"conv_in", 1)
+            torch.cuda.synchronize()
+            assert written.value == (1 if forced_fallback else 0), written.value      # every other shape here has the fused kernel
+            if written.value == 0:
+                assert float(a_buf.float().min()) == 7.0 and float(a_buf.float().max()) == 7.0     # never written
+        else:
+            G.lib.jck_bn_act_fwd_grouped(prec, y_d, aux_d, slope, a_buf, gimg * hin * hin, cin, groups, G.cur_stream())
+            fn_gr(prec, a_buf, wp, out, stats, ctypes.byref(slots), n, hin, hin, cin, cout, gimg, G.cur_stream())
+            torch.cuda.synchronize()
+        outs.append((out, stats[:slots.value * 2 * cout].clone(), slots.value, a_buf))
+    (o1, s1, n1, _), (o0, s0, n0, a0) = outs
+    assert n1 == n0 and torch.equal(o1.view(torch.int16), o0.view(torch.int16)), "fused output differs from the unfused pair"
+    assert torch.equal(s1.view(torch.int32), s0.view(torch.int32)), "statistic rows differ"
+    sc = aux[:, 0].repeat_interleave(gimg, 0)[:, :, None, None]
+    sh = aux[:, 1].repeat_interleave(gimg, 0)[:, :, None, None]
+    z = y * sc + sh
+    a = G.rnd(torch.where(z > 0, z, slope * z), prec)
+    G.check(G.from_nhwc(a0), a, 1e-2, "activation")
+    wr = G.rnd(w, prec)
+    ref = F.conv_transpose2d(a, wr, None, 2, 1) if kind == "up" else F.conv2d(a, wr, None, 2, 1)
+    G.check(G.from_nhwc(o1), ref, G.TOL[prec], "conv of the activation")
+
+
 # ---- BatchNorm statistics as exact integer-atomic sums (csrc/bnstat.hpp): the `_x` entry points -------------------------------
 def _bn_job(G, c, groups, gimg, **kw):
     """jck_bn_job over a zeroed accumulator buffer; keeps the tensors it points at alive on the returned object."""
