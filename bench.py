@@ -9,8 +9,9 @@ reference), 64x64x3 synthetic images, batch 256 per GPU, on the MI355X-native HI
 One process per GPU; data parallel = replicate, shard the batch, all-reduce D and G gradients with RCCL
 (torch.distributed "nccl").  Rank 0 prints ONE JSON line.
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM, including the RNG draws
-(instance noise x2, z, GP alpha), four D passes, one G pass, five backward chains, two Adam steps.  The step is replayed
-from captured hipGraphs (one host call per step segment; JCK_GRAPH=0 launches every kernel from the host instead).
+(instance noise x2, z, GP alpha), four D passes, one G pass, five backward chains, two Adam steps.  Every kernel is
+launched from the host on two HIP streams (JCK_GRAPH=1 replays the step from captured hipGraphs instead: one host call per
+step segment, but a captured step is one stream - `launch_mode` and `host_enqueue_ms_per_step` say which ran).
 With one GPU the same line carries `secondary.cgan`: BASELINE.json configs[3] (CGAN, 10-class labels, batch 256, the
 penalty back-propagated) measured the same way in the same process.
 """

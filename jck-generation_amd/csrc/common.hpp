@@ -28,6 +28,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {                  // RNE, NaN s
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
+// the same two roundings as ONE v_cvt_pk_bf16_f32 (the scalar form above compiles to two conversions and an SDWA or)
+__device__ __forceinline__ unsigned pack2bf_pk(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }

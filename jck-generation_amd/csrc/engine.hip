@@ -159,6 +159,11 @@ struct jck_engine {
   bool bucket_ready = false;            // evBucket was recorded in this step's PHASE_D_LOSS (gradients of conv4.weight .. conv5.weight final)
   bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
   bool bn2 = false;                     // exact-sum statistics accumulated by the producing launch (bnstat.hpp); JCK_BN2=1
+  // BatchNorm + activation of layer i applied by the convolution that consumes it (jck_conv_*_in; JCK_BNF=0 disables): the
+  // activation tensor is then written only where the backward reads it (weight gradients, CGAN's double backward) - on
+  // fwd_side, beside the forward chain - and not at all in the G phase's pass through D (its weight gradients are dead)
+  bool bnf = false, fwd_need_a = true;
+  hipStream_t fwd_side = nullptr;
   XsRegion g_xr;
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
@@ -367,6 +372,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   // but measured 4-6 % SLOWER at batch 256 (1.97-1.99 vs 1.85-1.89 ms): opt-in, JCK_BN2=1.
   e->bn2 = getenv("JCK_BN2") && atoi(getenv("JCK_BN2")) != 0;
   if (e->bn2) e->fuse_bnbwd = false;
+  e->bnf = getenv("JCK_BNF") && atoi(getenv("JCK_BNF")) != 0 && !e->bn2 && prec == JCK_PREC_BF16;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
@@ -539,12 +545,25 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
       in = D.a[i];
       continue;
     }
+    // layer i - 1's BatchNorm + LeakyReLU inside this convolution's operand path when nothing else needs a[i - 1] now
+    const bool fuse = e->bnf && i > 0 && (!e->fwd_need_a || e->fwd_side);
+    if (fuse) {
+      int wrote = 0;
+      if (e->fwd_need_a) HIPCHK(hipEventRecord(e->evW[i - 1], st));
+      JCK_TRY(jck_conv_down_in(e->prec, D.y[i - 1], D.bn[i - 1].aux, 0, LRELU, D.a[i - 1], &wrote, e->d_down[i], D.y[i], D.bn[i].stats,
+                               &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
+      if (!wrote && e->fwd_need_a) {            // for the weight gradient of layer i: beside the forward chain
+        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i - 1], 0));
+        JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i - 1], D.bn[i - 1].aux, LRELU, D.a[i - 1], (long long)B * hb * hb, TT.D_CB[i], e->fwd_side));
+      }
+    } else
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
-    JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
+    const bool next_fused = e->bnf && i + 1 < TT.NS && (!e->fwd_need_a || e->fwd_side);
+    if (!next_fused) JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
     in = D.a[i];
   }
   return JCK_OK;
@@ -706,12 +725,34 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
       in = at(S.a[i], (size_t)g0 * rows * cs);
       continue;
     }
+    // layer i - 1's BatchNorm + LeakyReLU inside this convolution's operand path (every group with its own table); a[i - 1] is
+    // then written beside the forward chain, for the weight gradient of layer i
+    const bool fuse = e->bnf && i > 0 && (!e->fwd_need_a || e->fwd_side);
+    if (fuse) {
+      const int cl = TT.D_CS[i - 1];
+      const long long rows_in = (long long)B * hb * hb;
+      void* y_in = at(S.y[i - 1], (size_t)g0 * rows_in * cl);
+      void* a_in = at(S.a[i - 1], (size_t)g0 * rows_in * cl);
+      const float* aux_in = S.aux[i - 1] + (size_t)g0 * 4 * cl;
+      int wrote = 0;
+      if (e->fwd_need_a) HIPCHK(hipEventRecord(e->evW[i - 1], st));
+      JCK_TRY(jck_conv_down_in(e->prec, y_in, aux_in, B, LRELU, a_in, &wrote, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots,
+                               n * B, hb, hb, TT.D_CB[i], cs, B, st));
+      // (DCGAN: the penalty group - the third - has no weight gradient: its activations are never read)
+      const int n_act = e->family == 0 ? std::max(0, std::min(g0 + n, 2) - g0) : n;
+      if (!wrote && e->fwd_need_a && n_act > 0) {
+        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i - 1], 0));
+        JCK_TRY(jck_bn_act_fwd_grouped(e->prec, y_in, aux_in, LRELU, a_in, rows_in, cl, n_act, e->fwd_side));
+      }
+    } else
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, B, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
-    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
-                                   at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
+    const bool next_fused = e->bnf && i + 1 < TT.NS && (!e->fwd_need_a || e->fwd_side);
+    if (!next_fused)
+      JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
+                                     at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
     in = at(S.a[i], (size_t)g0 * rows * cs);
   }
   return JCK_OK;
@@ -950,8 +991,20 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
     JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]),
                             e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset,
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
-    JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
-    if (i < TT.NS - 1)
+    // BatchNorm + ReLU of layer i inside the next ConvTranspose's operand path; a[i] itself (the weight gradient of that layer
+    // reads it in the G phase) is written beside the chain.  The last layer feeds the thin image kernel: always written here.
+    const bool fuse = e->bnf && i < TT.NS - 1 && e->fwd_side;
+    if (!fuse) JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
+    if (fuse) {
+      int wrote = 0;
+      HIPCHK(hipEventRecord(e->evW[i], st));
+      JCK_TRY(jck_conv_up_in(e->prec, e->g_y[i], e->g_bn[i].aux, 0, 0.f, e->g_a[i], &wrote, e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats,
+                             &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
+      if (!wrote) {
+        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i], 0));
+        JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, e->fwd_side));
+      }
+    } else if (i < TT.NS - 1)
       JCK_TRY(jck_conv_up_grouped(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
     else                                             // last ConvTranspose + tanh -> the image
       JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
@@ -1041,12 +1094,11 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
-  // weight gradients beside the dgrad chain on a second stream: +8 % for DCGAN.  CGAN (~280 kernels per step, most of them
-  // small) measured the same with and without it (3.478 vs 3.456 ms eager) and WORSE with it when the step is replayed from a
-  // hipGraph (3.82 ms: a graph with parallel branches costs ~7 us of host time per node and runs slower; the linear graph
-  // costs 0.18 ms per replay) - so CGAN keeps everything on one stream unless JCK_CGAN_SIDE=1.
+  // weight gradients beside the dgrad chain on a second stream: +8 % for DCGAN.  CGAN: +1.4 % since round 3 (2.886 vs 2.929 ms eager,
+  // tests/_ab.sh; in round 2 its ~280 launches per step were enqueue-bound and the second stream bought nothing, 3.478 vs 3.456) -
+  // on unless JCK_CGAN_SIDE=0.  A captured step keeps everything on one stream either way (below).
   static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
-  static const bool cgan_side = getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) != 0;
+  static const bool cgan_side = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
   // Under a stream capture everything stays on the capturing stream: a hipGraph with parallel branches makes the ROCm 7.2
   // runtime keep per-graph side streams, costs ~7 us of host time per node at launch, ran slower than the linear graph for
   // CGAN, and its hipGraphLaunch reads past the end of the graph's stream pool whenever two of those streams share the launch
@@ -1054,6 +1106,10 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   // any non-linear graph).  Same kernels, same order per stream as the eager schedule - bitwise the same results.
   const bool par = e->overlap && !e->capturing;
   hipStream_t sA = (par && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
+  // where a forward pass writes the activations only its backward reads (e->bnf).  CGAN's double backward reads them on the main
+  // stream: its D phase keeps the stand-alone passes
+  e->fwd_side = cg ? nullptr : sA;
+  e->fwd_need_a = true;
   const bool ov_g = par, ov_gp = par && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
@@ -1256,7 +1312,9 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
+      e->fwd_need_a = false;            // D's weight gradients from this pass are dead: only the head reads an activation
       JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st));
+      e->fwd_need_a = true;
       JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
       JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr));
@@ -1428,6 +1486,7 @@ extern "C" int jck_engine_sample(jck_engine* e, const float* z, const int64_t* l
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (n < 1 || n > e->B) JCK_FAIL(JCK_E_ARG, "sample: n must be in [1, batch]");
   hipStream_t st = (hipStream_t)stream;
+  e->fwd_side = nullptr;                // (sampling: one stream, every activation where the plain forward leaves it)
   JCK_TRY(g_forward(e, z, labels, n, st));
   return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, TT.HW, st);
 }

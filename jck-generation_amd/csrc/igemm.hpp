@@ -715,14 +715,14 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     unsigned rowoff[C::APASS], wrowoff[C::WPASS];
     int riy[C::APASS], rix[C::APASS];
     const bool bnf = !BNB && p.in_aux != nullptr;     // (dgrad launches with backward statistics never carry it)
-    int tgoff[C::APASS];                              // bnf: this row's table (its image's BatchNorm group), in floats
+    unsigned tgbits = 0u;                             // bnf: the BatchNorm group (< 4) of this lane's row in pass ps, 2 bits each
     auto setup = [&](int L) {
       locate(L);
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const int m = m0 + ps * 32 + lrow;
         const int n = m >> p.logOHW;
-        tgoff[ps] = (bnf && p.in_group_images > 0) ? (n / p.in_group_images) * 2 * Cc : 0;
+        if (bnf && p.in_group_images > 0) tgbits = (tgbits & ~(3u << (2 * ps))) | (((unsigned)(n / p.in_group_images) & 3u) << (2 * ps));
         const int rem = m & ((1 << p.logOHW) - 1);
         const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
         rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC)) * 2u;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     // (bit ps), the first channel of the k-step, the rows' tables, the stage; hist0 = the older of the two k-steps in flight
     unsigned ok_new = 0u, ok0 = 0u, ok1 = 0u;
     int cb_new = 0, cb0 = 0, cb1 = 0, st_new = 0, st0 = 0, st1 = 0;
-    int tg_new[C::APASS], tg0[C::APASS], tg1[C::APASS];
+    unsigned tg_new = 0u, tg0 = 0u, tg1 = 0u;
     auto issue = [&](int kc, int stage) {
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
@@ -755,14 +755,13 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       const int tp = p.tap[z][t];
       const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
       const unsigned toffb = (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
-      ok_new = 0u; cb_new = kbase & (Cc - 1); st_new = stage;
+      ok_new = 0u; cb_new = kbase & (Cc - 1); st_new = stage; tg_new = tgbits;
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
                                                  (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
         ok_new |= (ok ? 1u : 0u) << ps;
-        tg_new[ps] = tgoff[ps];
       }
     };
     // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads
@@ -771,9 +770,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     auto next = [&]() {
       issue(kq, slot);
       if (bnf) {
-        ok0 = ok1; cb0 = cb1; st0 = st1; ok1 = ok_new; cb1 = cb_new; st1 = st_new;
-#pragma unroll
-        for (int ps = 0; ps < C::APASS; ++ps) { tg0[ps] = tg1[ps]; tg1[ps] = tg_new[ps]; }
+        ok0 = ok1; cb0 = cb1; st0 = st1; tg0 = tg1; ok1 = ok_new; cb1 = cb_new; st1 = st_new; tg1 = tg_new;
       }
       slot = slot == 2 ? 0 : slot + 1;
       if (kq + 1 < nk) { ++kq; return; }
@@ -813,24 +810,50 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     // consumer waves before the barrier that follows
     auto xform = [&]() {
       unsigned char* sa = lds + st0 * STG_BYTES + (wave & 3) * (8 * LD * 2) + BCH * (LD * 2) + lane * 16;
-#pragma unroll
-      for (int ps = 0; ps < C::APASS; ++ps) {
-        if (!((ok0 >> ps) & 1u)) continue;
-        u32x4* pp = reinterpret_cast<u32x4*>(sa + ps * (32 * LD * 2));
-        const u32x4 r = *pp;
-        const float* tb = tab + tg0[ps] + cb0 + chunk8;
+      // all reads first, then the arithmetic, then all writes: the pieces alias as far as the compiler can tell, and a
+      // read -> compute -> write chain per piece (the first form) cost one LDS round trip per piece on the barrier's critical path
+      const int t0 = (int)(tg0 & 3u);
+      float sc[8], sh[8];
+      auto table = [&](int tg, float (&a)[8], float (&b)[8]) {
+        const float* tb = tab + tg * 2 * Cc + cb0 + chunk8;
         const f32x4 sA = *reinterpret_cast<const f32x4*>(tb), sB = *reinterpret_cast<const f32x4*>(tb + 4);
         const f32x4 hA = *reinterpret_cast<const f32x4*>(tb + Cc), hB = *reinterpret_cast<const f32x4*>(tb + Cc + 4);
-        const float sc[8] = {sA[0], sA[1], sA[2], sA[3], sB[0], sB[1], sB[2], sB[3]};
-        const float sh[8] = {hA[0], hA[1], hA[2], hA[3], hB[0], hB[1], hB[2], hB[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = sA[i]; a[4 + i] = sB[i]; b[i] = hA[i]; b[4 + i] = hB[i]; }
+      };
+      table(t0, sc, sh);
+      auto apply = [&](const u32x4 v, const float (&a)[8], const float (&b)[8]) {
         u32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float y0 = __uint_as_float(r[i] << 16), y1 = __uint_as_float(r[i] & 0xffff0000u);
-          const float z0 = y0 * sc[2 * i] + sh[2 * i], z1 = y1 * sc[2 * i + 1] + sh[2 * i + 1];
-          o[i] = pack2bf(z0 > 0.f ? z0 : slope * z0, z1 > 0.f ? z1 : slope * z1);
+          const float y0 = __uint_as_float(v[i] << 16), y1 = __uint_as_float(v[i] & 0xffff0000u);
+          const float z0 = y0 * a[2 * i] + b[2 * i], z1 = y1 * a[2 * i + 1] + b[2 * i + 1];
+          // act(z) = z > 0 ? z : slope * z (bn_act_fwd_kernel) as max(z, slope * z): the same bits for 0 <= slope < 1 (zeros
+          // keep their sign either way), one VALU operation instead of a compare and a select
+          o[i] = pack2bf_pk(fmaxf(z0, slope * z0), fmaxf(z1, slope * z1));
         }
-        *pp = o;
+        return o;
+      };
+      constexpr int XB = C::APASS < 4 ? C::APASS : 4;        // pieces in flight (registers: the 256-pixel tile has 8 per lane)
+#pragma unroll
+      for (int p0 = 0; p0 < C::APASS; p0 += XB) {
+        u32x4 r[XB];
+#pragma unroll
+        for (int q = 0; q < XB; ++q) r[q] = *reinterpret_cast<const u32x4*>(sa + (p0 + q) * (32 * LD * 2));
+#pragma unroll
+        for (int q = 0; q < XB; ++q) {
+          const int tgp = (int)((tg0 >> (2 * (p0 + q))) & 3u);
+          if (tgp == t0) r[q] = apply(r[q], sc, sh);
+          else {                                        // a row of another BatchNorm group (tiles at a group border only)
+            float s2[8], h2[8];
+            table(tgp, s2, h2);
+            r[q] = apply(r[q], s2, h2);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < XB; ++q)
+          if ((ok0 >> (p0 + q)) & 1u) *reinterpret_cast<u32x4*>(sa + (p0 + q) * (32 * LD * 2)) = r[q];
+        if (p0 + XB < C::APASS) __builtin_amdgcn_sched_barrier(0);
       }
     };
     wait_older();

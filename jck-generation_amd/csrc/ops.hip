@@ -191,7 +191,7 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   // (they take the place of the exact-sum scratch when that is not in use: same footprint, same workgroups per CU, same rows)
   const int tab_bytes = p.in_aux ? p.in_groups * 2 * (1 << p.logC) * 4 : 0;
   const int LDSB = LDSB0 + std::max(0, tab_bytes - (p.bnj.xs ? 0 : 8 * NCW * BCH));
-  if (p.in_aux && (p.bn_y || p.act_row_elems || LDSB > 160 * 1024)) return JCK_UNFUSED;
+  if (p.in_aux && (p.bn_y || p.act_row_elems || LDSB > 160 * 1024 || p.in_groups > 4)) return JCK_UNFUSED;   // (2 bits of group per row)
   ProfScope prof(variant, p.flops, st);
   auto kern = p.bn_y ? igemm_dma_persist_kernel<BCH, BPIX, true, NCW> : igemm_dma_persist_kernel<BCH, BPIX, false, NCW>;
   static bool attr_done = false;

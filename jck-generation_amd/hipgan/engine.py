@@ -108,12 +108,13 @@ class DcganEngine:
         self.size = image_size if share is None else share.size
         self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
         self._packed_version = -1
-        # hipGraph replay of the step (JCK_GRAPH=0 disables): one captured graph per (segment, step parity, input kind)
-        # Default: on for CGAN (its step is one stream anyway: 0.18 ms of host time per step instead of 2.4), off for DCGAN, whose
-        # eager schedule overlaps the weight gradients with the dgrad chain on a second stream (+8 %) - a captured step is
-        # linear (see jck_engine_phase) and the DCGAN host is not the bottleneck (1.2 ms of enqueue for a 2.1 ms step).
-        # JCK_GRAPH=1 / 0 forces it either way.
-        self.graphs = os.environ.get("JCK_GRAPH", "1" if self.family == 1 else "0") != "0"
+        # hipGraph replay of the step (JCK_GRAPH=1 enables): one captured graph per (segment, step parity, input kind).
+        # Default: off.  A captured step is linear (see jck_engine_phase), so it gives up the second stream that runs the weight
+        # gradients beside the dgrad chain (+8 % DCGAN, +1.4 % CGAN), and the host is not the bottleneck: 1.15 ms of enqueue for
+        # DCGAN's 1.8 ms step, 1.9 ms for CGAN's 2.9 ms (round 3, tests/_ab.sh: CGAN eager 2.886 ms, replayed 2.97 ms - in round 2
+        # the eager CGAN step was enqueue-bound at 3.4 ms and the graph was its default).  Replay remains the answer when the host
+        # is busy or slow: 0.10-0.13 ms of host time per step.
+        self.graphs = os.environ.get("JCK_GRAPH", "0") != "0"
         # steps without a noise dict draw z / alpha with torch and the two instance-noise tensors INSIDE the image kernels
         # (Philox, jck_engine_set_noise_seed); JCKGAN_FAST_NOISE=0 draws them with torch.randn as round 1 did
         self.fast_noise = os.environ.get("JCKGAN_FAST_NOISE", "1") != "0"
@@ -510,7 +511,7 @@ class DcganEngine:
     def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None, graph=None,
                    generator=None, labels=None, next_real=None, next_noise=None):
         """Enqueues one full step; no host sync.  noise=None draws on the device (generator= / labels= as draw_noise takes
-        them).  graph (default: on, env JCK_GRAPH=0 disables; never with the pipeline or per-launch profiling): replay the
+        them).  graph (default: off, env JCK_GRAPH=1 enables; never with the pipeline or per-launch profiling): replay the
         step from captured hipGraphs on the engine's own stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
         optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
         env JCK_PIPELINE=1 enables): run the G phase - with G's gradient all-reduce - on a second stream so that the next

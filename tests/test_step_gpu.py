@@ -256,6 +256,26 @@ def test_exact_sum_statistics_at_full_size(prec, tol, monkeypatch):
         assert torch.equal(v, eng2.arenas[k]), k
 
 
+@pytest.mark.parametrize("env", [{}, {"JCK_BATCHED": "0"}])
+def test_batchnorm_applied_in_the_consuming_gemm_gives_the_same_bits(env, monkeypatch):
+    """JCK_BNF=1 (bf16): every BatchNorm + (Leaky)ReLU between two convolutions is applied by the CONSUMING gather-GEMM to its
+    operand in LDS (jck_conv_*_in; reference model/DCGAN.py:30-33,62-65) and the activation tensors are written only for the
+    backward, beside the forward chain (never in the G phase's pass through D).  The transform reproduces the stand-alone
+    pass bit for bit, so two steps must leave exactly the weights, moments, statistics and scalars of the default schedule."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    runs = []
+    for bnf in ("0", "1"):
+        monkeypatch.setenv("JCK_BNF", bnf)
+        orc, eng, out = _run(64, 2, "bf16")
+        torch.cuda.synchronize()
+        runs.append(([o[1] for o in out], {k: v.clone() for k, v in eng.arenas.items()}))
+    (s0, a0), (s1, a1) = runs
+    assert s0 == s1, (s0, s1)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k
+
+
 def test_batched_schedule_with_a_non_power_of_two_batch():
     """Batch 24 (ragged last batches are multiples of 8 for CIFAR's 50000 = 195*256 + 80): the batched 3B D pass with groups
     of 24 images - tiles, statistic slots and BatchNorm groups must still line up."""
