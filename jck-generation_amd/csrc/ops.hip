@@ -1373,7 +1373,7 @@ extern "C" int jck_label_embed_fwd(int prec, const int64_t* labels, const float*
 extern "C" int jck_label_embed_bwd_tiled(int prec, const void* gc, int ld, int col0, const float* pre, const int64_t* labels, float slope,
                                          int B, int NI, int NO, float* dW, float* db, int label_period, void* stream) {
   if (label_period < 0 || (label_period > 0 && B % label_period)) JCK_FAIL(JCK_E_ARG, "label_embed: rows are not a multiple of the label period");
-  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + cdiv(NO, 64)), dim3(256), (size_t)B * (sizeof(float) + sizeof(int)), (hipStream_t)stream,
+  DISPATCH_T(prec, hipLaunchKernelGGL(label_embed_bwd_kernel<T>, dim3(NI + cdiv(NO, 16)), dim3(256), (size_t)B * (sizeof(float) + sizeof(int)), (hipStream_t)stream,
                                       (const T*)gc, ld, col0, pre, (const long long*)labels, slope, B, NI, NO, dW, db, label_period));
   HIPCHK(hipGetLastError());
   return JCK_OK;
@@ -1405,7 +1405,7 @@ extern "C" int jck_dropout(int prec, const void* x, const float* mask, float sca
   return JCK_OK;
 }
 extern "C" int jck_colsum(int prec, const void* g, int B, int N, int ld, float* db, void* stream) {
-  DISPATCH_T(prec, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream, (const T*)g, B, N, ld, db));
+  DISPATCH_T(prec, hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(N, COLSUM_COLS)), dim3(256), 0, (hipStream_t)stream, (const T*)g, B, N, ld, db));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
