@@ -220,6 +220,10 @@ int jck_axpy_noise(int prec, const void* x, const float* noise_nchw, float keep,
                    void* stream);
 /* x_hat = alpha*a + (1-alpha)*b                                                 train/dcgan_trainer.py:111-112 */
 int jck_interp(int prec, const void* a, const void* b, const float* alpha, void* out, int N, int HW, void* stream);
+/* jck_axpy_noise (noise_nchw given) or jck_axpy_noise_rng (rng given; exactly one of the two) followed by
+ * jck_interp(real, out, alpha) -> xhat, as one launch with the same results bit for bit (train/dcgan_trainer.py:171 then :111-113). */
+int jck_mix_interp(int prec, const void* x, const float* noise_nchw, const unsigned* rng, int tensor_id, float keep, float mix, void* out,
+                   const void* real, const float* alpha, void* xhat, int N, int HW, void* stream);
 /* scal[slot*scal_ld + n] = (||g[n]||_2 - 1)^2 (plain store per image; the caller sums the row in a fixed order - no float
  * atomics, so the logged penalty is bitwise reproducible); norms[n] optional     train/dcgan_trainer.py:125-126 */
 int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, int slot, int scal_ld, float* norms, void* stream);
@@ -249,6 +253,10 @@ int jck_head_unpack_grad(const float* dwp, int C, float* grad, int accumulate, v
  * float atomics.  Replaces aten::convolution_backward behind model/DCGAN.py:26 in train/dcgan_trainer.py:164,175,187. */
 int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4, float* grad,
                       float* ws, void* stream);
+/* the same over B rows plus, in the same launch, the input gradient alone of the B_more rows stored behind them (ds, a4 and g_a4
+ * hold B + B_more rows; the weight gradient sums the first B only): the loss groups and the penalty group of one batched D pass. */
+int jck_head_bwd_conv2(int prec, const float* ds, const float* wp, const void* a4, int B, int B_more, int C, void* g_a4, float* grad,
+                       float* ws, void* stream);
 
 /* ---- CGAN pieces (model/CGAN.py:79-162, train/cgan_trainer.py:173-213) ---------------------------------------------
  * Linear layers run on the gather-GEMM kernels as plain row-major products; our activation order is NHWC, so the

@@ -181,6 +181,7 @@ struct jck_engine {
   int hp_step[2] = {0, 0};              // which step's scalars each parity holds (checked by the optimiser phases) ...
   float hp_lr[2] = {-1.f, -1.f};        // ... and at which learning rate they were computed (a scheduler may change it between steps)
   bool hp_holds(int step, float lr) const { return hp_step[step & 1] == step && hp_lr[step & 1] == lr; }
+  int acc_clean_step = -1;              // the step whose accumulator rows jck_engine_set_step has just cleared (consumed by its first D phase)
   bool capturing = false;
   float* g1_ws = nullptr; size_t g1_ws_bytes = 0;
   float* wg_ws; size_t wg_ws_bytes;
@@ -339,6 +340,11 @@ struct jck_engine {
   int mix_fake_noise(const jck_step_inputs* in, int B, hipStream_t st) {
     if (!in->noise_fake) return jck_axpy_noise_rng(prec, fake_raw, rng(), 1, 0.9f, 0.1f, fake, B, T.HW, st);
     return jck_axpy_noise(prec, fake_raw, in->noise_fake, 0.9f, 0.1f, fake, B, T.HW, st);
+  }
+  // ... and the penalty's interpolate (:111-113) in the same launch
+  int mix_fake_noise_interp(const jck_step_inputs* in, int B, hipStream_t st) {
+    return jck_mix_interp(prec, fake_raw, in->noise_fake, in->noise_fake ? nullptr : rng(), 1, 0.9f, 0.1f, fake, real_noisy, in->alpha, xhat,
+                          B, T.HW, st);
   }
 };
 
@@ -847,9 +853,9 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
     }
     JCK_TRY(jck_head_fwd_grouped(e->prec, S.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, G, tg, md, S.prob, S.ds, e->acc, sl, sp, e->acc_ld, st));
   }
-  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]), e->head_ws, st));
-  JCK_TRY(jck_head_bwd_conv(e->prec, S.ds + gw * B, e->d_head_wp, at(S.a[TT.NS - 1], (size_t)gw * B * TT.FEAT), B, TT.G_C1,
-                            at(S.g[TT.NS - 1], (size_t)gw * B * TT.FEAT), nullptr, nullptr, st));
+  // loss groups (input + weight gradient) and the penalty group (input gradient only), one launch
+  JCK_TRY(jck_head_bwd_conv2(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
+                             e->head_ws, st));
   JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part));
   return JCK_OK;
 }
@@ -1061,6 +1067,14 @@ static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_
   return jck_img_prep(e->prec, in->real_nchw, in->noise_real, 0.9f, 0.1f, e->real_noisy, B, TT.HW, st);
 }
 
+// the step's accumulator rows (losses, probabilities, penalty norms): cleared by the launch that wrote the step's scalars
+// (jck_engine_set_step) when that has just run for this step, else - captured steps, a phase called twice - by a memset
+static int clear_acc(jck_engine* e, int step, hipStream_t st) {
+  if (e->acc_clean_step == step && !e->capturing) { e->acc_clean_step = -1; return JCK_OK; }
+  HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+  return JCK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------------------
@@ -1131,13 +1145,12 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         // head buffers serve all three; the penalty group goes last and leaves them as its double backward (PHASE_D_GP)
         // expects them.
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+        JCK_TRY(clear_acc(e, in->step, st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
         HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
         JCK_TRY(prep_real(e, in, B, st));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));
-        JCK_TRY(e->mix_fake_noise(in, B, st));
-        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
+        JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
         JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st));
         auto& S = e->bset;
         const float tg[2] = {0.9f, 0.1f};
@@ -1173,7 +1186,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       if (!cg && e->batched == 4) {                   // as 3, but D(real)'s forward runs beside G's forward
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+        JCK_TRY(clear_acc(e, in->step, st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
         JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
@@ -1203,12 +1216,11 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         // D(real)'s forward of this step may already have run under the previous step's G all-reduce (PHASE_D_REAL_FWD)
         const bool pre = e->real_fwd_step == (long long)in->step;
         e->real_fwd_step = -1;
-        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+        JCK_TRY(clear_acc(e, in->step, st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
         if (!pre) JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
-        JCK_TRY(e->mix_fake_noise(in, B, st));   // :171
-        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
+        JCK_TRY(e->mix_fake_noise_interp(in, B, st));                                             // :171, :111-113
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
         if (pre) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                          // :173, 118 as one 2B forward
@@ -1222,7 +1234,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_D_FAKE: {
       if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
         if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw (or real_u8)");
-        HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+        JCK_TRY(clear_acc(e, in->step, st));
         HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                   // D.zero_grad()  :155
         if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
       }
@@ -1354,7 +1366,9 @@ extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stre
   if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
   const int q = step & 1;
   JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream, e->rz[q], (long long)e->B * 100,
-                            e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f));
+                            e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f,
+                            e->acc2 + (size_t)8 * e->acc_ld * q, (long long)8 * e->acc_ld));
+  e->acc_clean_step = step;
   e->hp_step[step & 1] = step;
   e->hp_lr[step & 1] = lr;
   return JCK_OK;

@@ -157,7 +157,10 @@ __global__ void nhwc4_to_nchw_kernel(const T* __restrict__ in, float* __restrict
 // out = keep * x(NHWC4 T) + mix * noise(NCHW f32)
 template <typename T>
 __global__ void axpy_noise_kernel(const T* __restrict__ x, const float* __restrict__ noise, float keep, float mix,
-                                  T* __restrict__ out, int N, int HW, const unsigned* __restrict__ rng = nullptr, unsigned rng_tensor = 0) {
+                                  T* __restrict__ out, int N, int HW, const unsigned* __restrict__ rng = nullptr, unsigned rng_tensor = 0,
+                                  const T* __restrict__ real = nullptr, const float* __restrict__ alpha = nullptr, T* __restrict__ xhat = nullptr) {
+  // xhat != nullptr: the penalty's interpolate x_hat = alpha[n] * real + (1 - alpha[n]) * out in the same pass (interp_kernel's
+  // arithmetic on the value as STORED in `out`: same bits as the two launches)
   const long long total = (long long)N * HW;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long n = i / HW;
@@ -174,6 +177,18 @@ __global__ void axpy_noise_kernel(const T* __restrict__ x, const float* __restri
     }
     v[3] = 0.f;
     st4(out + i * 4, v);
+    if (xhat) {
+      const float al = alpha[n];
+      float va[4], r[4];
+      ld4(real + i * 4, va);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        T t;
+        stf(&t, v[c]);
+        r[c] = al * va[c] + ((1.f - al) * ldf(&t));
+      }
+      st4(xhat + i * 4, r);
+    }
   }
 }
 
@@ -392,33 +407,55 @@ static __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
                                                                  long long group_stride = 0, int groups = 1, int grad_groups = 1,
                                                                  long long partial_group_stride = -1) {
-  __shared__ float sh[4][8];
+  // groups in chunks of four: the loads of a chunk's groups are in flight together and one barrier pair serves them (the
+  // grouped D pass has 3: one memory round trip instead of three; same summation order per group - same bits)
+  __shared__ float sh[4][4][8];
   const int c0 = blockIdx.x * 4;
   const long long pgs = partial_group_stride >= 0 ? partial_group_stride : group_stride;
   float dg = 0.f, db = 0.f;
-  for (int g = 0; g < groups; ++g) {
-    const float* pp = partial + (long long)g * pgs;
-    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (int k = threadIdx.x; k < nblk; k += 256) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + c0);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + C + c0);
+  for (int g0 = 0; g0 < groups; g0 += 4) {
+    float s[4][4], q[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s[i] += a[i]; q[i] += b[i]; }
+    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[gg][i] = 0.f; q[gg][i] = 0.f; }
+    for (int k = threadIdx.x; k < nblk; k += 256) {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        if (g0 + gg >= groups) continue;
+        const float* pp = partial + (long long)(g0 + gg) * pgs;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + c0);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * 2 * C + C + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[gg][i] += a[i]; q[gg][i] += b[i]; }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i] = wave_sum(s[i]); q[i] = wave_sum(q[i]); }
-    __syncthreads();                                        // the previous group's sh[] has been read
+    for (int gg = 0; gg < 4; ++gg) {
+      if (g0 + gg >= groups) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[gg][i] = wave_sum(s[gg][i]); q[gg][i] = wave_sum(q[gg][i]); }
+    }
+    __syncthreads();                                        // the previous chunk's sh[] has been read
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { sh[threadIdx.x >> 6][i] = s[i]; sh[threadIdx.x >> 6][4 + i] = q[i]; }
+      for (int gg = 0; gg < 4; ++gg) {
+        if (g0 + gg >= groups) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sh[gg][threadIdx.x >> 6][i] = s[gg][i]; sh[gg][threadIdx.x >> 6][4 + i] = q[gg][i]; }
+      }
     }
     __syncthreads();
     if (threadIdx.x < 4) {
       const int i = threadIdx.x, c = c0 + i;
-      const float s1 = sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i], s2 = sh[0][4 + i] + sh[1][4 + i] + sh[2][4 + i] + sh[3][4 + i];
-      sums[(long long)g * group_stride + c] = s1;
-      sums[(long long)g * group_stride + C + c] = s2;
-      if (g < grad_groups) { dg += s2; db += s1; }
+      for (int gg = 0; gg < 4 && g0 + gg < groups; ++gg) {
+        const int g = g0 + gg;
+        const float s1 = sh[gg][0][i] + sh[gg][1][i] + sh[gg][2][i] + sh[gg][3][i];
+        const float s2 = sh[gg][0][4 + i] + sh[gg][1][4 + i] + sh[gg][2][4 + i] + sh[gg][3][4 + i];
+        sums[(long long)g * group_stride + c] = s1;
+        sums[(long long)g * group_stride + C + c] = s2;
+        if (g < grad_groups) { dg += s2; db += s1; }
+      }
     }
   }
   if (threadIdx.x < 4) {
@@ -660,7 +697,9 @@ static __global__ void head_part_reduce_kernel(const float* __restrict__ part, i
 template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __restrict__ ds, const float* __restrict__ w,
                                                              const T* __restrict__ a4, int B, int K, int C,
-                                                             T* __restrict__ g, float* __restrict__ grad) {
+                                                             T* __restrict__ g, float* __restrict__ grad, int Bmore = 0) {
+  // Bmore: rows [B, B + Bmore) that only get their input gradient (the penalty group behind the loss groups of the batched D
+  // pass): one launch for both; the rows < B meet the same lanes in the same order, so the partial sums keep their bits
   __shared__ float red[4][64][9];
   const int u = threadIdx.x & 63, ln = threadIdx.x >> 6;
   const int k = (blockIdx.x * 64 + u) * 8;
@@ -669,9 +708,9 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
     float wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[j] = w[k + j];
-    for (int n = blockIdx.y * 4 + ln; n < B; n += gridDim.y * 4) {
+    for (int n = blockIdx.y * 4 + ln; n < B + Bmore; n += gridDim.y * 4) {
       const float d = ds[n];
-      if (grad) {
+      if (grad && n < B) {
         float v[8];
         ld8(a4 + (long long)n * K + k, v);
 #pragma unroll
@@ -708,7 +747,8 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // (train/dcgan_trainer.py:168), alpha [nalpha] ~ U[0,1) (:111), CGAN's Dropout keep masks [nmask] in {0,1} with P(keep) = keep_p
 // (model/CGAN.py:105) - Philox4x32-10, counter = (index/4, tensor id 8 / 9 / 10, step), key = seed.  No ATen launch is left
 // in the step, and a captured step replays with fresh draws without any copy into static buffers.
-struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; };
+struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; float* zero; long long nzero; };
+// (zero / nzero: a small buffer the same launch clears - the engine's per-step accumulator rows, instead of a memset node)
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt, unsigned seed_lo, unsigned seed_hi,
                                       unsigned step, const StepRng r) {
@@ -718,6 +758,7 @@ static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, f
     w[0] = seed_lo; w[1] = seed_hi; w[2] = step; w[3] = 0u;
   }
   const long long q0 = (r.nz + 3) / 4, q1 = (r.nalpha + 3) / 4, q2 = (r.nmask + 3) / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < r.nzero; i += (long long)gridDim.x * blockDim.x) r.zero[i] = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q0 + q1 + q2; i += (long long)gridDim.x * blockDim.x) {
     unsigned o[4];
     if (i < q0) {                                                     // four normals: two Box-Muller pairs

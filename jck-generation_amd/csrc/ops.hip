@@ -1144,6 +1144,16 @@ extern "C" int jck_axpy_noise(int prec, const void* x, const float* noise, float
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
+// jck_axpy_noise (noise given) / jck_axpy_noise_rng (rng given) followed by jck_interp(real, out, alpha) -> xhat as ONE launch
+extern "C" int jck_mix_interp(int prec, const void* x, const float* noise, const unsigned* rng, int tensor_id, float keep, float mix,
+                              void* out, const void* real, const float* alpha, void* xhat, int N, int HW, void* stream) {
+  if (!real || !alpha || !xhat) JCK_FAIL(JCK_E_ARG, "mix_interp: real / alpha / xhat is NULL");
+  if ((noise != nullptr) == (rng != nullptr)) JCK_FAIL(JCK_E_ARG, "mix_interp: exactly one of noise and rng");
+  DISPATCH_T(prec, hipLaunchKernelGGL(axpy_noise_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0, (hipStream_t)stream,
+                                      (const T*)x, noise, keep, mix, (T*)out, N, HW, rng, (unsigned)tensor_id, (const T*)real, alpha, (T*)xhat));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 extern "C" int jck_interp(int prec, const void* a, const void* b, const float* alpha, void* out, int N, int HW, void* stream) {
   DISPATCH_T(prec, hipLaunchKernelGGL(interp_kernel<T>, dim3(ew_grid((long long)N * HW)), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)a, (const T*)b, alpha, (T*)out, N, HW));
@@ -1209,12 +1219,19 @@ extern "C" int jck_head_bwd(int prec, const float* ds, const float* wp, const vo
 }
 extern "C" int jck_head_bwd_conv(int prec, const float* ds, const float* wp, const void* a4, int B, int C, void* g_a4,
                                  float* grad, float* ws, void* stream) {
+  return jck_head_bwd_conv2(prec, ds, wp, a4, B, 0, C, g_a4, grad, ws, stream);
+}
+// jck_head_bwd_conv over B rows and, in the same launch, the input gradient alone for the B_more rows behind them (ds, a4, g_a4 hold
+// B + B_more rows; the weight gradient sums the first B only) - the loss groups and the penalty group of the batched D pass
+extern "C" int jck_head_bwd_conv2(int prec, const float* ds, const float* wp, const void* a4, int B, int B_more, int C, void* g_a4,
+                                  float* grad, float* ws, void* stream) {
   if (C % 8) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: C % 8 != 0");
+  if (B_more < 0 || (B_more > 0 && !g_a4)) JCK_FAIL(JCK_E_ARG, "head_bwd_conv2: the extra rows produce an input gradient only");
   if (!g_a4 && !grad) return JCK_OK;
   if (grad && !ws) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: the weight gradient needs a workspace of jck_head_bwd_ws_floats(16*C) floats");
   const int K = 16 * C;
   DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, (hipStream_t)stream, ds, wp,
-                                      (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr));
+                                      (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr, B_more));
   HIPCHK(hipGetLastError());
   if (grad) {
     hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, ws, HEAD_CONV_NS, K, C, grad, 1);
@@ -1241,10 +1258,11 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
 // the same update with {step_size, bc2_sqrt} read from device memory: jck_adam_set_step writes them (same host arithmetic)
 // ... and (rz / ralpha / rmasks, each optional) the step's small random inputs, drawn by the same launch (ew.hpp: adam_hp_kernel)
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st, float* rz,
-                      long long nz, float* ralpha, long long nalpha, float* rmasks, long long nmask, float keep_p) {
+                      long long nz, float* ralpha, long long nalpha, float* rmasks, long long nmask, float keep_p, float* zero,
+                      long long nzero) {
   if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
-  StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p};
+  StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p, zero, zero ? nzero : 0};
   const long long quads = (r.nz + 3) / 4 + (r.nalpha + 3) / 4 + (r.nmask + 3) / 4;
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 512));
   hipLaunchKernelGGL(adam_hp_kernel, dim3(blocks), dim3(256), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,

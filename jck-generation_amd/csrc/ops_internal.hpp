@@ -37,7 +37,7 @@ int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int ns
 // Adam with {step_size, bc2_sqrt} in device memory (ops.hip): the engine's step has no per-step kernel argument
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st,
                       float* rz = nullptr, long long nz = 0, float* ralpha = nullptr, long long nalpha = 0, float* rmasks = nullptr,
-                      long long nmask = 0, float keep_p = 0.75f);
+                      long long nmask = 0, float keep_p = 0.75f, float* zero = nullptr, long long nzero = 0);
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st);
 bool jck_prof_is_on();

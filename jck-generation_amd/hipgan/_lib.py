@@ -73,6 +73,7 @@ PROTOS = {
     "jck_nhwc4_to_nchw": (i32, [i32, vp, vp, i32, i32, vp]),
     "jck_axpy_noise": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_interp": (i32, [i32, vp, vp, vp, vp, i32, i32, vp]),
+    "jck_mix_interp": (i32, [i32, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "jck_gp_norm": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp]),
     "jck_tanh_bwd": (i32, [i32, vp, vp, f32, vp, i64, vp]),
     "jck_head_fwd": (i32, [i32, vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, i32, i32, i32, vp]),
@@ -102,6 +103,7 @@ PROTOS = {
     "jck_head_bwd": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]),
     "jck_head_unpack_grad": (i32, [vp, i32, vp, i32, vp]),
     "jck_head_bwd_conv": (i32, [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
+    "jck_head_bwd_conv2": (i32, [i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "jck_adam": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, i32, f32, vp]),
     "jck_engine_create": (i32, [C.POINTER(vp), i32, i32, i32]),
     "jck_engine_create_sized": (i32, [C.POINTER(vp), i32, i32, i32, i32]),
