@@ -122,6 +122,12 @@ struct XsRegion { unsigned char* base = nullptr; size_t bytes = 0; };     // a p
 
 }  // namespace
 
+// the engine's events order kernels of ONE device across its streams: no system-scope fence (cache write-back for the host's sake)
+// when they are recorded; JCK_EVENT_FENCE=1 restores the default
+static unsigned jck_event_flags() {
+  static const bool fence = getenv("JCK_EVENT_FENCE") && atoi(getenv("JCK_EVENT_FENCE")) != 0;
+  return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
 struct jck_engine {
   int family, prec, B;
   Topo T;
@@ -163,6 +169,9 @@ struct jck_engine {
   // activation tensor is then written only where the backward reads it (weight gradients, CGAN's double backward) - on
   // fwd_side, beside the forward chain - and not at all in the G phase's pass through D (its weight gradients are dead)
   bool bnf = false, fwd_need_a = true;
+  // cross-stream hand-overs of the backward: the producing launch completes the event itself (jck_arm_stop_event) instead of a
+  // hipEventRecord behind it; JCK_EXT_EVENTS=0 restores the records
+  bool ext_events = true;
   hipStream_t fwd_side = nullptr;
   XsRegion g_xr;
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
@@ -378,13 +387,14 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   // but measured 4-6 % SLOWER at batch 256 (1.97-1.99 vs 1.85-1.89 ms): opt-in, JCK_BN2=1.
   e->bn2 = getenv("JCK_BN2") && atoi(getenv("JCK_BN2")) != 0;
   if (e->bn2) e->fuse_bnbwd = false;
+  e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bnf = getenv("JCK_BNF") && atoi(getenv("JCK_BNF")) != 0 && !e->bn2 && prec == JCK_PREC_BF16;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
     hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
     for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
-    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
+    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
   }
   *out = e;
   return JCK_OK;
@@ -662,6 +672,9 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     float* dgam = want_wgrad ? e->P(e->LD, e->dg, NWN[i]) : nullptr;
     float* dbet = want_wgrad ? e->P(e->LD, e->dg, NBN[i]) : nullptr;
+    // the launch that writes g_y hands it to the weight-gradient stream by completing evW[i] itself
+    const bool armed = par && e->ext_events && !e->bn2;
+    if (armed) jck_arm_stop_event(e->evW[i]);
     if (e->bn2) {
       // s1 | s2, dgamma, dbeta of layer i were left by the dgrad launch of layer i+1 (previous iteration); the top layer's
       // gradient comes from the head: one reduction launch.  Then ONE pass over (g, y) writes g_y.
@@ -680,7 +693,7 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
-      if (par) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+      if (par) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
       JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, ws));
     }
     if (i > 0 && e->bn2) {
@@ -780,6 +793,8 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
     const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     const bool resume = part == 2 && i == TT.NS - 1;      // part 2 starts at this layer's dgrad
+    const bool armed = side && e->ext_events && !e->bn2 && !resume;
+    if (armed) jck_arm_stop_event(e->evW[i]);             // the launch that writes g_y completes evW[i] itself
     if (resume) {
     } else if (e->bn2) {
       if (i == TT.NS - 1) {            // the top layer's gradient comes from the head: one reduction launch over all groups
@@ -797,7 +812,7 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
     if (!resume) {
-    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    if (side) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
     }
     if (part == 1) {
@@ -1020,12 +1035,16 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
 
 // g_fake = gradient w.r.t. the noisy fake image (NHWC4); fills G's grads arena (accumulating)
 static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side) {
+  // every launch that writes a gradient the weight-gradient stream reads (tanh backward, then the BatchNorm backward of each
+  // stage) completes that stage's event itself
+  const bool armed = side && e->ext_events && !e->bn2 && !e->fuse_bnbwd;
+  if (armed) jck_arm_stop_event(e->evW[TT.NS - 1]);
   JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st));
   const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
   for (int i = TT.NS - 1; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = TT.G_CS[i]), big side has TT.G_CB[i] channels
     const int hs = TT.G_HS[i], cs = TT.G_CS[i], cb = TT.G_CB[i];
     hipStream_t ws = st;
-    if (side) { HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    if (side) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
     const long long rows = (long long)B * hs * hs;
@@ -1041,6 +1060,7 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
                                 e->g_gr[i], e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, st));
     } else {
       JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
+      if (armed && i > 0) jck_arm_stop_event(e->evW[i - 1]);      // g_gr[i] is what stage i - 1's weight gradient reads
       JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
                              e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, st));
     }
@@ -1456,7 +1476,7 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;
-      HIPCHK(hipEventCreateWithFlags(p, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
     }
     e->bucket_ready = false; e->gp_inflight = false;
     (void)hipGetLastError();

@@ -56,6 +56,20 @@ extern "C" int jck_tune(const char* key, int value) {
   JCK_FAIL(JCK_E_ARG, std::string("jck_tune: unknown key ") + (key ? key : "(null)"));
 }
 
+#include <hip/hip_ext.h>
+static thread_local hipEvent_t t_stop_event = nullptr;
+void jck_arm_stop_event(hipEvent_t ev) { t_stop_event = ev; }
+// launch that honours jck_arm_stop_event (every kernel argument must be passed explicitly: the extended launch checks the count)
+#define LAUNCH_ARMABLE(kernel, grid, block, shmem, stream, ...)                                              \
+  do {                                                                                                       \
+    if (t_stop_event) {                                                                                      \
+      hipEvent_t ev_ = t_stop_event;                                                                         \
+      t_stop_event = nullptr;                                                                                \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (hipEvent_t) nullptr, ev_, 0u, __VA_ARGS__); \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                   \
+    }                                                                                                        \
+  } while (0)
 #define DISPATCH_T(prec, CALL)                                  \
   do {                                                          \
     if ((prec) == JCK_PREC_BF16) { typedef bf16_t T; CALL; }    \
@@ -947,8 +961,8 @@ extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const fl
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C));
+  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
+                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, 0ll));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -996,8 +1010,8 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
                      gstride, groups, grad_groups);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
+  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1013,9 +1027,9 @@ extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const
                      dbeta, C, gstride, groups, grad_groups, (long long)slots_per_group * 2 * C);
   HIPCHK(hipGetLastError());
   const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
-                                      gstride));
+  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
+                                  gstride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1070,9 +1084,9 @@ extern "C" int jck_bn_bwd_apply(int prec, const void* g_a, const void* y, const 
                                 float slope, void* g_y, long long rows_per_group, int C, int groups, void* stream) {
   if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_apply: bad shape");
   const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)g_a, (const T*)y, aux, sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
-                                      sums_stride));
+  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
+                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
+                                  sums_stride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1169,8 +1183,8 @@ extern "C" int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, 
 }
 extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out, long long numel, void* stream) {
   if (numel % 4) JCK_FAIL(JCK_E_ARG, "tanh_bwd: numel % 4 != 0");
-  DISPATCH_T(prec, hipLaunchKernelGGL(tanh_bwd_kernel<T>, dim3(ew_grid(numel / 4)), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)g, (const T*)y, scale, (T*)out, numel / 4));
+  DISPATCH_T(prec, LAUNCH_ARMABLE(tanh_bwd_kernel<T>, dim3(ew_grid(numel / 4)), dim3(256), 0, (hipStream_t)stream,
+                                  (const T*)g, (const T*)y, scale, (T*)out, numel / 4));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

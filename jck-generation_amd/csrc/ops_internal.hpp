@@ -41,3 +41,7 @@ int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st);
 bool jck_prof_is_on();
+// The next BatchNorm-backward apply / tanh-backward launch of this thread completes `ev` itself (hipExtLaunchKernel's stopEvent:
+// the dispatch packet's own completion signal) - what a hipEventRecord behind it would do with a marker packet of its own,
+// which costs the launch stream ~6-7 us of idle time per record on this runtime.  No-op for ev == nullptr.
+void jck_arm_stop_event(hipEvent_t ev);
