@@ -28,6 +28,35 @@ def counters(path):
     return out
 
 
+def cgan_summary(tag):
+    """profiles/rNN_cgan_summary.md + rNN_cgan_kernel_stats.csv from tests/_prof_cgan.sh's output (gpurun_out/prof_cgan), if present."""
+    src = os.path.join(ROOT, "gpurun_out", "prof_cgan")
+    stats = os.path.join(src, "bench_kernel_stats.csv")
+    if not os.path.exists(stats):
+        return
+    shutil.copy(stats, os.path.join(DST, f"{tag}_cgan_kernel_stats.csv"))
+    line = [l for l in open(os.path.join(src, "bench_stdout.log")).read().splitlines() if l.startswith("{")][-1]
+    b = json.loads(line)
+    n = b["steps"] + b["warmup"]
+    rows = list(csv.DictReader(open(stats)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / n / 1e6
+    calls = sum(int(r["Calls"]) for r in rows) / n
+
+    def part(keys):
+        return sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys)) / n / 1e6
+    gemm = part(("igemm", "wgrad_dma", "wgrad_halo", "wgrad_kernel", "img_down", "img_up"))
+    bn = part(("bn_", "bn2_"))
+    md = [f"# CGAN bench (eager launches, two HIP streams: the default), rocprofv3 --kernel-trace --stats, {n} traced steps ({tag})", "",
+          f"Sum of kernel durations {tot:.3f} ms/step over {calls:.0f} launches/step: GEMM-shaped {gemm:.2f}, BatchNorm {bn:.2f}, "
+          f"everything else {tot - gemm - bn:.2f} ms (the weight gradients overlap the main stream, so the sum exceeds the wall time); "
+          f"the profiled run reported {b['ms_per_step']} ms/step = {b['value']} images/sec.", "",
+          "| ms/step | launches/step | avg us | kernel |", "|---|---|---|---|"]
+    for r in rows[:40]:
+        c, t = int(r["Calls"]), float(r["TotalDurationNs"])
+        md.append(f"| {t / n / 1e6:.4f} | {c / n:.1f} | {t / c / 1e3:.2f} | `{r['Name'][:100]}` |")
+    open(os.path.join(DST, f"{tag}_cgan_summary.md"), "w").write("\n".join(md) + "\n")
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     for f in ("bench_kernel_stats.csv", "bench_domain_stats.csv"):
@@ -90,7 +119,9 @@ def main():
                 lines.append(f"{(st - a) / 1e3:8.1f} {(en - st) / 1e3:7.1f} s{sid} {nm} g{grid}")
         open(os.path.join(DST, f"{tag}_timeline.txt"), "w").write("\n".join(lines) + "\n")
     for extra in sys.argv[2:]:
-        shutil.copy(extra, os.path.join(DST, f"{tag}_{os.path.basename(extra)}"))
+        base = os.path.basename(extra)
+        shutil.copy(extra, os.path.join(DST, base if base.startswith(tag + "_") else f"{tag}_{base}"))
+    cgan_summary(tag)
     print("wrote profiles/%s_*" % tag)
 
 
