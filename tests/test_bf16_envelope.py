@@ -53,10 +53,13 @@ def test_bf16_step_against_the_storage_emulation(family, B, steps):
             assert be.worst(rows, group, "hip_vs_emu") <= 0.75 * be.worst(rows, group, "hip_vs_ref") + FLOOR[group], group
 
 
-@pytest.mark.parametrize("family,prec,B", [("dcgan", "bf16", 16), ("dcgan", "f32", 16), ("dcgan", "bf16", 256), ("cgan", "bf16", 16)])
+@pytest.mark.parametrize("family,prec,B", [("dcgan", "bf16", 16), ("dcgan", "f32", 16), ("dcgan", "bf16", 256), ("cgan", "bf16", 16),
+                                            ("cgan", "f32", 8)])
 def test_two_runs_are_bitwise_identical(family, prec, B):
     """Same weights, batch and noise twice, two steps each: gradients, weights, Adam moments, BN statistics and the logged
-    scalars must be bit-for-bit equal (the reductions that used float atomics in round 1 are two-stage sums now)."""
+    scalars must be bit-for-bit equal (the reductions that used float atomics in round 1 are two-stage sums now).  The small
+    exact-fp32 cases have the shortest kernels: they are the ones that show a missing cross-stream dependency (round 3: an
+    image-gradient launch moved to the second stream raced with the optimiser's repack here, one run in three)."""
     import bf16_error as be
     from hipgan.engine import CganEngine, DcganEngine
     from oracle.gan_oracle import build_params
