@@ -394,7 +394,8 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
     hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
     for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
-    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
+    // (evBucket hands gradients to the communication library - possibly read by peer devices: it keeps the default fence)
+    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, p == &e->evBucket ? (unsigned)hipEventDisableTiming : jck_event_flags()));
   }
   *out = e;
   return JCK_OK;
@@ -1476,7 +1477,7 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;
-      HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
+      HIPCHK(hipEventCreateWithFlags(p, p == &e->evBucket ? (unsigned)hipEventDisableTiming : jck_event_flags()));
     }
     e->bucket_ready = false; e->gp_inflight = false;
     (void)hipGetLastError();
