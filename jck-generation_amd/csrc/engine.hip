@@ -694,7 +694,8 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
-      if (par) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+      // (an armed event that no launch took - a path without an armable launch - is recorded the ordinary way)
+      if (par) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
       JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, ws));
     }
     if (i > 0 && e->bn2) {
@@ -813,7 +814,7 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
     if (!resume) {
-    if (side) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    if (side) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
     }
     if (part == 1) {
@@ -1045,7 +1046,7 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
   for (int i = TT.NS - 1; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = TT.G_CS[i]), big side has TT.G_CB[i] channels
     const int hs = TT.G_HS[i], cs = TT.G_CS[i], cb = TT.G_CB[i];
     hipStream_t ws = st;
-    if (side) { if (!armed) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    if (side) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
     const long long rows = (long long)B * hs * hs;

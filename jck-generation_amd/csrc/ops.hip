@@ -59,6 +59,7 @@ extern "C" int jck_tune(const char* key, int value) {
 #include <hip/hip_ext.h>
 static thread_local hipEvent_t t_stop_event = nullptr;
 void jck_arm_stop_event(hipEvent_t ev) { t_stop_event = ev; }
+hipEvent_t jck_take_stop_event() { hipEvent_t ev = t_stop_event; t_stop_event = nullptr; return ev; }
 // launch that honours jck_arm_stop_event (every kernel argument must be passed explicitly: the extended launch checks the count)
 #define LAUNCH_ARMABLE(kernel, grid, block, shmem, stream, ...)                                              \
   do {                                                                                                       \

@@ -45,3 +45,5 @@ bool jck_prof_is_on();
 // the dispatch packet's own completion signal) - what a hipEventRecord behind it would do with a marker packet of its own,
 // which costs the launch stream ~6-7 us of idle time per record on this runtime.  No-op for ev == nullptr.
 void jck_arm_stop_event(hipEvent_t ev);
+// the armed event if no launch has taken it yet (and disarms): the caller then records it the ordinary way
+hipEvent_t jck_take_stop_event();
