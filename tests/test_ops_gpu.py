@@ -294,6 +294,17 @@ def test_head(G, prec):
     G.lib.jck_head_bwd_conv(prec, ds, wp, a4d, b, c, None, gw3, hws, G.cur_stream())
     torch.cuda.synchronize()
     assert torch.equal(gw3, gw2)
+    # the batched D pass: loss rows (input + weight gradient) and, behind them, rows that only get their input gradient - one
+    # launch with the bits of the two it replaces
+    b1 = 10
+    ga4 = torch.full_like(a4d, 3.0)
+    gw4 = torch.full((1, c, 4, 4), 0.5, device="cuda")
+    G.lib.jck_head_bwd_conv2(prec, ds, wp, a4d, b1, b - b1, c, ga4, gw4, hws, G.cur_stream())
+    ga5, gw5 = torch.full_like(a4d, 3.0), torch.full((1, c, 4, 4), 0.5, device="cuda")
+    G.lib.jck_head_bwd_conv(prec, ds, wp, a4d, b1, c, ga5, gw5, hws, G.cur_stream())
+    G.lib.jck_head_bwd_conv(prec, ds[b1:], wp, a4d[b1:], b - b1, c, ga5[b1:], None, None, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ga4, ga5) and torch.equal(ga4, ga) and torch.equal(gw4, gw5)
     # gradient-penalty mode: d sum(sigmoid) / d logit
     G.lib.jck_head_fwd(prec, a4d, wp, None, b, 16 * c, 0.0, 1, prob, ds, scal, -1, -1, ld, G.cur_stream())
     torch.cuda.synchronize()
@@ -360,6 +371,18 @@ def test_image_ops(G, prec):
     G.lib.jck_interp(prec, out, o2, al.cuda(), o3, n, hw, G.cur_stream())
     a_, b_ = G.from_nhwc(out, 3), G.from_nhwc(o2, 3)
     G.check(G.from_nhwc(o3, 3), al.view(n, 1, 1, 1) * a_ + (1 - al.view(n, 1, 1, 1)) * b_, tol, "interp")
+    # noise mix + interpolate as one launch (explicit noise, and the in-kernel Philox stream): the bits of the two launches
+    o2b, o3b = torch.empty_like(out), torch.empty_like(out)
+    G.lib.jck_mix_interp(prec, G.to_nhwc(x, prec), nz.cuda(), None, 0, 0.9, 0.1, o2b, out, al.cuda(), o3b, n, hw, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o2b, o2) and torch.equal(o3b, o3)
+    rng = torch.tensor([123, 456, 7, 0], dtype=torch.int32, device="cuda")
+    o2c, o3c, o2d, o3d = (torch.empty_like(out) for _ in range(4))
+    G.lib.jck_axpy_noise_rng(prec, G.to_nhwc(x, prec), rng, 1, 0.9, 0.1, o2c, n, hw, G.cur_stream())
+    G.lib.jck_interp(prec, out, o2c, al.cuda(), o3c, n, hw, G.cur_stream())
+    G.lib.jck_mix_interp(prec, G.to_nhwc(x, prec), None, rng, 1, 0.9, 0.1, o2d, out, al.cuda(), o3d, n, hw, G.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o2c, o2d) and torch.equal(o3c, o3d)
     scal = torch.zeros(8, 4, device="cuda")
     norms = torch.empty(n, device="cuda")
     G.lib.jck_gp_norm(prec, o3, n, hw, scal, 6, 4, norms, G.cur_stream())
