@@ -391,13 +391,17 @@ def main():
     # cuda:0 and gloo instead of RCCL (RCCL needs one device per rank).  Never set by the driver.
     if os.environ.get("JCK_BENCH_ONE_GPU") == "1":
         local = 0
+        os.environ.setdefault("JCK_BN_RES", "0")      # ranks share one GPU: the resident (grid-barrier) launches need a chip each
     backend = os.environ.get("JCK_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("JCK_BENCH_FORCE_DDP") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))     # the one-rank rehearsal hook only
+        else:
+            os.environ.setdefault("MASTER_PORT", "29500")      # every rank must agree: a fixed default (torchrun sets it anyway)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:

@@ -100,6 +100,17 @@ int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slop
                            int groups, void* stream);
 int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                            float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* stream);
+/* Resident form of jck_bn_act_bwd_grouped (round 4; csrc/bnres.hpp): ONE launch; one workgroup per CU keeps its share of a
+ * group's (g_a, y) in registers across a grid barrier, so every tensor byte is read once (HBM passes 5 -> 3, launches 3 -> 1).
+ * Same arguments and results (summation order differs: fp32 rounding), plus sync_ws = jck_grid_sync_bytes() bytes of device
+ * memory zeroed ONCE by the caller and used by no two launches at the same time (the launch occupies every CU: one stream).
+ * Falls back to jck_bn_act_bwd_grouped when the layer does not fit the chip's register file, for fp32, for C < 64, with
+ * sync_ws == NULL or JCK_BN_RES=0.  jck_grid_sync_error: 1 if a barrier timed out (results invalid; re-zero sync_ws). */
+size_t jck_grid_sync_bytes(void);
+int jck_grid_sync_error(const void* sync_ws);
+int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                       float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* sync_ws,
+                       void* stream);
 /* BatchNorm backward fused with the dgrad that produces its input: jck_conv_up_bnbwd / jck_conv_down_bnbwd are
  * jck_conv_up / jck_conv_down whose statistic slots receive sum(g_z) and sum(g_z*xhat) of the layer whose input gradient
  * they produce (g_z = g_a*act'(z); bn_y = that layer's saved conv output, same layout as the output; bn_aux = its
@@ -394,6 +405,9 @@ int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* st
 int jck_engine_grad_bucket(jck_engine*, int net, void* stream, long long* offset, long long* numel);
 /* first element of the gradient-arena tail that PHASE_D_LOSS_A finalises (net 1 = D); -1 when the schedule has no such split */
 long long jck_engine_grad_tail(const jck_engine*, int net);
+/* after a device synchronisation: JCK_E_HIP if a grid barrier of a resident launch (jck_bn_act_bwd_res) timed out since the last
+ * call - the step's results are then invalid; the barrier state is re-armed */
+int jck_engine_check(jck_engine*);
 const float* jck_engine_scalars(const jck_engine*);
 const float* jck_engine_scalars_at(const jck_engine*, int step);   /* buffer of the given (1-based) step's parity */
 /* G forward only (train/dcgan_trainer.py:199-200, train-mode BN: running stats move); out NCHW fp32 [n,3,64,64] */
@@ -455,6 +469,9 @@ int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_
 /* debug probe: lane l of one wave returns the 8 elements wgrad's transposed LDS read hands it from a
  * [32][ld] 16-bit tile: out[l*8+j] must equal in[(8*(l>>4)+j)*ld + (l&15)] */
 int jck_debug_tr_read(const void* in, int ld, void* out, void* stream);
+/* development aid: the resident BatchNorm launches write [256][8] s_memrealtime stamps (uint64) of their workgroup leaders to buf
+ * (device memory; NULL switches it off) */
+int jck_debug_bnres_stamps(void* buf);
 /* development probe: per-wave s_memtime totals {wait+barrier, DMA issue, LDS reads+MFMA, whole kernel} of the last
  * weight-gradient launch made with JCK_WGRAD_STAMP=1 (n = number of 64-bit values to copy, 4 per wave, 8 waves per workgroup
  * slot, first 1024 workgroups); synchronises the device */

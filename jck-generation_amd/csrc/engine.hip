@@ -172,6 +172,8 @@ struct jck_engine {
   // cross-stream hand-overs of the backward: the producing launch completes the event itself (jck_arm_stop_event) instead of a
   // hipEventRecord behind it; JCK_EXT_EVENTS=0 restores the records
   bool ext_events = true;
+  // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
+  unsigned* gsync = nullptr; bool bn_res = true;
   hipStream_t fwd_side = nullptr;
   XsRegion g_xr;
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
@@ -276,6 +278,7 @@ struct jck_engine {
     }
     head_ws = c.take<float>(jck_head_bwd_ws_floats(TT.FEAT));
     gp2_ws = c.take<float>((size_t)acc_ld + jck_head_bwd_ws_floats(L1_OUT));
+    gsync = c.take<unsigned>(jck_grid_sync_bytes() / sizeof(unsigned));
     size_t w = 0;
     for (int i = 0; i < TT.NS; ++i) {
       w = std::max(w, jck_conv_wgrad_ws_bytes(B, TT.D_HB[i], TT.D_HB[i], TT.D_CB[i], TT.D_CS[i]));
@@ -388,6 +391,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->bn2 = getenv("JCK_BN2") && atoi(getenv("JCK_BN2")) != 0;
   if (e->bn2) e->fuse_bnbwd = false;
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
+  e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
   e->bnf = getenv("JCK_BNF") && atoi(getenv("JCK_BNF")) != 0 && !e->bn2 && prec == JCK_PREC_BF16;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
@@ -465,6 +469,7 @@ extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, 
     unsigned char* p1 = reinterpret_cast<unsigned char*>(e->dset[0].y[0]);
     HIPCHK(hipMemset(p0, 0, (size_t)(p1 - p0)));
   }
+  HIPCHK(hipMemset(e->gsync, 0, jck_grid_sync_bytes()));
   e->gp = g_params; e->gg = g_grads; e->gm = g_m; e->gv = g_v; e->gbn = g_bn; e->gnbt = g_nbt;
   e->dp = d_params; e->dg = d_grads; e->dm = d_m; e->dv = d_v; e->dbn = d_bn; e->dnbt = d_nbt;
   e->bound = true;
@@ -690,7 +695,8 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
       JCK_TRY(jck_bn_bwd_finish(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].stats, D.bn[i].slots, D.bn[i].sums, D.g[i], dgam,
                                 dbet, rows, cs, 1, 1, st));
     else
-      JCK_TRY(jck_bn_act_bwd(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, st));
+      JCK_TRY(jck_bn_act_bwd_res(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, 1, 1,
+                                 e->bn_res ? e->gsync : nullptr, st));
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
@@ -809,8 +815,8 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
       JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
                                 e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
     else
-      JCK_TRY(jck_bn_act_bwd_grouped(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NWN[i]),
-                                     e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
+      JCK_TRY(jck_bn_act_bwd_res(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NWN[i]),
+                                 e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, e->bn_res ? e->gsync : nullptr, st));
     const void* big = i == 0 ? x_in : S.a[i - 1];
     hipStream_t ws = st;
     if (!resume) {
@@ -1063,8 +1069,8 @@ static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, 
     } else {
       JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
       if (armed && i > 0) jck_arm_stop_event(e->evW[i - 1]);      // g_gr[i] is what stage i - 1's weight gradient reads
-      JCK_TRY(jck_bn_act_bwd(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
-                             e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, st));
+      JCK_TRY(jck_bn_act_bwd_res(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
+                                 e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, e->bn_res ? e->gsync : nullptr, st));
     }
     gbig = e->g_gr[i];
   }
@@ -1091,6 +1097,16 @@ static int prep_real(jck_engine* e, const jck_step_inputs* in, int B, hipStream_
 
 // the step's accumulator rows (losses, probabilities, penalty norms): cleared by the launch that wrote the step's scalars
 // (jck_engine_set_step) when that has just run for this step, else - captured steps, a phase called twice - by a memset
+// An optimiser phase called with another learning rate than the step's loss phases (separate G and D rates): only the Adam
+// scalars of the step's slot are rewritten - NOT the accumulator rows (the step's losses are in them, the tail of G_STEP reads
+// them) and not the step's random inputs (jck_engine_set_step here logged loss_d = loss_g = gp = 0).
+static int refresh_adam_scalars(jck_engine* e, int step, float lr, hipStream_t st) {
+  const int q = step & 1;
+  JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, st));
+  e->hp_step[q] = step;
+  e->hp_lr[q] = lr;
+  return JCK_OK;
+}
 static int clear_acc(jck_engine* e, int step, hipStream_t st) {
   if (e->acc_clean_step == step && !e->capturing) { e->acc_clean_step = -1; return JCK_OK; }
   HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
@@ -1125,7 +1141,12 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->parity = in->step & 1;
   if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL || phase == JCK_PHASE_D_LOSS_A) e->bucket_ready = false;
   // eager callers that did not call jck_engine_set_step: the step's scalars / Philox words are written by its first phase
-  if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+  // (a phase called with another learning rate than the step's earlier phases - separate G and D rates - rewrites the Adam
+  // scalars only: the step's accumulator rows and random inputs are live)
+  if (!e->capturing) {
+    if (e->hp_step[in->step & 1] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+    else if (e->hp_lr[in->step & 1] != in->lr) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
+  }
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
@@ -1340,7 +1361,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_D_STEP: {                                                                      // :180
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
-      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));   // (eager callers)
+      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));   // (eager callers)
       JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       return jck_engine_repack(e, 1, st);
     }
@@ -1356,7 +1377,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       return JCK_OK;
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
-      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+      if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
       JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
       JCK_TRY(jck_engine_repack(e, 0, st));
       {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
@@ -1515,6 +1536,16 @@ extern "C" long long jck_engine_grad_tail(const jck_engine* e, int net) {
   return (long long)find(e->LD, CWN[e->T.NS - 1])->offset;
 }
 
+// Call after a device synchronisation (e.g. when the step scalars are read): a grid barrier of a resident launch that timed out -
+// its workgroups were not all resident, which happens when another process or stream fills the same GPU - leaves invalid
+// results; the error is reported here, the barrier state re-armed.
+extern "C" int jck_engine_check(jck_engine* e) {
+  if (!e || !e->bound || !e->gsync) return JCK_OK;
+  if (!jck_grid_sync_error(e->gsync)) return JCK_OK;
+  HIPCHK(hipMemset(e->gsync, 0, jck_grid_sync_bytes()));
+  JCK_FAIL(JCK_E_HIP, "a grid barrier of the resident BatchNorm backward timed out: the launch needs every CU of the device to itself "
+                      "(another process or stream on this GPU?); the step's results are invalid - set JCK_BN_RES=0 to use the three-launch form");
+}
 extern "C" const float* jck_engine_scalars(const jck_engine* e) { return e ? e->scal_out : nullptr; }
 extern "C" const float* jck_engine_scalars_at(const jck_engine* e, int step) { return e ? e->scal2 + 8 * (step & 1) : nullptr; }
 

@@ -2,6 +2,7 @@
 #include "ops_internal.hpp"
 #include "thin.hpp"
 #include "wgrad_halo.hpp"
+#include "bnres.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -33,7 +34,8 @@ static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neu
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
 static int g_conv_in = env_int("JCK_CONV_IN", 1);                // 0: the jck_conv_*_in entry points always take the unfused route
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
-static int g_bn_unr = env_int("JCK_BN_UNR", 2);                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
+static int g_bn_unr = env_int("JCK_BN_UNR", 2);
+static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
 static int g_wgrad_wgs = env_int("JCK_WGRAD_WGS", 256);      // split-K target workgroups
@@ -47,7 +49,7 @@ static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 // slabs - it is the faster one (1.82-1.83 vs 1.86 ms, tests/_ab.sh JCK_WGRAD_HALO=0 / 1, two rounds)
 static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 0);
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"conv_in", &g_conv_in}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"conv_in", &g_conv_in}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
@@ -1013,6 +1015,72 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
   const long long total8 = rows * C / 8;
   DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
                                   (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// Resident form (bnres.hpp): one launch per layer, every tensor byte read once, the groups one after the other.  Falls back to
+// the three-launch form above when the layer does not fit the register file of the chip (or is not bf16, or JCK_BN_RES=0).
+static int bnres_cus() {
+  static int cus = [] {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    return pr.multiProcessorCount;
+  }();
+  return cus;
+}
+static unsigned long long* g_bnres_stamps = nullptr;
+extern "C" int jck_debug_bnres_stamps(void* buf) { g_bnres_stamps = (unsigned long long*)buf; return JCK_OK; }   // [256][8] u64, development aid
+extern "C" size_t jck_grid_sync_bytes(void) { return BNRES_SYNC_BYTES; }
+// 1 if a grid barrier of a resident launch timed out since the state was last zeroed (synchronises the device)
+extern "C" int jck_grid_sync_error(const void* sync_ws) {
+  unsigned err = 0;
+  if (!sync_ws) return 0;
+  if (hipMemcpy(&err, (const unsigned*)sync_ws + BNRES_W_ERR * 32, sizeof(err), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return err != 0;
+}
+// nb workgroups (all co-resident), nsl channel slices, chunks per thread; 0 = does not fit
+static int bnres_plan(int prec, long long rows, int C, int groups, int* nb_out, int* nsl_out) {
+  if (!g_bn_res || prec != JCK_PREC_BF16 || !is_pow2(C) || C < 64 || groups < 1 || rows < 1) return 0;
+  // Several groups in one pass (the batched D pass): the three-launch form's second read of (g_a, y) comes out of the
+  // Infinity Cache while all groups fit it, and then it is as fast or faster in the step (measured, DESIGN.md section 5.3:
+  // D.conv2's layer at 3 x 256 images 60 vs 70 us alone, the step 1.744 vs 1.733 ms); the resident form wins where they do not
+  // fit (D.conv1's layer: 3 x 2 x 33.5 MB).  bn_res = 2 takes the resident form whenever it fits the registers.
+  if (g_bn_res == 1 && groups > 1 && (long long)groups * rows * C * 4 <= (160ll << 20)) return 0;
+  const int nsl = C / 64;
+  int nb = std::min(bnres_cus(), 256);
+  nb -= nb % std::max(nsl, 8);
+  if (nb < nsl || nb < 8) return 0;
+  if ((long long)groups * rows * C * 2 >= (1ll << 40)) return 0;
+  const long long per_iter = (long long)(nb / nsl) * BNRES_ROWS;
+  const long long need = (rows + per_iter - 1) / per_iter;
+  if (need > 16) return 0;
+  *nb_out = nb; *nsl_out = nsl;
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+}
+extern "C" int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                                  float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups,
+                                  void* sync_ws, void* stream) {
+  int nb = 0, nsl = 0;
+  const int nch = sync_ws ? bnres_plan(prec, rows_per_group, C, groups, &nb, &nsl) : 0;
+  if (!nch) return jck_bn_act_bwd_grouped(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows_per_group, C, groups, grad_groups, stream);
+  BnResParams p;
+  p.ga = (const bf16_t*)g_a; p.y = (const bf16_t*)y; p.gy = (bf16_t*)g_y; p.aux = aux;
+  p.sums = sums; p.sums_stride = (long long)jck_bn_bwd_ws_floats(C);
+  p.dgamma = dgamma; p.dbeta = dbeta; p.sync = (unsigned*)sync_ws; p.stamps = g_bnres_stamps;
+  p.rows = rows_per_group; p.C = C; p.groups = groups; p.grad_groups = grad_groups; p.nb = nb; p.nsl = nsl;
+  p.slope = slope; p.inv_count = 1.0f / (float)rows_per_group;
+  const dim3 grid(nb), block(BNRES_THREADS);
+  // groups resident together (one barrier for all of them) while their chunks fit the register file
+  const int ng = (groups >= 3 && 3 * nch <= 16) ? 3 : (groups >= 2 && 2 * nch <= 16) ? 2 : 1;
+#define BNRES_CASE(NCH_, NG_) case NCH_ * 4 + NG_: LAUNCH_ARMABLE((bn_bwd_res_kernel<NCH_, NG_>), grid, block, 0, (hipStream_t)stream, p); break
+  switch (nch * 4 + ng) {
+    BNRES_CASE(1, 1); BNRES_CASE(2, 1); BNRES_CASE(4, 1); BNRES_CASE(8, 1); BNRES_CASE(16, 1);
+    BNRES_CASE(1, 2); BNRES_CASE(2, 2); BNRES_CASE(4, 2); BNRES_CASE(8, 2);
+    BNRES_CASE(1, 3); BNRES_CASE(2, 3); BNRES_CASE(4, 3);
+    default: JCK_FAIL(JCK_E_ARG, "bn_act_bwd_res: no kernel for this plan");
+  }
+#undef BNRES_CASE
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

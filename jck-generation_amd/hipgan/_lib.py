@@ -57,6 +57,10 @@ PROTOS = {
     "jck_conv_down_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
     "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "jck_grid_sync_bytes": (sz, []),
+    "jck_debug_bnres_stamps": (i32, [vp]),
+    "jck_grid_sync_error": (i32, [vp]),
+    "jck_bn_act_bwd_res": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "jck_bnx_bytes": (sz, [i32, i32]),
     "jck_conv_down_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
     "jck_conv_up_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
@@ -123,6 +127,7 @@ PROTOS = {
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
     "jck_engine_grad_bucket": (i32, [vp, i32, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "jck_engine_grad_tail": (i64, [vp, i32]),
+    "jck_engine_check": (i32, [vp]),
     "jck_engine_scalars": (vp, [vp]),
     "jck_engine_scalars_at": (vp, [vp, i32]),
     "jck_engine_sample": (i32, [vp, vp, vp, i32, vp, vp]),
@@ -205,7 +210,7 @@ class _Lib:
                 if r < 0:
                     raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
                 return r
-            if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect") \
+            if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect", "jck_grid_sync_error") \
                     and r != 0:
                 raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
             return r

@@ -509,8 +509,8 @@ class DcganEngine:
         self._keep = keep
 
     def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None, graph=None,
-                   generator=None, labels=None, next_real=None, next_noise=None):
-        """Enqueues one full step; no host sync.  noise=None draws on the device (generator= / labels= as draw_noise takes
+                   generator=None, labels=None, next_real=None, next_noise=None, lr_g=None):
+        """Enqueues one full step; no host sync.  lr_g: G's learning rate when it differs from D's `lr` (eager launches only).  noise=None draws on the device (generator= / labels= as draw_noise takes
         them).  graph (default: off, env JCK_GRAPH=1 enables; never with the pipeline or per-launch profiling): replay the
         step from captured hipGraphs on the engine's own stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
         optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
@@ -527,7 +527,7 @@ class DcganEngine:
         if self._packed_version != self._shared["version"]:
             self.join()
             self.repack()
-        use_graph = (self.graphs if graph is None else graph) and not pipeline and self._eager_steps >= 1
+        use_graph = (self.graphs if graph is None else graph) and not pipeline and self._eager_steps >= 1 and lr_g is None
         pre_key = getattr(self, "_prefetched_real", None)
         if pre_key is not None:
             self._prefetched_real = None
@@ -546,6 +546,8 @@ class DcganEngine:
                 if self._fallback_inputs is not None:      # this step's inputs are already drawn / copied into the static buffers
                     real, noise = self._fallback_inputs
                     self._fallback_inputs = None
+        if lr_g is not None and pipeline:
+            raise JckError("lr_g needs the plain eager schedule")
         self._eager_steps += 1
         noise = noise if noise is not None else self.draw_noise(generator, labels=labels, fast=self.fast_noise)
         si, keep = self._inputs(real, noise, lr, grad_scale)
@@ -598,6 +600,8 @@ class DcganEngine:
                 lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), gs.cuda_stream)
         else:
             lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
+            if lr_g is not None:
+                si.lr = lr_g                 # the engine rewrites only the Adam scalars of the step for the new rate
             handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
             if handle is not None:
                 if next_real is not None and self.family == 0 and getattr(self, "_prefetch_ok", True) and not (self.graphs if graph is None else graph):
@@ -661,6 +665,7 @@ class DcganEngine:
     def scalars(self):
         """Host copy of the eight step scalars (one device->host sync)."""
         vals = self.scalars_view().cpu().tolist()
+        lib.jck_engine_check(self._h)          # raises if a grid barrier of the step timed out (results invalid)
         return dict(zip(SCALAR_NAMES, vals))
 
     def _ws_view(self, ptr, numel, dtype):

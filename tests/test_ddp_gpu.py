@@ -27,6 +27,7 @@ def _worker(rank, world, port, q, steps, B):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ["JCK_DDP_BUCKETS"] = "1"            # experimental early bucket (off by default): keep it under test
+    os.environ["JCK_BN_RES"] = "0"                 # two ranks share ONE GPU here: a resident (grid-barrier) launch needs the chip to itself
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hipgan.dist import GradReducer
     from hipgan.engine import DcganEngine
@@ -108,6 +109,7 @@ def _trainer_worker(rank, world, port, q):
     import argparse
     import tempfile
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["JCK_BN_RES"] = "0"                 # two ranks share ONE GPU here (see _worker)
     os.chdir(tempfile.mkdtemp())
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import main          # noqa: F401  (seeds every rank with RANDOMSEED, as `python main.py` does)

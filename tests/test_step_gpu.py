@@ -296,3 +296,35 @@ def test_per_pass_schedule_at_the_8gpu_tail_batch():
         assert _rel(got[k], ref[k]) < 1e-3, (k, got[k], ref[k])
     _cmp_tensors(eng.named_views("d", "grads"), dgr, 3e-2, "d_grads", 5e-3)
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
+
+
+def test_separate_generator_learning_rate_keeps_the_step_scalars():
+    """an optimiser phase called with another learning rate than the step's loss phases used to re-run
+    jck_engine_set_step, which zeroed the step's accumulator rows - loss_d / loss_g / gp were then logged as 0.  Two engines from
+    one state and one noise draw, lr 2e-4 for both nets vs lr_g 1e-4: the logged scalars and D's update must be bitwise equal,
+    and G's first Adam step (lr * m_hat / (sqrt(v_hat) + eps): proportional to lr) exactly half as large."""
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import GanOracle
+    from util import synth_images
+    B = 16
+    orc = GanOracle("dcgan", lr=2e-4, seed=12345)
+    real, nz = synth_images(B).cuda(), {k: v.cuda() for k, v in _noise(B, 7).items()}
+    res = []
+    for lr_g in (None, 1e-4):
+        eng = DcganEngine(batch=B, prec="f32")
+        eng.load_state(orc.g, orc.d)
+        g0 = {k: v.detach().clone() for k, v in eng.named_views("g").items() if k.endswith("weight")}
+        eng.step_async(real, nz, lr=2e-4, lr_g=lr_g)
+        sc = eng.scalars()
+        res.append((sc, {k: eng.named_views("g")[k].detach() - v for k, v in g0.items()},
+                    {k: v.detach().clone() for k, v in eng.named_views("d").items()}))
+    (s0, dg0, d0), (s1, dg1, d1) = res
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert s1[k] == s0[k] and (s1[k] != 0.0 or k == "gp"), (k, s0[k], s1[k])
+    assert s1["loss_d"] > 0.1 and s1["loss_g"] > 0.1
+    for k in d0:
+        assert torch.equal(d0[k], d1[k]), k
+    for k in dg0:
+        a, b = dg0[k].float(), dg1[k].float()
+        assert a.abs().max() > 0
+        assert torch.allclose(b, 0.5 * a, rtol=1e-3, atol=2e-9), (k, (b - 0.5 * a).abs().max().item(), a.abs().max().item())
