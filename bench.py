@@ -215,40 +215,31 @@ def measure(a, model, world, rank, dev, dist):
                       next_real=None if (cgan or not overlap["on"]) else batches[(i + 1) % 4])
         eng.step_async(batches[i % 4], None, 2e-4, generator=gen, labels=labels[i % 4] if cgan else None, **kw)
 
-    def replicas_in_sync():
-        """every rank holds the same parameters (the all-reduced gradients went through the same Adam): max == min of a checksum"""
-        if not dist or world == 1:
-            return True
-        torch.cuda.synchronize()
-        c = torch.stack([eng.arenas["d_params"].double().sum(), eng.arenas["g_params"].double().sum(),
-                         eng.arenas["d_params"].double().abs().sum(), eng.arenas["g_params"].double().abs().sum()])
-        hi, lo = c.clone(), c.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        return bool(torch.equal(hi, lo))
+    # every rank must hold the same parameters (the all-reduced gradients went through the same Adam); on a mismatch the guard
+    # re-broadcasts rank 0's state and switches the engine to the plain schedule (hipgan/dist.py - the trainers run the same guard)
+    from hipgan.dist import ReplicaGuard
+    guard = ReplicaGuard(eng, world if dist else 1)
 
     ddp = {}
     if not overlap["on"]:
-        os.environ["JCK_DDP_SPLIT"] = "0"
+        eng.ddp_overlap = False
     for i in range(a.warmup):
         one_step(i)
     torch.cuda.synchronize()
     if red:
         ddp["mode"] = ("D all-reduce in two pieces under D's own backward + G all-reduce under the next batch's D(real) forward"
                        if overlap["on"] and not cgan else "one all-reduce per network, waited for before its Adam")
-        ddp["replicas_in_sync_after_warmup"] = replicas_in_sync()
+        torch.cuda.synchronize()
+        ddp["replicas_in_sync_after_warmup"] = guard.check()
         if not ddp["replicas_in_sync_after_warmup"] and overlap["on"]:
             # the overlapped schedule has only ever run against one device (tests): if the first multi-device run disagrees,
             # measure the plain schedule instead of a wrong one - and say so
             overlap["on"] = False
-            os.environ["JCK_DDP_SPLIT"] = "0"
-            for key in ("g_params", "d_params", "g_m", "g_v", "d_m", "d_v"):
-                dist.broadcast(eng.arenas[key], src=0)
-            eng.mark_weights_changed()
             for i in range(max(2, a.warmup)):
                 one_step(i)
             ddp["mode"] = "one all-reduce per network, waited for before its Adam (overlapped schedule failed the replica check)"
-            ddp["replicas_in_sync_after_fallback"] = replicas_in_sync()
+            torch.cuda.synchronize()
+            ddp["replicas_in_sync_after_fallback"] = guard.in_sync()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -293,7 +284,8 @@ def measure(a, model, world, rank, dev, dist):
         if dist and world > 1:
             dist.all_reduce(ce, op=dist.ReduceOp.MAX)
         ddp["comm_exposed_ms"] = {"d": round(float(ce[0]), 4), "g": round(float(ce[1]), 4)}
-        ddp["replicas_in_sync_at_end"] = replicas_in_sync()
+        torch.cuda.synchronize()
+        ddp["replicas_in_sync_at_end"] = guard.in_sync()
         use_red["on"] = False
         for i in range(2):
             one_step(i)

@@ -111,16 +111,6 @@ int jck_grid_sync_error(const void* sync_ws);
 int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                        float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* sync_ws,
                        void* stream);
-/* BatchNorm backward fused with the dgrad that produces its input: jck_conv_up_bnbwd / jck_conv_down_bnbwd are
- * jck_conv_up / jck_conv_down whose statistic slots receive sum(g_z) and sum(g_z*xhat) of the layer whose input gradient
- * they produce (g_z = g_a*act'(z); bn_y = that layer's saved conv output, same layout as the output; bn_aux = its
- * [groups][4C] table from jck_bn_finalize*; group_images = images per BatchNorm group, 0 = one group).  jck_bn_bwd_finish
- * then reduces the [groups][slots_per_group] slots, adds dgamma/dbeta and applies
- * g_y = scale*(g_z - s1/n - xhat*s2/n).  Together they replace aten::native_batch_norm_backward +
- * aten::leaky_relu_backward / threshold_backward (model/DCGAN.py:11-24,43-56 under train/dcgan_trainer.py:164,175,187)
- * without the separate reduction pass over g_a. */
-int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
-                      int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
 /* jck_conv_down / jck_conv_up with the forward statistics laid out per BatchNorm group of `group_images` images
  * (N % group_images == 0): *stats_slots rows, the first *stats_slots / (N / group_images) of them belong to group 0, and so
  * on - what jck_bn_finalize_grouped reads.  Large launches write one row per (workgroup, group) instead of one per (tile, wave). */
@@ -128,85 +118,6 @@ int jck_conv_down_grouped(int prec, const void* big, const void* w, void* small_
                           int Wb, int Cb, int Cs, int group_images, void* stream);
 int jck_conv_up_grouped(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs,
                         int Ws, int Cs, int Cb, int group_images, void* stream);
-/* Convolutions that consume a BatchNorm'd, activated tensor WITHOUT that tensor being written ("fused BatchNorm2d + (Leaky)ReLU"
- * on the consumer side; reference model/DCGAN.py:30-33,62-65 - the nn.BatchNorm2d + nn.LeakyReLU / nn.ReLU between two
- * convolutions).  y_in / in_aux: the producer's raw conv output and its [groups][4 * C] tables (jck_bn_finalize*).  The launch
- * computes the convolution of a = act(scale * y_in + shift), bit for bit the tensor jck_bn_act_fwd_grouped(y_in, in_aux, in_slope)
- * writes, by transforming the gathered operand in LDS.  in_group_images: images per BatchNorm group of the INPUT (0: one group);
- * output statistics per group of `group_images` images as jck_conv_*_grouped.  Shapes whose kernel has no such transform (fp32,
- * < 64 gathered channels, the 3-channel image layers): a is written to a_buf (then required) by the stand-alone pass and the
- * plain launch runs; *a_written (optional) says which happened (0 fused, 1 materialised). */
-int jck_conv_down_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
-                     int* a_written, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb, int Wb, int Cb,
-                     int Cs, int group_images, void* stream);
-int jck_conv_up_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf, int* a_written,
-                   const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs, int Ws, int Cs, int Cb,
-                   int group_images, void* stream);
-int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb,
-                        int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope, int group_images, void* stream);
-int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,
-                      int slots_per_group, float* sums, void* g_y, float* dgamma, float* dbeta, long long rows_per_group, int C,
-                      int groups, int grad_groups, void* stream);
-
-/* ---- BatchNorm statistics accumulated by the launch that writes the tensor, finalised by the one that reads it ------------
- * (csrc/bnstat.hpp, round 3).  The `_x` producers are the conv / dgrad / reduction launches above with the statistics in their
- * second form: per-channel sums kept exactly (three integer limbs per sum, integer atomics - the total does not depend on the
- * arrival order, two runs give the same bits) in `xbuf`.  The `_x` consumers (jck_bn_act_fwd_x, jck_bn_bwd_apply_x) turn the
- * sums into coefficients in their prologue and leave the tables later launches read.  No jck_bn_finalize / bn_bwd_sums launch,
- * no slot rows, and - backward - no separate reduction pass over (g_a, y).
- *   xbuf: jck_bnx_bytes(C, groups) bytes, ZEROED by the caller before the producer launch (hipMemsetAsync on the same stream;
- *         the engine zeroes a whole pass's accumulators with one memset).
- *   forward  (producers jck_conv_down_x / jck_conv_up_x / jck_g1_fwd_x read xbuf, groups, group_images; consumer
- *         jck_bn_act_fwd_x; replaces aten::native_batch_norm, model/DCGAN.py:30-33,62-65): a = act(scale*y + shift), fills
- *         aux[groups][4C] = scale | shift | mean | invstd, rec[groups][2C] = mean | unbiased var (optional; the deferred
- *         running-stat record), or - groups == 1 - updates running_mean / running_var / num_batches_tracked in place (optional).
- *   backward (producers jck_conv_up_bnx / jck_conv_down_bnx = dgrad whose epilogue reads the saved conv output bn_y of the
- *         layer its output is the gradient of, and that layer's aux; jck_bn_bwd_reduce_x = the reduction pass alone, for a
- *         layer whose gradient comes from elsewhere; consumer jck_bn_bwd_apply_x): g_y = scale*(g_z - s1/n - xhat*s2/n), fills
- *         sums[groups][sums_stride] (first 2C floats of a group: sum g_z | sum g_z*xhat), adds the groups < grad_groups to
- *         dgamma / dbeta (optional).  Together: aten::native_batch_norm_backward + leaky_relu_backward / threshold_backward
- *         under train/dcgan_trainer.py:164,175,187 with ONE pass over (g_a, y) instead of two. */
-typedef struct jck_bn_job {
-  void* xbuf;                 /* accumulators, zeroed by the caller before the producer launch */
-  int groups;                 /* BatchNorm batches stored back to back in the tensor (>= 1) */
-  int group_images;           /* images per group (N = groups * group_images) */
-  /* forward */
-  const float* gamma;
-  const float* beta;
-  float eps, momentum;
-  float* aux;                 /* forward: out [groups][4C]; backward: in */
-  float* rec;                 /* [groups][2C] or NULL */
-  float* running_mean;        /* [C] or NULL (groups == 1) */
-  float* running_var;
-  int64_t* num_batches_tracked;
-  /* backward */
-  const void* bn_y;           /* saved conv output of the normalised layer, layout of the launch's output */
-  float slope;                /* LeakyReLU slope (0 = ReLU) */
-  float* sums;
-  long long sums_stride;      /* floats between two groups' rows (>= 2C) */
-  float* dgamma;
-  float* dbeta;
-  int grad_groups;
-} jck_bn_job;
-size_t jck_bnx_bytes(int C, int groups);
-int jck_conv_down_x(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
-                    const jck_bn_job* job, void* stream);
-int jck_conv_up_x(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
-                  const jck_bn_job* job, void* stream);
-int jck_g1_fwd_x(int prec, const void* z, const void* w, void* out, int B, int CiPad, int Co, const jck_bn_job* job, void* stream);
-int jck_conv_up_bnx(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
-                    const jck_bn_job* job, void* stream);
-int jck_conv_down_bnx(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
-                      const jck_bn_job* job, void* stream);
-int jck_bn_bwd_reduce_x(int prec, const void* g_a, const void* y, long long rows_per_group, int C, const jck_bn_job* job,
-                        void* stream);
-int jck_bn_act_fwd_x(int prec, const void* y, float slope, void* a, long long rows_per_group, int C, const jck_bn_job* job,
-                     void* stream);
-int jck_bn_bwd_apply_x(int prec, const void* g_a, const void* y, void* g_y, long long rows_per_group, int C, const jck_bn_job* job,
-                       void* stream);
-int jck_bn_bwd_apply(int prec, const void* g_a, const void* y, const float* aux, const float* sums, long long sums_stride,
-                     float slope, void* g_y, long long rows_per_group, int C, int groups, void* stream);
-
 /* ---- images, noise, heads, loss ----------------------------------------------------------------------------- */
 /* out NHWC4 T = keep*img + mix*noise (NCHW fp32 inputs; noise may be NULL)   train/dcgan_trainer.py:157-160 */
 int jck_img_prep(int prec, const float* img_nchw, const float* noise_nchw, float keep, float mix, void* out, int N, int HW,
@@ -397,12 +308,6 @@ typedef struct jck_step_inputs {
 } jck_step_inputs;
 int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* stream);
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
-/* Data-parallel overlap: after PHASE_D_LOSS of the batched schedule the tail of D's gradient arena (conv4.weight, norm4.*,
- * conv5.weight: 76 % of its bytes) is final long before the phase ends.  Returns 1 with that [offset, offset+numel) range
- * (floats) and, when `stream` is not NULL, makes `stream` wait for the event that marks it final - start the all-reduce of
- * that slice on `stream`; returns 0 when the step has no early bucket.  (The all-reduce the reference would need before
- * optimizer_d.step(), train/dcgan_trainer.py:180, under DistributedDataParallel.) */
-int jck_engine_grad_bucket(jck_engine*, int net, void* stream, long long* offset, long long* numel);
 /* first element of the gradient-arena tail that PHASE_D_LOSS_A finalises (net 1 = D); -1 when the schedule has no such split */
 long long jck_engine_grad_tail(const jck_engine*, int net);
 /* after a device synchronisation: JCK_E_HIP if a grid barrier of a resident launch (jck_bn_act_bwd_res) timed out since the last

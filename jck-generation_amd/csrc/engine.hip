@@ -117,8 +117,7 @@ struct Carver {
   }
 };
 
-struct BnBuf { float *stats, *sums, *aux; int slots; void *xf, *xb; };     // xf / xb: exact-sum accumulators, forward / backward (bnstat.hpp)
-struct XsRegion { unsigned char* base = nullptr; size_t bytes = 0; };     // a pass's accumulators, zeroed with ONE memset before the pass
+struct BnBuf { float *stats, *sums, *aux; int slots; };
 
 }  // namespace
 
@@ -144,15 +143,14 @@ struct jck_engine {
   float *d_head_wp, *d_head_dwp;
   void *g1_w, *g_up[JCK_MAX_STAGES], *g_down[JCK_MAX_STAGES];
   // activations: three B-image D sets for the per-pass schedules (each pass that may run concurrently has its own)
-  struct DSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES], *gx; BnBuf bn[JCK_MAX_STAGES]; float *prob, *ds, *norms; XsRegion xr; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
+  struct DSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES], *gx; BnBuf bn[JCK_MAX_STAGES]; float *prob, *ds, *norms; } dset[3];      // 0: D(fake) and the G-phase pass, 1: penalty pass, 2: D(real) (may overlap the previous step's G phase)
   void **d_y = dset[0].y, **d_a = dset[0].a, **d_g = dset[0].g;
   void*& d_gx = dset[0].gx;
   BnBuf* d_bn = dset[0].bn;
   float*& prob = dset[0].prob; float*& ds = dset[0].ds; float*& norms = dset[0].norms;
   // batched D passes (DCGAN): up to 3 batches that share D's weights go through ONE launch per layer, BatchNorm grouped
-  struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds;
-                void *xf[JCK_MAX_STAGES], *xb[JCK_MAX_STAGES], *xf_pre[JCK_MAX_STAGES]; XsRegion xr, xr_pre; } bset;
-  int batched = 0;                      // 0 off, 2 = [fake | penalty] in one pass, 3 = [real | fake | penalty]
+  struct BSet { void *y[JCK_MAX_STAGES], *a[JCK_MAX_STAGES], *g[JCK_MAX_STAGES]; float *stats[JCK_MAX_STAGES], *aux[JCK_MAX_STAGES], *sums[JCK_MAX_STAGES]; float *prob, *ds; } bset;
+  int batched = 0;                      // 0: one D pass per batch (batch % 8 != 0, JCK_BATCHED=0), 3: [real | fake | penalty] as ONE 3B pass
   bool gp_done = false;
   long long real_fwd_step = -1;         // step whose D(real) forward already ran (PHASE_D_REAL_FWD), -1: none
   int head_row0 = 0;                    // CGAN: first row of the head state (h_drop, cbuf, pre_e) the pass in hand READS (2B: penalty group of a batched head)
@@ -161,21 +159,14 @@ struct jck_engine {
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr, evBucket = nullptr;
-  bool bucket_ready = false;            // evBucket was recorded in this step's PHASE_D_LOSS (gradients of conv4.weight .. conv5.weight final)
-  bool overlap = true, gp_inflight = false, defer_join = true, fuse_bnbwd = false;
-  bool bn2 = false;                     // exact-sum statistics accumulated by the producing launch (bnstat.hpp); JCK_BN2=1
-  // BatchNorm + activation of layer i applied by the convolution that consumes it (jck_conv_*_in; JCK_BNF=0 disables): the
-  // activation tensor is then written only where the backward reads it (weight gradients, CGAN's double backward) - on
-  // fwd_side, beside the forward chain - and not at all in the G phase's pass through D (its weight gradients are dead)
-  bool bnf = false, fwd_need_a = true;
-  // cross-stream hand-overs of the backward: the producing launch completes the event itself (jck_arm_stop_event) instead of a
+  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  bool overlap = true, gp_inflight = false, defer_join = true;
+  // cross-stream hand-overs of the backward: the producing launch completes the event itself (the `done` argument of
+  // bn_act_bwd_res_ev / tanh_bwd_ev: hipExtLaunchKernel's stop event) instead of a
   // hipEventRecord behind it; JCK_EXT_EVENTS=0 restores the records
   bool ext_events = true;
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
-  hipStream_t fwd_side = nullptr;
-  XsRegion g_xr;
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
@@ -293,36 +284,6 @@ struct jck_engine {
     // which is on that stream): its own split-K workspace, because the side stream may still be using wg_ws
     g1_ws_bytes = jck_g1_wgrad_ws_bytes(B, z_pad(family), TT.G_C1);
     g1_ws = c.take<float>(g1_ws_bytes / 4);
-    // exact-sum accumulators (bnstat.hpp): forward + backward of every BatchNorm layer, one contiguous region per pass
-    {
-      auto region = [&](XsRegion& r, auto&& fill) {
-        const size_t start = c.off;
-        fill();
-        r.base = base ? base + start : nullptr; r.bytes = c.off - start;
-      };
-      for (int sI = 0; sI < 3; ++sI)
-        region(dset[sI].xr, [&] {
-          for (int i = 0; i < TT.NS; ++i) {
-            dset[sI].bn[i].xf = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1));
-            dset[sI].bn[i].xb = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1));
-          }
-        });
-      region(g_xr, [&] {
-        for (int i = 0; i < TT.NS; ++i) {
-          g_bn[i].xf = c.take<unsigned char>(jck_bnx_bytes(TT.G_C1 >> i, 1));
-          g_bn[i].xb = c.take<unsigned char>(jck_bnx_bytes(TT.G_C1 >> i, 1));
-        }
-      });
-      if (batched) {
-        region(bset.xr, [&] {
-          for (int i = 0; i < TT.NS; ++i) {
-            bset.xf[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 3));
-            bset.xb[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 3));
-          }
-        });
-        region(bset.xr_pre, [&] { for (int i = 0; i < TT.NS; ++i) bset.xf_pre[i] = c.take<unsigned char>(jck_bnx_bytes(TT.D_CS[i], 1)); });
-      }
-    }
     if (family == 1) {
       l1_w = c.take<unsigned char>(bytes((size_t)L1_OUT * L1_KPAD)); l1_wT = c.take<unsigned char>(bytes((size_t)L1_KPAD * L1_OUT));
       // head buffers: HR batches of rows - the batched schedule runs the label / Linear / Dropout head of the real | fake |
@@ -379,27 +340,16 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->overlap = !(getenv("JCK_OVERLAP") && atoi(getenv("JCK_OVERLAP")) == 0);
   // batched D passes need whole tiles per group: 16*B rows at the last layer, tiles of up to 128 rows
   e->batched = getenv("JCK_BATCHED") ? atoi(getenv("JCK_BATCHED")) : JCK_BATCHED_DEFAULT;
-  if (!e->overlap || batch % 8 != 0 || (e->batched < 2 || e->batched > 4)) e->batched = 0;
-  if (family == 1 && e->batched) e->batched = 3;     // CGAN: [real | fake] conv stacks as one 2B pass (the penalty pass stays apart)
+  if (!e->overlap || batch % 8 != 0 || e->batched != 3) e->batched = 0;
   e->carve(nullptr);
-  // BatchNorm-backward statistics in the dgrad epilogue (jck_conv_*_bnbwd): correct and tested, but measured 4 % SLOWER than
-  // the separate reduction pass at B=256 (the extra epilogue work lengthens every workgroup's tail) - opt-in
-  e->fuse_bnbwd = getenv("JCK_FUSE_BNBWD") && atoi(getenv("JCK_FUSE_BNBWD")) != 0;
-  // Exact-sum statistics accumulated by the producing launch and finalised in the consumer's prologue (bnstat.hpp; no
-  // bn_finalize / bn_bwd_reduce / bn_bwd_sums launches: 93 instead of 126 per DCGAN step).  Correct, deterministic and tested,
-  // but measured 4-6 % SLOWER at batch 256 (1.97-1.99 vs 1.85-1.89 ms): opt-in, JCK_BN2=1.
-  e->bn2 = getenv("JCK_BN2") && atoi(getenv("JCK_BN2")) != 0;
-  if (e->bn2) e->fuse_bnbwd = false;
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
-  e->bnf = getenv("JCK_BNF") && atoi(getenv("JCK_BNF")) != 0 && !e->bn2 && prec == JCK_PREC_BF16;
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
-    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
-    // (evBucket hands gradients to the communication library - possibly read by peer devices: it keeps the default fence)
-    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, p == &e->evBucket ? (unsigned)hipEventDisableTiming : jck_event_flags()));
+    hipEvent_t* ev[5 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = &e->evW[i];
+    for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
   }
   *out = e;
   return JCK_OK;
@@ -409,8 +359,8 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[6 + JCK_MAX_STAGES] = {e->evWdone, e->ev0, e->evF, e->evReal, e->evGP, e->evBucket};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = e->evW[i];
+    hipEvent_t ev[5 + JCK_MAX_STAGES] = {e->evWdone, e->ev0, e->evF, e->evReal, e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = e->evW[i];
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -530,62 +480,20 @@ static const float BN_MOM = 0.1f, BN_EPS = 1e-5f, LRELU = 0.2f;
 
 typedef jck_engine::DSet DSet;
 
-// jobs of the exact-sum statistics (include/jckgan.h: jck_bn_job)
-static jck_bn_job bn_fwd_job(void* xbuf, int groups, int group_images, const float* gamma, const float* beta, float* aux, float* rec,
-                             float* rm = nullptr, float* rv = nullptr, int64_t* nbt = nullptr) {
-  jck_bn_job j = {};
-  j.xbuf = xbuf; j.groups = groups; j.group_images = group_images; j.gamma = gamma; j.beta = beta; j.eps = 1e-5f; j.momentum = 0.1f;
-  j.aux = aux; j.rec = rec; j.running_mean = rm; j.running_var = rv; j.num_batches_tracked = nbt;
-  return j;
-}
-static jck_bn_job bn_bwd_job(void* xbuf, int groups, int group_images, const void* y, float* aux, float slope, float* sums, int C,
-                             float* dgamma, float* dbeta, int grad_groups) {
-  jck_bn_job j = {};
-  j.xbuf = xbuf; j.groups = groups; j.group_images = group_images; j.bn_y = y; j.aux = aux; j.slope = slope; j.sums = sums;
-  j.sums_stride = (long long)jck_bn_bwd_ws_floats(C); j.dgamma = dgamma; j.dbeta = dbeta; j.grad_groups = grad_groups;
-  return j;
-}
-static int zero_region(const XsRegion& r, hipStream_t st) {
-  if (r.base && r.bytes) HIPCHK(hipMemsetAsync(r.base, 0, r.bytes, st));
-  return JCK_OK;
-}
-
 // conv stack of D on activation set `D`; BatchNorm running statistics are NOT touched here: (mean, unbiased var) go to the
 // deferred record of `pass` (0 real, 1 fake, 2 penalty, 3 G phase) and are applied in that order at the end of the step,
 // which keeps the result bitwise independent of how the passes overlap on streams.
 static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st) {
   const void* in = x_in;
-  if (e->bn2) JCK_TRY(zero_region(D.xr, st));              // forward and backward accumulators of this pass
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
-    if (e->bn2) {       // the conv launch accumulates the statistics, the activation launch finalises them (no bn_finalize launch)
-      const jck_bn_job job = bn_fwd_job(D.bn[i].xf, 1, B, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), D.bn[i].aux,
-                                        e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
-      JCK_TRY(jck_conv_down_x(e->prec, in, e->d_down[i], D.y[i], B, hb, hb, TT.D_CB[i], cs, &job, st));
-      JCK_TRY(jck_bn_act_fwd_x(e->prec, D.y[i], LRELU, D.a[i], rows, cs, &job, st));
-      in = D.a[i];
-      continue;
-    }
-    // layer i - 1's BatchNorm + LeakyReLU inside this convolution's operand path when nothing else needs a[i - 1] now
-    const bool fuse = e->bnf && i > 0 && (!e->fwd_need_a || e->fwd_side);
-    if (fuse) {
-      int wrote = 0;
-      if (e->fwd_need_a) HIPCHK(hipEventRecord(e->evW[i - 1], st));
-      JCK_TRY(jck_conv_down_in(e->prec, D.y[i - 1], D.bn[i - 1].aux, 0, LRELU, D.a[i - 1], &wrote, e->d_down[i], D.y[i], D.bn[i].stats,
-                               &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
-      if (!wrote && e->fwd_need_a) {            // for the weight gradient of layer i: beside the forward chain
-        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i - 1], 0));
-        JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i - 1], D.bn[i - 1].aux, LRELU, D.a[i - 1], (long long)B * hb * hb, TT.D_CB[i], e->fwd_side));
-      }
-    } else
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
-    const bool next_fused = e->bnf && i + 1 < TT.NS && (!e->fwd_need_a || e->fwd_side);
-    if (!next_fused) JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
+    JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
     in = D.a[i];
   }
   return JCK_OK;
@@ -679,41 +587,16 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     float* dgam = want_wgrad ? e->P(e->LD, e->dg, NWN[i]) : nullptr;
     float* dbet = want_wgrad ? e->P(e->LD, e->dg, NBN[i]) : nullptr;
     // the launch that writes g_y hands it to the weight-gradient stream by completing evW[i] itself
-    const bool armed = par && e->ext_events && !e->bn2;
-    if (armed) jck_arm_stop_event(e->evW[i]);
-    if (e->bn2) {
-      // s1 | s2, dgamma, dbeta of layer i were left by the dgrad launch of layer i+1 (previous iteration); the top layer's
-      // gradient comes from the head: one reduction launch.  Then ONE pass over (g, y) writes g_y.
-      if (i == TT.NS - 1) {
-        const jck_bn_job job = bn_bwd_job(D.bn[i].xb, 1, B, D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, cs, dgam, dbet, 1);
-        JCK_TRY(jck_bn_bwd_reduce_x(e->prec, D.g[i], D.y[i], rows, cs, &job, st));
-      }
-      const jck_bn_job aj = bn_bwd_job(D.bn[i].xb, 1, B, D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, cs, dgam, dbet, 1);
-      JCK_TRY(jck_bn_bwd_apply_x(e->prec, D.g[i], D.y[i], D.g[i], rows, cs, &aj, st));
-    } else
-    if (i < TT.NS - 1 && e->fuse_bnbwd)      // the dgrad launch below (previous iteration) already left sum g_z, sum g_z*xhat in the slots
-      JCK_TRY(jck_bn_bwd_finish(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].stats, D.bn[i].slots, D.bn[i].sums, D.g[i], dgam,
-                                dbet, rows, cs, 1, 1, st));
-    else
-      JCK_TRY(jck_bn_act_bwd_res(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, 1, 1,
-                                 e->bn_res ? e->gsync : nullptr, st));
+    hipEvent_t done = par && e->ext_events ? e->evW[i] : nullptr;
+    JCK_TRY(bn_act_bwd_res_ev(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, 1, 1,
+                              e->bn_res ? e->gsync : nullptr, st, done));
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
-      // (an armed event that no launch took - a path without an armable launch - is recorded the ordinary way)
-      if (par) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+      if (par) { if (!done) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
       JCK_TRY(jck_conv_wgrad(e->prec, D.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, ws));
     }
-    if (i > 0 && e->bn2) {
-      const int cl = TT.D_CS[i - 1];
-      const jck_bn_job job = bn_bwd_job(D.bn[i - 1].xb, 1, B, D.y[i - 1], D.bn[i - 1].aux, LRELU, D.bn[i - 1].sums, cl,
-                                        want_wgrad ? e->P(e->LD, e->dg, NWN[i - 1]) : nullptr, want_wgrad ? e->P(e->LD, e->dg, NBN[i - 1]) : nullptr, 1);
-      JCK_TRY(jck_conv_up_bnx(e->prec, D.g[i], e->d_up[i], D.g[i - 1], B, hb / 2, hb / 2, cs, cb, &job, st));
-    } else
-    if (i > 0 && e->fuse_bnbwd)
-      JCK_TRY(jck_conv_up_bnbwd(e->prec, D.g[i], e->d_up[i], D.g[i - 1], D.bn[i - 1].stats, &D.bn[i - 1].slots, B, hb / 2, hb / 2, cs, cb,
-                                D.y[i - 1], D.bn[i - 1].aux, LRELU, 0, st));
-    else if (i > 0)
+    if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, D.g[i], e->d_up[i], D.g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
     else if (want_xgrad)
       JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
@@ -735,51 +618,18 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
   const void* in = x_in;
-  if (e->bn2) JCK_TRY(zero_region((g0 == 0 && n == 1) ? S.xr_pre : S.xr, st));
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     // statistic slots of group g0 start at the g0/3 point of the buffer (sized for 3B pixels at one slot per 32 pixels)
     float* stats = S.stats[i] + (size_t)g0 * (jck_stats_floats((long long)3 * B * (hb / 2) * (hb / 2), cs, 1) / 3 / (2 * cs)) * (2 * cs);
     int slots = 0;
-    if (e->bn2) {
-      // (g0, n) = (0, 3) or (1, 2): the pass's own accumulators; (0, 1) = D(real) ahead of its pass: a set of its own
-      void* xbuf = (g0 == 0 && n == 1) ? S.xf_pre[i] : S.xf[i];
-      const jck_bn_job job = bn_fwd_job(xbuf, n, B, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), S.aux[i] + (size_t)g0 * 4 * cs,
-                                        e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs);
-      JCK_TRY(jck_conv_down_x(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), n * B, hb, hb, TT.D_CB[i], cs, &job, st));
-      JCK_TRY(jck_bn_act_fwd_x(e->prec, at(S.y[i], (size_t)g0 * rows * cs), LRELU, at(S.a[i], (size_t)g0 * rows * cs), rows, cs, &job, st));
-      in = at(S.a[i], (size_t)g0 * rows * cs);
-      continue;
-    }
-    // layer i - 1's BatchNorm + LeakyReLU inside this convolution's operand path (every group with its own table); a[i - 1] is
-    // then written beside the forward chain, for the weight gradient of layer i
-    const bool fuse = e->bnf && i > 0 && (!e->fwd_need_a || e->fwd_side);
-    if (fuse) {
-      const int cl = TT.D_CS[i - 1];
-      const long long rows_in = (long long)B * hb * hb;
-      void* y_in = at(S.y[i - 1], (size_t)g0 * rows_in * cl);
-      void* a_in = at(S.a[i - 1], (size_t)g0 * rows_in * cl);
-      const float* aux_in = S.aux[i - 1] + (size_t)g0 * 4 * cl;
-      int wrote = 0;
-      if (e->fwd_need_a) HIPCHK(hipEventRecord(e->evW[i - 1], st));
-      JCK_TRY(jck_conv_down_in(e->prec, y_in, aux_in, B, LRELU, a_in, &wrote, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots,
-                               n * B, hb, hb, TT.D_CB[i], cs, B, st));
-      // (DCGAN: the penalty group - the third - has no weight gradient: its activations are never read)
-      const int n_act = e->family == 0 ? std::max(0, std::min(g0 + n, 2) - g0) : n;
-      if (!wrote && e->fwd_need_a && n_act > 0) {
-        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i - 1], 0));
-        JCK_TRY(jck_bn_act_fwd_grouped(e->prec, y_in, aux_in, LRELU, a_in, rows_in, cl, n_act, e->fwd_side));
-      }
-    } else
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, B, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
-    const bool next_fused = e->bnf && i + 1 < TT.NS && (!e->fwd_need_a || e->fwd_side);
-    if (!next_fused)
-      JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
-                                     at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
+    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
+                                   at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
     in = at(S.a[i], (size_t)g0 * rows * cs);
   }
   return JCK_OK;
@@ -796,54 +646,36 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
-  int bslots[JCK_MAX_STAGES] = {0, 0, 0, 0, 0};
   for (int i = TT.NS - 1; i >= 0; --i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     const bool resume = part == 2 && i == TT.NS - 1;      // part 2 starts at this layer's dgrad
-    const bool armed = side && e->ext_events && !e->bn2 && !resume;
-    if (armed) jck_arm_stop_event(e->evW[i]);             // the launch that writes g_y completes evW[i] itself
-    if (resume) {
-    } else if (e->bn2) {
-      if (i == TT.NS - 1) {            // the top layer's gradient comes from the head: one reduction launch over all groups
-        const jck_bn_job job = bn_bwd_job(S.xb[i], G, B, S.y[i], S.aux[i], LRELU, S.sums[i], cs, e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), gw);
-        JCK_TRY(jck_bn_bwd_reduce_x(e->prec, S.g[i], S.y[i], rows, cs, &job, st));
-      }
-      const jck_bn_job aj = bn_bwd_job(S.xb[i], G, B, S.y[i], S.aux[i], LRELU, S.sums[i], cs, e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), gw);
-      JCK_TRY(jck_bn_bwd_apply_x(e->prec, S.g[i], S.y[i], S.g[i], rows, cs, &aj, st));
-    } else if (i < TT.NS - 1 && e->fuse_bnbwd)
-      JCK_TRY(jck_bn_bwd_finish(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.stats[i], bslots[i] / G, S.sums[i], S.g[i],
-                                e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, st));
-    else
-      JCK_TRY(jck_bn_act_bwd_res(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NWN[i]),
-                                 e->P(e->LD, e->dg, NBN[i]), rows, cs, G, gw, e->bn_res ? e->gsync : nullptr, st));
+    // The bottom layer's weight gradient is the last product of the pass and nothing but the penalty's image gradient runs
+    // beside it (37 us of the main stream waiting for it in round 3).  Its operand is the gradient of the LOSS groups only:
+    // their BatchNorm backward goes first, the weight gradient starts behind it on the second stream, and the penalty
+    // group's BatchNorm backward (a launch of its own - in the resident form the groups of this layer go one after the other
+    // anyway) runs beside it.
+    // (the split does not depend on the stream layout: a captured, one-stream step is the same arithmetic launch for launch)
+    const bool split0 = !resume && i == 0 && e->bn_res && e->prec == JCK_PREC_BF16 && gw > 0 && gw < G;
+    hipEvent_t done = side && e->ext_events && !resume ? e->evW[i] : nullptr;    // the launch that writes g_y completes evW[i] itself
+    if (!resume)
+      JCK_TRY(bn_act_bwd_res_ev(e->prec, S.g[i], S.y[i], S.aux[i], LRELU, S.sums[i], S.g[i], e->P(e->LD, e->dg, NWN[i]),
+                                e->P(e->LD, e->dg, NBN[i]), rows, cs, split0 ? gw : G, gw, e->bn_res ? e->gsync : nullptr, st, done));
     const void* big = i == 0 ? x_in : S.a[i - 1];
-    hipStream_t ws = st;
     if (!resume) {
-    if (side) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
-    JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
+      hipStream_t ws = st;
+      if (side) { if (!done) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+      JCK_TRY(jck_conv_wgrad(e->prec, S.g[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, gw * B, hb, hb, cb, cs, ws));
     }
+    if (split0)
+      JCK_TRY(bn_act_bwd_res_ev(e->prec, at(S.g[i], (size_t)gw * rows * cs), at(S.y[i], (size_t)gw * rows * cs), S.aux[i] + (size_t)gw * 4 * cs, LRELU,
+                                S.sums[i] + (size_t)gw * jck_bn_bwd_ws_floats(cs), at(S.g[i], (size_t)gw * rows * cs), nullptr, nullptr, rows, cs,
+                                G - gw, 0, e->gsync, st, nullptr));
     if (part == 1) {
       if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
       return JCK_OK;
     }
-    if (!resume && i == TT.NS - 1 && e->family == 0 && G == 3) {
-      // conv4.weight, norm4.* and conv5.weight (the tail of D's gradient arena, 76 % of its bytes) are final once this
-      // product has run: a data-parallel caller may start their all-reduce now, under the rest of the backward
-      // (jck_engine_grad_bucket)
-      HIPCHK(hipEventRecord(e->evBucket, ws));
-      e->bucket_ready = true;
-    }
-    if (i > 0 && e->bn2) {
-      const int cl = TT.D_CS[i - 1];
-      const jck_bn_job job = bn_bwd_job(S.xb[i - 1], G, B, S.y[i - 1], S.aux[i - 1], LRELU, S.sums[i - 1], cl, e->P(e->LD, e->dg, NWN[i - 1]),
-                                        e->P(e->LD, e->dg, NBN[i - 1]), gw);
-      JCK_TRY(jck_conv_up_bnx(e->prec, S.g[i], e->d_up[i], S.g[i - 1], G * B, hb / 2, hb / 2, cs, cb, &job, st));
-    } else if (i > 0 && e->fuse_bnbwd) {
-      JCK_TRY(jck_conv_up_bnbwd(e->prec, S.g[i], e->d_up[i], S.g[i - 1], S.stats[i - 1], &bslots[i - 1], G * B, hb / 2, hb / 2, cs, cb,
-                                S.y[i - 1], S.aux[i - 1], LRELU, B, st));
-      if (bslots[i - 1] % G) JCK_FAIL(JCK_E_ARG, "batched D pass: backward statistic slots do not split by group");
-    } else if (i > 0)
+    if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, S.g[i], e->d_up[i], S.g[i - 1], nullptr, nullptr, 0, G * B, hb / 2, hb / 2, cs, cb, st));
     else if (xgrad_last)
       JCK_TRY(jck_conv_up(e->prec, at(S.g[0], (size_t)(G - 1) * rows * cs), e->d_up[0], e->d_gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
@@ -990,29 +822,6 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
     if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, 100, zp, e->g_z, st); else launch_pad_rows<float>(z, B, 100, zp, e->g_z, st);
     HIPCHK(hipGetLastError());
   }
-  if (e->bn2) {
-    // statistics, scale / shift and the running statistics of layer i come out of the launch that writes its input
-    JCK_TRY(zero_region(e->g_xr, st));
-    auto job_of = [&](int i) {
-      return bn_fwd_job(e->g_bn[i].xf, 1, B, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]), e->g_bn[i].aux, nullptr,
-                        e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset, e->gnbt + i);
-    };
-    const jck_bn_job j0 = job_of(0);
-    JCK_TRY(jck_g1_fwd_x(e->prec, e->g_z, e->g1_w, e->g_y[0], B, zp, TT.G_C1, &j0, st));
-    for (int i = 0; i < TT.NS; ++i) {
-      const int h = 4 << i, C = TT.G_C1 >> i;
-      const long long rows = (long long)B * h * h;
-      const jck_bn_job jc = job_of(i);
-      JCK_TRY(jck_bn_act_fwd_x(e->prec, e->g_y[i], 0.f, e->g_a[i], rows, C, &jc, st));
-      if (i < TT.NS - 1) {
-        const jck_bn_job ji = job_of(i + 1);
-        JCK_TRY(jck_conv_up_x(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], B, h, h, TT.G_CS[i], TT.G_CB[i], &ji, st));
-      } else {
-        JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
-      }
-    }
-    return JCK_OK;
-  }
   JCK_TRY(jck_g1_fwd(e->prec, e->g_z, e->g1_w, e->g_y[0], e->g_bn[0].stats, &e->g_bn[0].slots, B, zp, TT.G_C1, st));
   for (int i = 0; i < TT.NS; ++i) {
     const int h = 4 << i, C = TT.G_C1 >> i;
@@ -1020,20 +829,8 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
     JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]),
                             e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset,
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
-    // BatchNorm + ReLU of layer i inside the next ConvTranspose's operand path; a[i] itself (the weight gradient of that layer
-    // reads it in the G phase) is written beside the chain.  The last layer feeds the thin image kernel: always written here.
-    const bool fuse = e->bnf && i < TT.NS - 1 && e->fwd_side;
-    if (!fuse) JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
-    if (fuse) {
-      int wrote = 0;
-      HIPCHK(hipEventRecord(e->evW[i], st));
-      JCK_TRY(jck_conv_up_in(e->prec, e->g_y[i], e->g_bn[i].aux, 0, 0.f, e->g_a[i], &wrote, e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats,
-                             &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
-      if (!wrote) {
-        HIPCHK(hipStreamWaitEvent(e->fwd_side, e->evW[i], 0));
-        JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, e->fwd_side));
-      }
-    } else if (i < TT.NS - 1)
+    JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
+    if (i < TT.NS - 1)
       JCK_TRY(jck_conv_up_grouped(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
     else                                             // last ConvTranspose + tanh -> the image
       JCK_TRY(jck_conv_up(e->prec, e->g_a[i], e->g_up[i], e->fake_raw, nullptr, nullptr, 1, B, h, h, TT.G_CS[i], TT.G_CB[i], st));
@@ -1045,33 +842,21 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
 static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side) {
   // every launch that writes a gradient the weight-gradient stream reads (tanh backward, then the BatchNorm backward of each
   // stage) completes that stage's event itself
-  const bool armed = side && e->ext_events && !e->bn2 && !e->fuse_bnbwd;
-  if (armed) jck_arm_stop_event(e->evW[TT.NS - 1]);
-  JCK_TRY(jck_tanh_bwd(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st));
+  const bool ext = side && e->ext_events;
+  JCK_TRY(tanh_bwd_ev(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st, ext ? e->evW[TT.NS - 1] : nullptr));
   const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
   for (int i = TT.NS - 1; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = TT.G_CS[i]), big side has TT.G_CB[i] channels
     const int hs = TT.G_HS[i], cs = TT.G_CS[i], cb = TT.G_CB[i];
     hipStream_t ws = st;
-    if (side) { if (!armed || jck_take_stop_event()) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
+    if (side) { if (!ext) HIPCHK(hipEventRecord(e->evW[i], st)); HIPCHK(hipStreamWaitEvent(side, e->evW[i], 0)); ws = side; }
     JCK_TRY(jck_conv_wgrad(e->prec, e->g_a[i], gbig, e->wg_ws, e->wg_ws_bytes, e->P(e->LG, e->gg, CWN[i + 1]), 1, B,
                            2 * hs, 2 * hs, cb, cs, ws));
     const long long rows = (long long)B * hs * hs;
-    if (e->bn2) {
-      const jck_bn_job job = bn_bwd_job(e->g_bn[i].xb, 1, B, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, cs, e->P(e->LG, e->gg, NWN[i]),
-                                        e->P(e->LG, e->gg, NBN[i]), 1);
-      JCK_TRY(jck_conv_down_bnx(e->prec, gbig, e->g_down[i], e->g_gr[i], B, 2 * hs, 2 * hs, cb, cs, &job, st));
-      JCK_TRY(jck_bn_bwd_apply_x(e->prec, e->g_gr[i], e->g_y[i], e->g_gr[i], rows, cs, &job, st));
-    } else if (e->fuse_bnbwd) {
-      JCK_TRY(jck_conv_down_bnbwd(e->prec, gbig, e->g_down[i], e->g_gr[i], e->g_bn[i].stats, &e->g_bn[i].slots, B, 2 * hs, 2 * hs, cb, cs,
-                                  e->g_y[i], e->g_bn[i].aux, 0.f, 0, st));
-      JCK_TRY(jck_bn_bwd_finish(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].stats, e->g_bn[i].slots, e->g_bn[i].sums,
-                                e->g_gr[i], e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, st));
-    } else {
-      JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
-      if (armed && i > 0) jck_arm_stop_event(e->evW[i - 1]);      // g_gr[i] is what stage i - 1's weight gradient reads
-      JCK_TRY(jck_bn_act_bwd_res(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
-                                 e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, e->bn_res ? e->gsync : nullptr, st));
-    }
+    JCK_TRY(jck_conv_down(e->prec, gbig, e->g_down[i], e->g_gr[i], nullptr, nullptr, B, 2 * hs, 2 * hs, cb, cs, st));
+    // g_gr[i] is what stage i - 1's weight gradient reads
+    JCK_TRY(bn_act_bwd_res_ev(e->prec, e->g_gr[i], e->g_y[i], e->g_bn[i].aux, 0.f, e->g_bn[i].sums, e->g_gr[i],
+                              e->P(e->LG, e->gg, NWN[i]), e->P(e->LG, e->gg, NBN[i]), rows, cs, 1, 1, e->bn_res ? e->gsync : nullptr, st,
+                              ext && i > 0 ? e->evW[i - 1] : nullptr));
     gbig = e->g_gr[i];
   }
   // G.conv1's weight gradient depends on the last kernel of the main stream: it runs there, behind it, with its own
@@ -1139,7 +924,6 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   DSet& D1 = e->dset[1];
   DSet& DR = cg ? e->dset[0] : e->dset[2];          // D(real): own set so it may run beside the previous step's G phase
   e->parity = in->step & 1;
-  if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_REAL || phase == JCK_PHASE_D_LOSS_A) e->bucket_ready = false;
   // eager callers that did not call jck_engine_set_step: the step's scalars / Philox words are written by its first phase
   // (a phase called with another learning rate than the step's earlier phases - separate G and D rates - rewrites the Adam
   // scalars only: the step's accumulator rows and random inputs are live)
@@ -1151,23 +935,18 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   e->scal_out = e->scal2 + 8 * e->parity;
   // stream overlap (DCGAN): A = wgrads, B = G forward beside D(real), C = penalty pass beside D(fake).  CGAN keeps the penalty
   // on the main stream (it produces gradients and shares the head buffers).
-  // weight gradients beside the dgrad chain on a second stream: +8 % for DCGAN.  CGAN: +1.4 % since round 3 (2.886 vs 2.929 ms eager,
-  // tests/_ab.sh; in round 2 its ~280 launches per step were enqueue-bound and the second stream bought nothing, 3.478 vs 3.456) -
-  // on unless JCK_CGAN_SIDE=0.  A captured step keeps everything on one stream either way (below).
+  // weight gradients beside the dgrad chain on a second stream: +8 % for DCGAN in round 1, +1.5 % now; CGAN +1.4 % (2.886 vs
+  // 2.929 ms eager, round 3).  JCK_WGRAD_SIDE=0 keeps them on the main stream.  A captured step keeps everything on one stream
+  // either way (below).
   static const bool wgrad_side = !(getenv("JCK_WGRAD_SIDE") && atoi(getenv("JCK_WGRAD_SIDE")) == 0);
-  static const bool cgan_side = !(getenv("JCK_CGAN_SIDE") && atoi(getenv("JCK_CGAN_SIDE")) == 0);
   // Under a stream capture everything stays on the capturing stream: a hipGraph with parallel branches makes the ROCm 7.2
   // runtime keep per-graph side streams, costs ~7 us of host time per node at launch, ran slower than the linear graph for
   // CGAN, and its hipGraphLaunch reads past the end of the graph's stream pool whenever two of those streams share the launch
   // stream's hardware queue (hip::Graph::UpdateStreams; cause and frame in DESIGN.md section 5.6; jck_engine_capture_end refuses
   // any non-linear graph).  Same kernels, same order per stream as the eager schedule - bitwise the same results.
   const bool par = e->overlap && !e->capturing;
-  hipStream_t sA = (par && wgrad_side && (!cg || cgan_side)) ? e->sA : nullptr;
-  // where a forward pass writes the activations only its backward reads (e->bnf).  CGAN's double backward reads them on the main
-  // stream: its D phase keeps the stand-alone passes
-  e->fwd_side = cg ? nullptr : sA;
-  e->fwd_need_a = true;
-  const bool ov_g = par, ov_gp = par && !cg && !(e->batched == 2 && phase == JCK_PHASE_D_LOSS);
+  hipStream_t sA = (par && wgrad_side) ? e->sA : nullptr;
+  const bool ov_g = par, ov_gp = par && !cg;
   auto penalty_pass = [&](DSet& D, hipStream_t s) -> int {                                      // :110-127, 178
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
     JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
@@ -1224,25 +1003,6 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           e->head_wrow0 = 0;
         }
         JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
-        e->gp_done = true;
-        return JCK_OK;
-      }
-      if (!cg && e->batched == 4) {                   // as 3, but D(real)'s forward runs beside G's forward
-        if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
-        JCK_TRY(clear_acc(e, in->step, st));
-        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
-        HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0));
-        JCK_TRY(g_forward(e, in->z, in->labels, B, e->sB));                                       // :168-169
-        JCK_TRY(e->mix_fake_noise(in, B, e->sB));   // :171
-        HIPCHK(hipEventRecord(e->evF, e->sB));
-        JCK_TRY(prep_real(e, in, B, st));   // :160
-        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                             // :162
-        HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
-        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));      // :111-113
-        JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                                   // :173, 118
-        const float tg[2] = {0.9f, 0.1f};
-        const int sl[2] = {0, 1}, sp[2] = {3, 4};
-        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, true));             // :163-176, 178
         e->gp_done = true;
         return JCK_OK;
       }
@@ -1303,14 +1063,6 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       // ---- D on the fake batch (:170-176) with the penalty pass (:178) beside it
       if (ov_g) HIPCHK(hipStreamWaitEvent(st, e->evF, 0));
-      if (e->batched == 2 && phase == JCK_PHASE_D_LOSS) {       // [fake | penalty] as one 2B pass
-        JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, st));
-        const float tg[1] = {0.1f};
-        const int sl[1] = {1}, sp[1] = {4};
-        JCK_TRY(d_batched_pass(e, e->fake, B, 2, 1, tg, sl, sp, st, sA));
-        e->gp_done = true;
-        return JCK_OK;
-      }
       if (ov_gp) {                                   // penalty pass on its own stream and activation set
         if (phase == JCK_PHASE_D_FAKE) HIPCHK(hipEventRecord(e->evReal, st));    // real_noisy came from an earlier call on st
         HIPCHK(hipStreamWaitEvent(e->sC, e->evF, 0));
@@ -1339,8 +1091,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
       if (e->gp_done && cg) {                         // forward and first backward ran as group 2 of the batched pass
         e->gp_done = false;
-        static const bool cg_side2 = cgan_side;
-        JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side2 ? sA : nullptr));
+        JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, sA));
         e->head_row0 = 0;
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
         return JCK_OK;
@@ -1353,8 +1104,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       }
       JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
-        static const bool cg_side = cgan_side;
-        JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 10.0f, in->drop_mask[2], st, cg_side ? sA : nullptr));
+        JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 10.0f, in->drop_mask[2], st, sA));
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
       }
       return JCK_OK;
@@ -1367,9 +1117,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
-      e->fwd_need_a = false;            // D's weight gradients from this pass are dead: only the head reads an activation
       JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st));
-      e->fwd_need_a = true;
       JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
       JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr));
@@ -1494,14 +1242,14 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
       HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
     }
     // ... and so may the events recorded inside it
-    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP, &e->evBucket};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
+    hipEvent_t* ev[5 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = &e->evW[i];
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;
-      HIPCHK(hipEventCreateWithFlags(p, p == &e->evBucket ? (unsigned)hipEventDisableTiming : jck_event_flags()));
+      HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
     }
-    e->bucket_ready = false; e->gp_inflight = false;
+    e->gp_inflight = false;
     (void)hipGetLastError();
   }
   return JCK_OK;
@@ -1513,22 +1261,6 @@ extern "C" int jck_graph_launch(void* graph_exec, void* stream) {
 }
 extern "C" void jck_graph_destroy(void* graph_exec) {
   if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
-}
-
-// Early gradient bucket of PHASE_D_LOSS (batched schedule): returns 1 and the [offset, offset + numel) range of D's gradient
-// arena whose values are final as soon as the recorded event fires, and - when `stream` is not NULL - makes `stream` wait
-// for that event (and consumes it); returns 0 when this step has no early bucket (per-pass schedules, CGAN).
-extern "C" int jck_engine_grad_bucket(jck_engine* e, int net, void* stream, long long* offset, long long* numel) {
-  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
-  if (net != 1 || !e->bucket_ready || !e->evBucket) return 0;
-  const long long off = find(e->LD, CWN[TT.NS - 1])->offset;
-  if (offset) *offset = off;
-  if (numel) *numel = (long long)e->LD.n_params - off;
-  if (stream) {
-    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evBucket, 0));
-    e->bucket_ready = false;
-  }
-  return 1;
 }
 
 extern "C" long long jck_engine_grad_tail(const jck_engine* e, int net) {
@@ -1553,7 +1285,6 @@ extern "C" int jck_engine_sample(jck_engine* e, const float* z, const int64_t* l
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (n < 1 || n > e->B) JCK_FAIL(JCK_E_ARG, "sample: n must be in [1, batch]");
   hipStream_t st = (hipStream_t)stream;
-  e->fwd_side = nullptr;                // (sampling: one stream, every activation where the plain forward leaves it)
   JCK_TRY(g_forward(e, z, labels, n, st));
   return jck_nhwc4_to_nchw(e->prec, e->fake_raw, out_nchw, n, TT.HW, st);
 }

@@ -6,7 +6,6 @@
 // two runs of a step give bitwise identical gradients and scalars).
 #pragma once
 #include "common.hpp"
-#include "bnstat.hpp"
 
 // ------------------------------------------------------------------------------------------------------
 // In-kernel instance noise (perf mode): the reference draws 0.1 * N(0,1) for every pixel of the real and of the fake batch each
@@ -253,12 +252,6 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, i
 #ifndef JCK_BN_PRIO
 #define JCK_BN_PRIO 3
 #endif
-// The streaming BatchNorm kernels run at wave priority 3: in the backward passes they share the chip with the weight-gradient
-// products of the second stream, whose waves otherwise win the issue arbitration by age (step 1.8535 -> 1.8466 ms, two A/B
-// rounds on one box; -DJCK_BN_PRIO=0 to compare)
-#ifndef JCK_BN_PRIO
-#define JCK_BN_PRIO 3
-#endif
 // stats: [slots][2][C] partial sums / sums of squares written by the GEMM epilogue (every slot complete).
 // aux layout (floats): [0,C) scale = gamma*invstd   [C,2C) shift = beta - mean*scale
 //                      [2C,3C) mean                 [3C,4C) invstd
@@ -350,10 +343,7 @@ template <typename T, int UNR = 1>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ ga, const T* __restrict__ y,
                                                             const float* __restrict__ aux, float slope,
                                                             float* __restrict__ partial, long long rows, int C,
-                                                            long long group_stride = 0, const BnStatJob bj = BnStatJob{}) {
-  // bj.xs != nullptr (bnstat.hpp): the workgroup sums go to the exact per-channel accumulators by integer atomics and
-  // bn_bwd_apply_x_kernel makes s1 | s2, dgamma, dbeta of them - no partial rows, no bn_bwd_sums launch; the second sum is
-  // then sum g_z (y - mean), multiplied by invstd once by the consumer
+                                                            long long group_stride = 0) {
   extern __shared__ float lsum[];                         // [rstep][2][C]
   __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
   ga += (long long)blockIdx.y * rows * C; y += (long long)blockIdx.y * rows * C;                    // group
@@ -385,7 +375,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const float z = vy[u][k] * sc[k] + sh[k];
         const float gz = z > 0.f ? vg[u][k] : slope * vg[u][k];
         s1[k] += gz;
-        s2[k] += bj.xs ? gz * (vy[u][k] - mu[k]) : gz * ((vy[u][k] - mu[k]) * is[k]);
+        s2[k] += gz * ((vy[u][k] - mu[k]) * is[k]);
       }
     }
   }
@@ -395,8 +385,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float t = 0.f;
     for (int rr = 0; rr < rstep; ++rr) t += lsum[rr * 2 * C + i];
-    if (bj.xs) xsum_add(bj, (int)(blockIdx.x % (unsigned)bj.reps), (int)blockIdx.y, i >= C ? 1 : 0, i >= C ? i - C : i, t);
-    else partial[(long long)blockIdx.x * 2 * C + i] = t;
+    partial[(long long)blockIdx.x * 2 * C + i] = t;
   }
 }
 
@@ -485,105 +474,6 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restric
       const float gz = z > 0.f ? vg[k] : slope * vg[k];
       const float xh = (vy[k] - aux[2 * C + c + k]) * aux[3 * C + c + k];
       vg[k] = sc * (gz - sums[c + k] * inv_count - xh * (sums[C + c + k] * inv_count));
-    }
-    st8(gy + i * 8, vg);
-  }
-}
-
-// Consumers of the exact-sum statistics (bnstat.hpp).  Every workgroup first turns the sums of its group into per-channel
-// coefficients in LDS (a few KB of loads behind the kernel boundary - no statistics-finalising launch), then streams its share of
-// the tensor, 16 bytes per lane; workgroup 0 of a group also leaves the tables later launches read.
-// a = act(scale[c]*y + shift[c]);   writes aux = scale | shift | mean | invstd, the running-stat record / running statistics
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_x_kernel(const T* __restrict__ y, const BnStatJob j, float slope,
-                                                           T* __restrict__ a, long long total8) {
-  extern __shared__ float cf[];                           // [2][C]: scale | shift
-  const int C = j.C, g = blockIdx.y;
-  const bool poison = bn_poisoned(j);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const BnFwdCoef k = bn_fwd_coef(j, g, c, poison);
-    cf[c] = k.scale; cf[C + c] = k.shift;
-    if (blockIdx.x == 0) {
-      float* aux = j.aux + (long long)g * 4 * C;
-      aux[c] = k.scale; aux[C + c] = k.shift; aux[2 * C + c] = k.mean; aux[3 * C + c] = k.invstd;
-      if (j.rec) { j.rec[(long long)g * 2 * C + c] = k.mean; j.rec[(long long)g * 2 * C + C + c] = k.unbiased; }
-      if (j.running_mean && g == 0) {
-        j.running_mean[c] = (1.f - j.momentum) * j.running_mean[c] + j.momentum * k.mean;
-        j.running_var[c] = (1.f - j.momentum) * j.running_var[c] + j.momentum * k.unbiased;
-      }
-    }
-  }
-  if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && j.nbt) *j.nbt += 1;
-  __syncthreads();
-  y += (long long)g * total8 * 8; a += (long long)g * total8 * 8;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += 2 * stride) {
-    const long long i1 = i + stride;
-    float v[8], u[8];
-    ld8(y + i * 8, v);
-    if (i1 < total8) ld8(y + i1 * 8, u);
-    const int c = (int)((i * 8) & (C - 1)), c1 = (int)((i1 * 8) & (C - 1));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float z = v[k] * cf[c + k] + cf[C + c + k];
-      v[k] = z > 0.f ? z : slope * z;
-    }
-    st8(a + i * 8, v);
-    if (i1 < total8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float z = u[k] * cf[c1 + k] + cf[C + c1 + k];
-        u[k] = z > 0.f ? z : slope * z;
-      }
-      st8(a + i1 * 8, u);
-    }
-  }
-}
-
-// g_y = scale * (g_z - s1/n - xhat * s2/n);   writes sums = s1 | s2 per group, dgamma += sum_g s2, dbeta += sum_g s1
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_x_kernel(const T* __restrict__ ga, const T* __restrict__ y, const BnStatJob j,
-                                                             float slope, float inv_count, T* __restrict__ gy, long long total8) {
-  extern __shared__ float cf[];                           // [6][C]: scale | shift | mean | invstd | s1/n | s2/n
-  const int C = j.C, g = blockIdx.y;
-  const bool poison = bn_poisoned(j);
-  const float* aux = j.aux + (long long)g * 4 * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float is = aux[3 * C + c];
-    float s1, s2;
-    bn_bwd_sums(j, g, c, poison, is, s1, s2);
-    cf[c] = aux[c]; cf[C + c] = aux[C + c]; cf[2 * C + c] = aux[2 * C + c]; cf[3 * C + c] = is;
-    cf[4 * C + c] = s1 * inv_count; cf[5 * C + c] = s2 * inv_count;
-    if (blockIdx.x == 0) {
-      j.sums[(long long)g * j.sums_stride + c] = s1;
-      j.sums[(long long)g * j.sums_stride + C + c] = s2;
-      if (g == 0 && (j.dgamma || j.dbeta)) {              // the gradient groups in order: independent of any arrival order
-        float dg = s2, db = s1;
-        for (int q = 1; q < j.grad_groups; ++q) {
-          float t1, t2;
-          bn_bwd_sums(j, q, c, poison, j.aux[(long long)q * 4 * C + 3 * C + c], t1, t2);
-          dg += t2; db += t1;
-        }
-        if (j.grad_groups < 1) { dg = 0.f; db = 0.f; }
-        if (j.dgamma) j.dgamma[c] += dg;
-        if (j.dbeta) j.dbeta[c] += db;
-      }
-    }
-  }
-  __syncthreads();
-  ga += (long long)g * total8 * 8; y += (long long)g * total8 * 8; gy += (long long)g * total8 * 8;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)((i * 8) & (C - 1));
-    float vg[8], vy[8];
-    ld8(ga + i * 8, vg);
-    ld8(y + i * 8, vy);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float sc = cf[c + k];
-      const float z = vy[k] * sc + cf[C + c + k];
-      const float gz = z > 0.f ? vg[k] : slope * vg[k];
-      const float xh = (vy[k] - cf[2 * C + c + k]) * cf[3 * C + c + k];
-      vg[k] = sc * (gz - cf[4 * C + c + k] - xh * cf[5 * C + c + k]);
     }
     st8(gy + i * 8, vg);
   }

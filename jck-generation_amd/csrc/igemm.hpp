@@ -19,7 +19,6 @@
 // per-(tile, wave) slot that jck_bn_finalize sums - and tanh.
 #pragma once
 #include "common.hpp"
-#include "bnstat.hpp"
 
 struct IgemmParams {
   const void* act;        // gathered NHWC tensor, element type T
@@ -52,30 +51,11 @@ struct IgemmParams {
   long long out_split_stride;
   int out_f32;            // store fp32 regardless of T (split-K slabs)
   long long w_phase_stride;
-  // BatchNorm-backward statistics instead of forward ones (dgrad launches): with bn_y != nullptr the stats slots receive
-  // sum(g_z) and sum(g_z * xhat) of the layer whose input gradient this launch produces - g_z = g_a * act'(z),
-  // z = y*scale + shift, xhat = (y - mean)*invstd, y = that layer's saved conv output (same layout as `out`), aux = its
-  // [scale | shift | mean | invstd] table ([groups][4*cstat]; group = pixel row / bn_group_rows when bn_group_rows > 0)
-  const void* bn_y;
-  const float* bn_aux;
-  float bn_slope;
-  int bn_group_rows;
-  // forward statistics accumulated per workgroup and BatchNorm group by the persistent kernels (rows [group][rank][2][cstat],
-  // group = pixel row / bn_group_rows) instead of one row per (tile, wave); set by the launcher for the *_grouped entry points
+  int bn_group_rows;      // > 0: BatchNorm group = pixel row / bn_group_rows (independent batches that went through ONE launch)
+  // forward statistics accumulated per workgroup and BatchNorm group by the persistent kernels (rows [group][rank][2][cstat])
+  // instead of one row per (tile, wave); set by the launcher for the *_grouped entry points
   int stat_accum;
-  // second form of the statistics (bnstat.hpp): exact sums by integer atomics, finalised by the launch's last workgroup.
-  // bnj.xs != nullptr switches every statistics path of this file to it (forward: bnj.mode 1; with bn_y: mode 2, the second
-  // sum is sum g_z (y - mean)); `stats` is then unused.  Groups = pixel row / bn_group_rows as above.
-  BnStatJob bnj;
   int loader_prio;        // persistent kernels: s_setprio of the loader waves (jck_tune "igemm_prio")
-  // Fused BatchNorm + (Leaky)ReLU on the GATHERED operand (persistent kernels, round 3): `act` is then the producer's raw conv
-  // output y, and the loader waves turn every piece they have brought into LDS into a = act(y * scale[c] + shift[c]), rounded to
-  // bf16 - the tensor the stand-alone bn_act_fwd pass would have written (same arithmetic, same bits) - before the consumer
-  // waves see it; out-of-image taps and rows past M stay zero.  in_aux: [in_groups][4 * C] tables as bn_finalize writes them
-  // (scale | shift | ..), group of image n = n / in_group_images (0: one group).
-  const float* in_aux;
-  int in_groups, in_group_images;
-  float in_slope;
   double flops;           // algorithmic FLOPs of this launch (profiling only)
 };
 
@@ -99,17 +79,6 @@ template <class P, int BCH, int BPIX, int NW = 4> struct IgemmCfg {      // NW: 
 };
 
 
-// this lane's 4 consecutive saved-output values per accumulator fragment, loaded BEFORE the main loop when the launch
-// computes BatchNorm-backward statistics (the loads complete under the k-loop instead of stalling the epilogue)
-template <class P> struct BnRaw;
-template <> struct BnRaw<PrecBf16> { typedef u32x2 R; };
-template <> struct BnRaw<PrecF32> { typedef f32x4 R; };
-__device__ __forceinline__ void bn_unpack(u32x2 r, float (&v)[4]) {
-  v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
-  v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
-}
-__device__ __forceinline__ void bn_unpack(f32x4 r, float (&v)[4]) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
-
 template <int FN>
 __device__ __forceinline__ void igemm_pixel_offsets(const IgemmParams& p, int lane, int wpix, int m0, long long (&poff)[FN]) {
 #pragma unroll
@@ -122,88 +91,35 @@ __device__ __forceinline__ void igemm_pixel_offsets(const IgemmParams& p, int la
   }
 }
 
-template <class P, int FM, int FN>
-__device__ __forceinline__ void igemm_bn_prefetch(const IgemmParams& p, int lane, int wch, int wpix, int z, int m0, int ch0,
-                                                  typename BnRaw<P>::R (&ypre)[FM][FN]) {
-  typedef typename P::T T;
-  typedef typename BnRaw<P>::R R;
-  long long poff[FN];
-  igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
-  const T* by = reinterpret_cast<const T*>(p.bn_y);
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      R r = {};
-      if (ch < p.NchStore && poff[j] >= 0) r = *reinterpret_cast<const R*>(by + poff[j] + p.obase[z] + ch);
-      ypre[i][j] = r;
-    }
-  }
-}
-
 // Shared epilogue: optional BatchNorm partial statistics, bias, tanh, NHWC store of 4 consecutive channels per lane.
-template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN, bool BNB>
+template <class P, int BCH, int BPIX, int FM, int FN, int WPIXN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z, int zraw,
-                                               int bidx, int bidy, int m0, int ch0, typename BnRaw<P>::R (&ypre)[BNB ? FM : 1][BNB ? FN : 1],
-                                               float* x2scr = nullptr) {
+                                               int bidx, int bidy, int m0, int ch0) {
   typedef typename P::T T;
   // ---- epilogue --------------------------------------------------------------------------------------
   long long poff[FN];                                               // output offset of this lane's pixel in tile column j (-1: past M)
   igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
-  const bool x2 = p.bnj.xs != nullptr;                              // exact sums by atomics (bnstat.hpp) instead of slot rows
-  if (p.stats || x2) {
+  if (p.stats) {
     // slot = one (pixel tile, phase, channel-set replica, pixel-wave); every (slot, channel) is written exactly once
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
     // pixel tile slowest, so that the slots of consecutive pixel ranges (BatchNorm groups) are consecutive too
     const long long slot = (((long long)bidx * p.gz + zraw) * nyrep + yrep) * WPIXN + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
-    const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
-    const float* aux = p.bn_aux + (long long)grp * 4 * p.cstat;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int ch = ch0 + wch * FM * 16 + i * 16 + (lane >> 4) * 4;
       const bool chok = ch < p.NchStore;
       const int cc = ch & (p.cstat - 1);
       float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (BNB) {
-        // backward statistics: s = sum g_z, q = sum g_z * xhat
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, is = sc;
-        if (chok) {
-          sc = *reinterpret_cast<const f32x4*>(aux + cc); sh = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc);
-          mu = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc); is = *reinterpret_cast<const f32x4*>(aux + 3 * p.cstat + cc);
-        }
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          float yv[4];
-          bn_unpack(ypre[i][j], yv);
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = acc[i][j][r];
-            const float zz = yv[r] * sc[r] + sh[r];
-            const float gz = zz > 0.f ? v : p.bn_slope * v;
-            s[r] += gz;
-            q[r] += x2 ? gz * (yv[r] - mu[r]) : gz * ((yv[r] - mu[r]) * is[r]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
-      }
+        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; s[r] += v; q[r] += v * v; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); q[r] = row16_sum(q[r]); }
       if ((lane & 15) == 0 && chok) {
-        if (!x2) {
-          *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
-          *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
-        }
-      }
-      if (x2 && (lane & 15) == 0) {     // this wave's partial of its FM * 16 channels -> LDS (igemm_stats_tail adds the waves' rows)
-        float* sr = x2scr + ((wch * WPIXN + wpix) * 2) * (FM * 16) + i * 16 + (lane >> 4) * 4;
-        *reinterpret_cast<f32x4*>(sr) = chok ? f32x4{s[0], s[1], s[2], s[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(sr + FM * 16) = chok ? f32x4{q[0], q[1], q[2], q[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sp + cc) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
       }
     }
   }
@@ -233,19 +149,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
   }
 }
 
-// exact-sum statistics of a one-tile workgroup (bnstat.hpp): the waves' partial rows (written to LDS by igemm_epilogue) are added
-// per channel and go out as one atomic add per (channel, statistic); the consumer kernel finalises.  Called by every
-// thread that ran the epilogue (nthr of them: the whole workgroup, or the consumer waves once the loader waves have returned).
-template <int BCH, int CHW, int WPIXN>
-__device__ __forceinline__ void igemm_stats_tail(const IgemmParams& p, const float* scr, unsigned* flag, int tid, int nthr, int m0, int ch0) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  const int grp = p.bn_group_rows > 0 ? m0 / p.bn_group_rows : 0;
-  bn_wg_partials_add<BCH, CHW, WPIXN>(p.bnj, scr, tid, nthr, (int)(blockIdx.x % (unsigned)p.bnj.reps), grp, ch0, p.NchStore, p.cstat);
-  (void)flag;
-}
-
-template <class P, int BCH, int BPIX, int NSUB, int NST = 2, bool BNB = false>
+template <class P, int BCH, int BPIX, int NSUB, int NST = 2>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   typedef typename P::T T;        // activation storage type
   typedef typename P::W W;        // LDS / packed-weight element type (bf16_t or float)
@@ -404,8 +308,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
-  if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
   // software pipeline: LDS double buffer + NST register stages; k-step k lives in stage k % NST
   load_tiles(0, st[0]);
   store_tiles(0, st[0]);
@@ -426,10 +328,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  // the k-loop ended on a barrier: the LDS tiles are free for the statistics' partial rows (behind the dead tap tables)
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre, reinterpret_cast<float*>(lds));
-  if (p.bnj.xs)
-    igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds), reinterpret_cast<unsigned*>(smem_raw), tid, 256, m0, ch0);
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -446,7 +345,7 @@ static __device__ __attribute__((aligned(16))) unsigned int g_jck_zero_page[64];
 // about one workgroup per CU, where a 4-wave workgroup would serialise DMA issue and MFMA in every wave.
 // NCW = 8 (768 threads) with a 128 x 256 tile: the weight tile is filled once for twice the pixels - 85 instead of 64 FLOP
 // per filled byte (the kernels are bound by the LDS fill rate).
-template <int BCH, int BPIX, int NSTG, bool BNB = false, bool WS = false, int NCW = 4>
+template <int BCH, int BPIX, int NSTG, bool WS = false, int NCW = 4>
 __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(const IgemmParams p) {
   static_assert(!WS || NSTG == 3, "wave specialisation uses 3 LDS stages");
   static_assert(NCW == 4 || (WS && NCW == 8), "8 consumer waves exist in the wave-specialised form only");
@@ -551,7 +450,6 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
     }
   };
 
-  typename BnRaw<P>::R ypre[BNB ? FM : 1][BNB ? FN : 1];
   if constexpr (WS) {
     if (loader) {
       issue(0, 0); issue(1, 1);                                       // stages 0, 1 in flight
@@ -568,21 +466,15 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
-    if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);
     int slot = 0;
     for (int k = 0; k < nk; ++k) {
       __builtin_amdgcn_s_barrier();
       compute(slot);
       slot = slot == 2 ? 0 : slot + 1;
     }
-    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre,
-                                                       reinterpret_cast<float*>(lds + NSTG * STG_BYTES + 64));
-    if (p.bnj.xs)
-      igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds + NSTG * STG_BYTES + 64),
-                                              reinterpret_cast<unsigned*>(lds + NSTG * STG_BYTES), tid, NCW * 64, m0, ch0);
+    igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
     return;
   }
-  if constexpr (BNB) igemm_bn_prefetch<P, FM, FN>(p, lane, wch, wpix, z, m0, ch0, ypre);   // older than every DMA: done by the first wait
   // prologue: NSTG-1 stages in flight
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s) issue(s, s);
@@ -603,11 +495,7 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
     st_i = (st_i + 1 == NSTG) ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain the dead tail loads before the epilogue reuses nothing of LDS
-  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX, BNB>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0, ypre,
-                                                     reinterpret_cast<float*>(lds + NSTG * STG_BYTES + 64));
-  if (p.bnj.xs)
-    igemm_stats_tail<BCH, FM * 16, C::WPIX>(p, reinterpret_cast<const float*>(lds + NSTG * STG_BYTES + 64),
-                                            reinterpret_cast<unsigned*>(lds + NSTG * STG_BYTES), tid, 256, m0, ch0);
+  igemm_epilogue<P, BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, zraw, bidx, bidy, m0, ch0);
 }
 
 // Epilogue of the persistent kernel: 16-byte stores.  The loader fills LDS weight row r of every 32-row block with output
@@ -669,10 +557,10 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
 // workgroup's next tile are already in flight, and no workgroup launch / LDS allocation sits between two tiles of a CU.
 // Same tiles and k order as igemm_dma_kernel<.., WS = true>, the output channels of a 32-row block permuted between LDS row and
 // MFMA row so that the epilogue stores 16 bytes per lane (igemm_epilogue_perm) - the same products in the same order: bitwise
-// the same results.  Statistics (forward: p.stat_accum; BatchNorm backward: BNB) are accumulated per workgroup and group.
+// the same results.  Forward statistics (p.stat_accum) are accumulated per workgroup and BatchNorm group.
 // Both roles execute exactly (tiles of this workgroup) x (K / 64) barriers.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BCH, int BPIX, bool BNB, int NCW>
+template <int BCH, int BPIX, int NCW>
 __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const IgemmParams p) {
   typedef PrecBf16 P;
   typedef IgemmCfg<P, BCH, BPIX, NCW> C;
@@ -714,15 +602,12 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     const unsigned src_chunk = (unsigned)(unit ^ ((lrow >> 1) & 7)) * 16u;
     unsigned rowoff[C::APASS], wrowoff[C::WPASS];
     int riy[C::APASS], rix[C::APASS];
-    const bool bnf = !BNB && p.in_aux != nullptr;     // (dgrad launches with backward statistics never carry it)
-    unsigned tgbits = 0u;                             // bnf: the BatchNorm group (< 4) of this lane's row in pass ps, 2 bits each
     auto setup = [&](int L) {
       locate(L);
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const int m = m0 + ps * 32 + lrow;
         const int n = m >> p.logOHW;
-        if (bnf && p.in_group_images > 0) tgbits = (tgbits & ~(3u << (2 * ps))) | (((unsigned)(n / p.in_group_images) & 3u) << (2 * ps));
         const int rem = m & ((1 << p.logOHW) - 1);
         const int iy0 = (rem >> p.logOW) * p.sy, ix0 = (rem & ((1 << p.logOW) - 1)) * p.sx;
         rowoff[ps] = ((unsigned)(((n * p.H + iy0) * p.W + ix0) << p.logC)) * 2u;
@@ -739,11 +624,6 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     // returns zeros, which replaces the zero page for out-of-image taps and rows past M.
     const auto rs_a = make_rsrc(p.act, p.act_bytes);
     const auto rs_wt = make_rsrc(p.w, p.w_bytes);
-    // bnf: what the transform of a stage needs once its pieces have landed - which of this lane's pieces are inside the image
-    // (bit ps), the first channel of the k-step, the rows' tables, the stage; hist0 = the older of the two k-steps in flight
-    unsigned ok_new = 0u, ok0 = 0u, ok1 = 0u;
-    int cb_new = 0, cb0 = 0, cb1 = 0, st_new = 0, st0 = 0, st1 = 0;
-    unsigned tg_new = 0u, tg0 = 0u, tg1 = 0u;
     auto issue = [&](int kc, int stage) {
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
@@ -755,13 +635,11 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       const int tp = p.tap[z][t];
       const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
       const unsigned toffb = (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
-      ok_new = 0u; cb_new = kbase & (Cc - 1); st_new = stage; tg_new = tgbits;
 #pragma unroll
       for (int ps = 0; ps < C::APASS; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
                                                  (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
-        ok_new |= (ok ? 1u : 0u) << ps;
       }
     };
     // (Lq, kq): the next k-step to issue; past the last tile the last k-step is issued again into a stage nobody reads
@@ -769,9 +647,6 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     if (my_tiles > 0) setup(Lq);
     auto next = [&]() {
       issue(kq, slot);
-      if (bnf) {
-        ok0 = ok1; cb0 = cb1; st0 = st1; tg0 = tg1; ok1 = ok_new; cb1 = cb_new; st1 = st_new; tg1 = tg_new;
-      }
       slot = slot == 2 ? 0 : slot + 1;
       if (kq + 1 < nk) { ++kq; return; }
       if (Lq + (int)gridDim.x < ntiles) { Lq += gridDim.x; kq = 0; setup(Lq); }   // else: stay on the last k-step (dead re-loads)
@@ -784,114 +659,29 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       else if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else static_assert(NLD == 8 || NLD == 6 || NLD == 12, "add the vmcnt literal");
     };
-    if (!bnf) {
-      for (int s = 0; s < steps; ++s) {
-        wait_older();
-        __builtin_amdgcn_s_barrier();                                 // consumers may read this step's stage; the one before is free
-        next();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      return;
-    }
-    // ---- fused BatchNorm + activation on the gathered operand ----
-    // tables [in_groups][scale | shift][C] into LDS (in the scratch of the exact-sum statistics when those are not in use, else
-    // behind it: the usual launch keeps its LDS footprint and with it its workgroups per CU and its statistic rows), visible to
-    // the four loader waves after the one extra barrier both roles execute
-    float* const tab = reinterpret_cast<float*>(lds + 3 * STG_BYTES + 64 + (p.bnj.xs ? 8 * NCW * BCH : 0));
-    for (int i = tid; i < p.in_groups * 2 * Cc; i += 256) {
-      const int g = i / (2 * Cc);
-      tab[i] = p.in_aux[(long long)g * 4 * Cc + (i - g * 2 * Cc)];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int chunk8 = (unit ^ ((lrow >> 1) & 7)) * 8;                // the channels (within the k-step's 64) this lane's LDS slot holds
-    const float slope = p.in_slope;
-    // every lane transforms the pieces IT brought in (its own vmcnt covers them), in place: the stage is not visible to the
-    // consumer waves before the barrier that follows
-    auto xform = [&]() {
-      unsigned char* sa = lds + st0 * STG_BYTES + (wave & 3) * (8 * LD * 2) + BCH * (LD * 2) + lane * 16;
-      // all reads first, then the arithmetic, then all writes: the pieces alias as far as the compiler can tell, and a
-      // read -> compute -> write chain per piece (the first form) cost one LDS round trip per piece on the barrier's critical path
-      const int t0 = (int)(tg0 & 3u);
-      float sc[8], sh[8];
-      auto table = [&](int tg, float (&a)[8], float (&b)[8]) {
-        const float* tb = tab + tg * 2 * Cc + cb0 + chunk8;
-        const f32x4 sA = *reinterpret_cast<const f32x4*>(tb), sB = *reinterpret_cast<const f32x4*>(tb + 4);
-        const f32x4 hA = *reinterpret_cast<const f32x4*>(tb + Cc), hB = *reinterpret_cast<const f32x4*>(tb + Cc + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = sA[i]; a[4 + i] = sB[i]; b[i] = hA[i]; b[4 + i] = hB[i]; }
-      };
-      table(t0, sc, sh);
-      auto apply = [&](const u32x4 v, const float (&a)[8], const float (&b)[8]) {
-        u32x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float y0 = __uint_as_float(v[i] << 16), y1 = __uint_as_float(v[i] & 0xffff0000u);
-          const float z0 = y0 * a[2 * i] + b[2 * i], z1 = y1 * a[2 * i + 1] + b[2 * i + 1];
-          // act(z) = z > 0 ? z : slope * z (bn_act_fwd_kernel) as max(z, slope * z): the same bits for 0 <= slope < 1 (zeros
-          // keep their sign either way), one VALU operation instead of a compare and a select
-          o[i] = pack2bf_pk(fmaxf(z0, slope * z0), fmaxf(z1, slope * z1));
-        }
-        return o;
-      };
-      constexpr int XB = C::APASS < 4 ? C::APASS : 4;        // pieces in flight (registers: the 256-pixel tile has 8 per lane)
-#pragma unroll
-      for (int p0 = 0; p0 < C::APASS; p0 += XB) {
-        u32x4 r[XB];
-#pragma unroll
-        for (int q = 0; q < XB; ++q) r[q] = *reinterpret_cast<const u32x4*>(sa + (p0 + q) * (32 * LD * 2));
-#pragma unroll
-        for (int q = 0; q < XB; ++q) {
-          const int tgp = (int)((tg0 >> (2 * (p0 + q))) & 3u);
-          if (tgp == t0) r[q] = apply(r[q], sc, sh);
-          else {                                        // a row of another BatchNorm group (tiles at a group border only)
-            float s2[8], h2[8];
-            table(tgp, s2, h2);
-            r[q] = apply(r[q], s2, h2);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < XB; ++q)
-          if ((ok0 >> (p0 + q)) & 1u) *reinterpret_cast<u32x4*>(sa + (p0 + q) * (32 * LD * 2)) = r[q];
-        if (p0 + XB < C::APASS) __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    wait_older();
-    xform();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int s = 0; s < steps; ++s) {
-      __builtin_amdgcn_s_barrier();                                   // consumers may read this step's (transformed) stage
-      next();                                                         // k-step s + 2 into the stage that became free
-      wait_older();                                                   // k-step s + 1 has landed:
-      xform();                                                        // ... transform it under the consumers' k-step s
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_older();
+      __builtin_amdgcn_s_barrier();                                   // consumers may read this step's stage; the one before is free
+      next();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-  if (!BNB && p.in_aux) __builtin_amdgcn_s_barrier();                 // (consumer side of the loaders' table barrier)
 
   const int wch = (C::WCH == 2) ? (wave / C::WPIX) : 0;
   const int wpix = (C::WCH == 2) ? (wave % C::WPIX) : wave;
   const int sw = ((lane & 15) >> 1) & 7;
   int slot = 0;
-  // Statistics are accumulated per LANE over the tiles of the workgroup that share a (BatchNorm group, channel tile) and leave
-  // the lanes only when that pair changes and at the end (a workgroup's tiles come in increasing pixel order):
-  //   x2 (p.bnj.xs, bnstat.hpp): reduced over the 16 pixel lanes and added to the exact per-channel sums by integer atomics;
-  //      the launch's last workgroup finalises.  Forward (sum y, sum y^2) or - BNB - the BatchNorm-backward sums of the tensor
-  //      this launch's output is the gradient of (sum g_z, sum g_z (y - mean)): no separate pass over g and y afterwards.
-  //   legacy forward rows (p.stats && p.stat_accum, round 2): rows [group][rank * WPIX + wpix][2][cstat], rank = position of
-  //      this workgroup among those with its channel tile; needs the launcher's divisibility conditions.
+  // Forward statistics (p.stats && p.stat_accum) are accumulated per LANE over the tiles of the workgroup that share a BatchNorm
+  // group and leave the lanes only when the group changes and at the end (a workgroup keeps its channel tile and meets its tiles
+  // in increasing pixel order): rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with
+  // its channel tile; needs the launcher's divisibility conditions.  Rows of groups a workgroup has no tile in are zeros.
   constexpr int NPAIR = FM / 2;
   float S1[NPAIR][8], S2[NPAIR][8];
-  int cur_group = -1, cur_ch0 = -1, next_row_group = 0;
-  const bool x2 = p.bnj.xs != nullptr;
-  const bool rows_stats = !x2 && !BNB && p.stats && p.stat_accum;
-  const bool acc_stats = x2 || rows_stats;
+  int cur_group = -1, next_row_group = 0;
+  const bool acc_stats = p.stats && p.stat_accum;
   const int ngroups = acc_stats ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
-  const int rep = x2 ? (int)(blockIdx.x % (unsigned)p.bnj.reps) : 0;
   int rank = 0, rows_per_group = 0;
-  if (x2 && tid == 0) *reinterpret_cast<unsigned*>(lds + 3 * STG_BYTES + 16) = 0u;      // flush counter (first used behind >= K/64 barriers)
   if (acc_stats) {
     locate(blockIdx.x);
     // first-tile wgid = base(xcd) + idx with base % gy == 0 (launcher): channel tile = idx % gy, rank = xcd * (G/8/gy) + idx / gy
@@ -920,47 +710,11 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
     }
   };
-  // x2: the sums of (group grp, channel tile chb) leave the lanes.  Every consumer wave puts its row into LDS and counts itself
-  // in; the wave that arrives last adds the WPIX rows of each channel in wave order and issues the atomics - one partial per
-  // (workgroup, channel, statistic), 64 consecutive channels per instruction.  No barrier (the loader waves are mid-pipeline): the
-  // next flush of any wave lies behind at least one k-loop, whose barriers the last arriver only reaches after it has read the rows.
-  // Two row buffers, alternated per flush: a workgroup's LAST flush may follow the one before it with no k-loop in between (its
-  // last tile opened a new group), but flush n + 2 is always a whole k-loop behind flush n.
-  constexpr int CHW = FM * 16;
-  unsigned* const xcnt = reinterpret_cast<unsigned*>(lds + 3 * STG_BYTES + 16);
-  int nflush = 0;
-  auto x2_flush = [&](int grp, int chb) __attribute__((always_inline)) {
-    float* const xscr = reinterpret_cast<float*>(lds + 3 * STG_BYTES + 64) + (nflush & 1) * (NCW * 2 * CHW);     // [NCW][2][CHW]
-    ++nflush;
-#pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-      float a[8], b[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { a[c] = row16_sum(S1[k][c]); b[c] = row16_sum(S2[k][c]); }
-      if ((lane & 15) == 0) {
-        float* sr = xscr + (wave * 2) * CHW + k * 32 + 8 * (lane >> 4);
-        *reinterpret_cast<f32x4*>(sr) = f32x4{a[0], a[1], a[2], a[3]};
-        *reinterpret_cast<f32x4*>(sr + 4) = f32x4{a[4], a[5], a[6], a[7]};
-        *reinterpret_cast<f32x4*>(sr + CHW) = f32x4{b[0], b[1], b[2], b[3]};
-        *reinterpret_cast<f32x4*>(sr + CHW + 4) = f32x4{b[4], b[5], b[6], b[7]};
-      }
-    }
-    unsigned old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(xcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // behind this wave's LDS stores (in order)
-    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-    if ((old + 1u) % (unsigned)NCW == 0u)
-      bn_wg_partials_add<BCH, CHW, C::WPIX>(p.bnj, xscr, lane, 64, rep, grp, chb, p.NchStore, p.cstat);
-  };
   auto stat_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
-    if (x2) {
-      if (cur_group >= 0) x2_flush(cur_group, cur_ch0);
-    } else {
-      if (cur_group >= 0) { rows_write(cur_group, false); next_row_group = cur_group + 1; }
-      for (int gq = next_row_group; gq < grp; ++gq) rows_write(gq, true);       // groups this workgroup has no tile in
-      if (grp > next_row_group) next_row_group = grp;
-    }
+    if (cur_group >= 0) { rows_write(cur_group, false); next_row_group = cur_group + 1; }
+    for (int gq = next_row_group; gq < grp; ++gq) rows_write(gq, true);       // groups this workgroup has no tile in
+    if (grp > next_row_group) next_row_group = grp;
     cur_group = grp;
-    cur_ch0 = ch0;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k)
 #pragma unroll
@@ -994,77 +748,19 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       slot = slot == 2 ? 0 : slot + 1;
     }
     const int grp = (acc_stats && p.bn_group_rows > 0) ? m0 / p.bn_group_rows : 0;
-    if (acc_stats && (grp != cur_group || (x2 && ch0 != cur_ch0))) stat_switch(grp);
-    if constexpr (!BNB) {
-      igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats);
-      if (acc_stats) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
+    if (acc_stats && grp != cur_group) stat_switch(grp);
+    igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats);
+    if (acc_stats) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
 #pragma unroll
-        for (int k = 0; k < NPAIR; ++k)
+      for (int k = 0; k < NPAIR; ++k)
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const float v = acc[2 * k + (c >> 2)][j][c & 3];
-              S1[k][c] += v;
-              S2[k][c] += v * v;
-            }
-      }
-    } else {
-      // BatchNorm-backward statistics (x2 only): one fragment pair at a time - its saved conv outputs y (16 bytes per pixel
-      // column) first, the gradient stores next, then the arithmetic with the pair's 24 table values; nothing of a pair
-      // outlives its iteration (the round-2 form kept four column chunks and four tables alive and went to scratch)
-      int poff[FN];                      // element offsets fit 31 bits (launcher), -1: row past M
-      {
-        long long po64[FN];
-        igemm_pixel_offsets<FN>(p, lane, wpix, m0, po64);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) poff[j] = po64[j] < 0 ? -1 : (int)(po64[j] + p.obase[z]);
-      }
-      const int g = lane >> 4;
-      const bf16_t* by = reinterpret_cast<const bf16_t*>(p.bn_y);
-      bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-      const float* aux = p.bn_aux + (long long)grp * 4 * p.cstat;
-#pragma unroll
-      for (int k = 0; k < NPAIR; ++k) {
-        const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-        const bool chok = ch < p.NchStore;
-        const int cc = ch & (p.cstat - 1);
-        u32x4 yr[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          yr[j] = u32x4{0u, 0u, 0u, 0u};
-          if (poff[j] >= 0 && chok) yr[j] = *reinterpret_cast<const u32x4*>(by + poff[j] + ch);
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          if (poff[j] < 0 || !chok) continue;
-          const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
-                              acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
-          st8(outp + poff[j] + ch, v);
-        }
-        if (chok) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {        // the pair's two fragments one after the other: 12 table values alive, not 24
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(aux + cc + 4 * h), sh = *reinterpret_cast<const f32x4*>(aux + p.cstat + cc + 4 * h);
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(aux + 2 * p.cstat + cc + 4 * h);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-              if (poff[j] < 0) continue;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int c = 4 * h + r;
-                const float yv = (c & 1) ? __uint_as_float(yr[j][c >> 1] & 0xffff0000u) : __uint_as_float(yr[j][c >> 1] << 16);
-                const float v = acc[2 * k + h][j][r];
-                const float zz = yv * sc[r] + sh[r];
-                const float gz = zz > 0.f ? v : p.bn_slope * v;
-                S1[k][c] += gz;
-                S2[k][c] += gz * (yv - mu[r]);
-              }
-            }
+          for (int c = 0; c < 8; ++c) {
+            const float v = acc[2 * k + (c >> 2)][j][c & 3];
+            S1[k][c] += v;
+            S2[k][c] += v * v;
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);       // keep the pairs apart: the next pair's loads must not be hoisted over this one
-      }
     }
   }
   if (acc_stats) stat_switch(ngroups);

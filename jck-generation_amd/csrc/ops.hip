@@ -1,7 +1,6 @@
 // C-ABI launchers for the per-op entry points of include/jckgan.h (host side; kernels in *.hpp).
 #include "ops_internal.hpp"
 #include "thin.hpp"
-#include "wgrad_halo.hpp"
 #include "bnres.hpp"
 
 #include <cstdlib>
@@ -32,7 +31,6 @@ static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wa
 // +0.3..3 % per gather-GEMM (tests/_mb2.py igemm_prio 0 1 ...)
 static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neutral (1.905 vs 1.907 ms)
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
-static int g_conv_in = env_int("JCK_CONV_IN", 1);                // 0: the jck_conv_*_in entry points always take the unfused route
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);
 static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
@@ -43,35 +41,25 @@ static int g_wgrad_small_wgs = env_int("JCK_WGRAD_SMALL_WGS", 512);
 static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
 static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
-// tap-reuse kernel (wgrad_halo.hpp) for the 16-tap stride-2 layers: 0 never, 1 where it measured faster ALONE (the 2B-image
-// products), 2 always.  Default 0 since round 3: with the LDS-DMA pieces issued as buffer loads the per-tap kernel caught up, and
-// in the step - where the weight gradients share the chip with the dgrad chain and the tap-reuse kernel writes twice the split-K
-// slabs - it is the faster one (1.82-1.83 vs 1.86 ms, tests/_ab.sh JCK_WGRAD_HALO=0 / 1, two rounds)
-static int g_wgrad_halo = env_int("JCK_WGRAD_HALO", 0);
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"conv_in", &g_conv_in}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
-                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_halo", &g_wgrad_halo}};
+                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}};
   for (auto& t : tab)
     if (key && !strcmp(t.k, key)) { *t.p = value; return JCK_OK; }
   JCK_FAIL(JCK_E_ARG, std::string("jck_tune: unknown key ") + (key ? key : "(null)"));
 }
 
 #include <hip/hip_ext.h>
-static thread_local hipEvent_t t_stop_event = nullptr;
-void jck_arm_stop_event(hipEvent_t ev) { t_stop_event = ev; }
-hipEvent_t jck_take_stop_event() { hipEvent_t ev = t_stop_event; t_stop_event = nullptr; return ev; }
-// launch that honours jck_arm_stop_event (every kernel argument must be passed explicitly: the extended launch checks the count)
-#define LAUNCH_ARMABLE(kernel, grid, block, shmem, stream, ...)                                              \
-  do {                                                                                                       \
-    if (t_stop_event) {                                                                                      \
-      hipEvent_t ev_ = t_stop_event;                                                                         \
-      t_stop_event = nullptr;                                                                                \
-      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (hipEvent_t) nullptr, ev_, 0u, __VA_ARGS__); \
-    } else {                                                                                                 \
-      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                   \
-    }                                                                                                        \
+// launch whose completion hands a tensor to another stream: `ev` (may be null) is completed by the dispatch packet itself
+// (hipExtLaunchKernel's stop event) - what a hipEventRecord behind the launch would do with a marker packet of its own, which
+// costs the launch stream ~6-7 us of idle time per record on this runtime.  Every kernel argument must be passed explicitly
+// (the extended launch checks the count).
+#define LAUNCH_EV(kernel, grid, block, shmem, stream, ev, ...)                                                      \
+  do {                                                                                                              \
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (hipEvent_t) nullptr, (hipEvent_t)(ev), 0u, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                       \
   } while (0)
 #define DISPATCH_T(prec, CALL)                                  \
   do {                                                          \
@@ -94,7 +82,7 @@ const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "
                                   "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
                                   "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
                                   "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>",
-                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>",    "wgrad_halo<bf16,64,512>"};
+                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>"};
 struct ProfScope {
   ProfRec r; bool on; hipStream_t st;
   ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
@@ -137,22 +125,15 @@ extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, 
 // ---------------------------------------------------------------------------------------------------------
 // gather-GEMM dispatch
 // ---------------------------------------------------------------------------------------------------------
-// internal: the launch asked for the fused input transform (IgemmParams::in_aux) and the kernel the dispatch picked has none -
-// nothing was launched; the *_in entry points then materialise the activation and launch again without it
-#define JCK_UNFUSED 1000
 template <class P, int BCH, int BPIX, int NSUB>
 static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
   typedef IgemmCfg<P, BCH, BPIX> C;
-  if (p.in_aux) return JCK_UNFUSED;
   constexpr int variant = (P::IS_F32 ? 5 : 0) + (BCH == 128 ? (BPIX == 128 ? 0 : 1) : (BCH == 64 ? (NSUB == 2 ? 2 : 3) : 4));
   ProfScope prof(variant, p.flops, st);
-  auto kern = p.bn_y ? igemm_kernel<P, BCH, BPIX, NSUB, 2, true> : igemm_kernel<P, BCH, BPIX, NSUB, 2, false>;
+  auto kern = igemm_kernel<P, BCH, BPIX, NSUB, 2>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<P, BCH, BPIX, NSUB, 2, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<P, BCH, BPIX, NSUB, 2, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -170,21 +151,13 @@ static int launch_igemm_t(const IgemmParams& p, int nch_pad, int phases, hipStre
 
 template <int BCH, int BPIX, int NSTG, bool WS = false, int NCW = 4>
 static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2 + 64 + 4096;     // + arrival flag and partial rows of bnstat.hpp
+  constexpr int LDSB = NSTG * (BCH + BPIX) * IG_BK * 2;
   constexpr int variant = BPIX == 256 ? 20 : BCH == 64 ? 3 : (BPIX == 128 ? 0 : 1);
-  if (p.in_aux) return JCK_UNFUSED;
   ProfScope prof(variant, p.flops, st);
-  // the 256-pixel tile has no slot-row BatchNorm-backward form (its shared epilogue went to scratch, 5 VGPRs): the dispatch sends
-  // those launches to the 128-pixel tiles
-  constexpr bool HAS_BNB = BPIX != 256;
-  if (!HAS_BNB && p.bn_y) JCK_FAIL(JCK_E_ARG, "igemm: internal - BatchNorm-backward rows on the 256-pixel tile");
-  auto kern = (HAS_BNB && p.bn_y) ? igemm_dma_kernel<BCH, BPIX, NSTG, HAS_BNB, WS, NCW> : igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>;
+  auto kern = igemm_dma_kernel<BCH, BPIX, NSTG, WS, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, HAS_BNB, WS, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_kernel<BCH, BPIX, NSTG, false, WS, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -202,21 +175,13 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
 // persistent wave-specialised form: at most `cap` workgroups (what the chip holds at this tile's LDS footprint) walk the tiles
 template <int BCH, int BPIX, int NCW>
 static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB0 = 3 * (BCH + BPIX) * IG_BK * 2 + 64 + 8 * NCW * BCH;   // + arrival flag, flush counter and 2 x [NCW][2][BCH / 2] partial rows of bnstat.hpp
+  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2;
   constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
-  // fused input transform: + the [groups][scale | shift][C] tables
-  // (they take the place of the exact-sum scratch when that is not in use: same footprint, same workgroups per CU, same rows)
-  const int tab_bytes = p.in_aux ? p.in_groups * 2 * (1 << p.logC) * 4 : 0;
-  const int LDSB = LDSB0 + std::max(0, tab_bytes - (p.bnj.xs ? 0 : 8 * NCW * BCH));
-  if (p.in_aux && (p.bn_y || p.act_row_elems || LDSB > 160 * 1024 || p.in_groups > 4)) return JCK_UNFUSED;   // (2 bits of group per row)
   ProfScope prof(variant, p.flops, st);
-  auto kern = p.bn_y ? igemm_dma_persist_kernel<BCH, BPIX, true, NCW> : igemm_dma_persist_kernel<BCH, BPIX, false, NCW>;
+  auto kern = igemm_dma_persist_kernel<BCH, BPIX, NCW>;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, true, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_dma_persist_kernel<BCH, BPIX, false, NCW>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
@@ -226,19 +191,18 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   const int ntiles = (int)(grid.x * grid.y * grid.z);
   const int cap = 256 * (160 * 1024 / LDSB);                         // 256 CUs x workgroups that fit their LDS
   const int nwg = std::min(ntiles, cap);
-  if (q.bnj.xs) q.stat_accum = 0;                                    // exact sums by atomics: no row bookkeeping at all
-  if (q.stats && !q.bn_y && q.stat_accum) {
+  if (q.stats && q.stat_accum) {
     // accumulated rows need several tiles of ONE channel tile per workgroup and tiles inside one group (igemm.hpp)
     const int gyy = (int)grid.y;
     if (!(g_stat_accum && ntiles >= cap && ntiles % 8 == 0 && (ntiles / 8) % gyy == 0 && (cap / 8) % gyy == 0 && q.cstat == nch_pad &&
           (q.bn_group_rows == 0 || q.bn_group_rows % BPIX == 0)))
       q.stat_accum = 0;
   }
-  if (q.stats && !q.bn_y && !q.stat_accum && !q.bnj.xs) {
+  if (q.stats && !q.stat_accum) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
     if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
   }
-  if (!q.bnj.xs && q.stats && q.stat_accum) {    // accumulated forward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
+  if (q.stats && q.stat_accum) {    // accumulated forward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
     const int groups = q.bn_group_rows > 0 ? (q.M + q.bn_group_rows - 1) / q.bn_group_rows : 1;
     if (slots) *slots = groups * (nwg / (int)grid.y) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX;
   }
@@ -266,16 +230,9 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
     const long long wgs256 = (long long)cdiv(p.M, 256) * (nch_pad / 128) * phases;
     // persistent kernels: plain bf16 conv / dgrad launches only (their epilogue has no bias, tanh, fp32 or split-K output)
     int persist = (p.bias || p.epi || p.out_f32 || p.rows_are_phases || p.out_split_stride) ? 0 : g_igemm_persist;
-    const bool x2 = p.bnj.xs != nullptr;
-    // BatchNorm-backward statistics on the persistent kernels: the exact-sum form only (bnstat.hpp); the slot-row form of the
-    // per-op entry points (jck_conv_*_bnbwd) runs on the one-tile-per-workgroup kernels
-    if (p.bn_y && !x2) persist = 0;
-    // a tile must not straddle two BatchNorm groups: slot rows - groups are multiples of 8 images (8 * OH*OW % 256 == 0), backward
-    // statistics carry their group size; exact sums - the group size in pixel rows is given either way
-    auto grp_ok = [&](int bpix) { return p.bn_group_rows == 0 || p.bn_group_rows % bpix == 0; };
-    if (x2 && !grp_ok(64)) persist &= ~2;
-    const bool groups_ok = x2 ? grp_ok(256) : (!p.stats || (p.bn_y ? (p.bn_group_rows == 0 || p.bn_group_rows % 256 == 0) : p.logOHW >= 5));
-    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0 && (!p.bn_y || (persist & 1)))
+    // a tile must not straddle two BatchNorm groups: groups are multiples of 8 images (8 * OH*OW % 256 == 0)
+    const bool groups_ok = !p.stats || p.logOHW >= 5;
+    if (min256 > 0 && wgs256 >= min256 && !p.act_row_elems && groups_ok && p.M % 256 == 0)
       return (persist & 1) ? launch_igemm_dma_persist<128, 256, 8>(p, nch_pad, phases, st, slots)
                            : launch_igemm_dma<128, 256, 3, true, 8>(p, nch_pad, phases, st, slots);
     if (wgs >= 512) return launch_igemm_dma<128, 128, 2>(p, nch_pad, phases, st, slots);
@@ -293,8 +250,7 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   if (nch_pad == 64) {
     if (use_dma && !P::IS_F32 && nsub == 1 && p.ksplit <= 1 && !p.rows_are_phases) {
       const long long t128 = (long long)cdiv(p.M, 128) * phases;
-      const bool bnb_ok = p.bnj.xs ? (p.bn_group_rows == 0 || p.bn_group_rows % 128 == 0) : !p.bn_y;
-      if ((g_igemm_persist & 4) && !p.act_row_elems && !p.bias && !p.epi && !p.out_f32 && !p.rows_are_phases && !p.out_split_stride && bnb_ok)
+      if ((g_igemm_persist & 4) && !p.act_row_elems && !p.bias && !p.epi && !p.out_f32 && !p.rows_are_phases && !p.out_split_stride)
         return launch_igemm_dma_persist<64, 128, 4>(p, nch_pad, phases, st, slots);
       return launch_igemm_dma<64, 128, 2>(p, nch_pad, phases, st, slots);
     }
@@ -343,12 +299,8 @@ extern "C" size_t jck_packed_bytes(int prec, long long elems) { return (size_t)e
 #define g_use_thin g_thin
 #define IMG_GPW 8
 static int launch_img_down(const void* x, const void* w, void* out, float* stats, int* slots, int N, int Hb, int Wb, double flops,
-                           hipStream_t st, const void* bn_y = nullptr, const float* bn_aux = nullptr, float bn_slope = 0.f,
-                           int bn_group_images = 0, const BnStatJob* bnj = nullptr) {
+                           hipStream_t st) {
   ImgDownParams q = {};
-  if (bnj) q.bnj = *bnj;
-  q.bn_y = bn_y; q.bn_aux = bn_aux; q.bn_slope = bn_slope;
-  q.bn_group_groups = bn_group_images > 0 ? bn_group_images * (Hb / 2) * (Wb / 2) / 16 : 0;
   const int OH = Hb / 2, OW = Wb / 2;
   q.x = x; q.w = w; q.out = out; q.stats = stats;
   q.ngroups = N * OH * (OW / 16); q.H = Hb; q.W = Wb; q.logOH = ilog2(OH); q.logG = ilog2(OW / 16);
@@ -376,11 +328,8 @@ static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, 
 }
 
 static int conv_down_impl(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
-                          int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float bn_slope,
-                          int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr,
-                          const float* in_aux = nullptr, int in_group_images = 0, float in_slope = 0.f) {
+                          int N, int Hb, int Wb, int Cb, int Cs, void* stream, int fwd_group_images = 0) {
   const int cbp = jck_pad_chan(Cb);
-  if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_down: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(cbp) || !is_pow2(Hb) || !is_pow2(Wb) || Hb < 2 || Wb < 2 || Cs % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_down: shapes must be powers of two (Hb,Wb,Cb) and Cs % 4 == 0");
   if ((long long)N * Hb * Wb * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_down: tensor exceeds 2^31 elements");
@@ -394,29 +343,14 @@ static int conv_down_impl(int prec, const void* big, const void* w, void* small_
   p.cstat = Cs; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
   if (stats && !is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
   p.flops = 2.0 * p.M * Cs * 16.0 * Cb;
-  p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * OH * OW : 0;
-  if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * OH * OW; p.stat_accum = 1; }
-  if (bnj) {                                              // exact-sum statistics (bnstat.hpp): group size for either direction
-    p.bnj = *bnj;
-    const int gi = bn_y ? bn_group_images : fwd_group_images;
-    p.bn_group_rows = gi > 0 ? gi * OH * OW : 0;
-    if (!is_pow2(Cs)) JCK_FAIL(JCK_E_ARG, "conv_down: BN statistics need a power-of-two channel count");
-    bn_group_images = gi;
-  }
-  if (in_aux) {
-    if (cbp != Cb || Cb < 64) return JCK_UNFUSED;
-    p.in_aux = in_aux; p.in_slope = in_slope; p.in_group_images = in_group_images;
-    p.in_groups = in_group_images > 0 ? N / in_group_images : 1;
-  }
-  if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH) &&
-      (bn_group_images == 0 || (bn_group_images * OH * OW) % (16 * 4 * IMG_GPW) == 0))
-    return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream, bn_y, bn_aux, bn_slope,
-                           bn_group_images, bnj);
+  if (stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * OH * OW; p.stat_accum = 1; }
+  if (g_use_thin && prec == JCK_PREC_BF16 && cbp == 4 && Cs == 64 && OW % 16 == 0 && is_pow2(OH))
+    return launch_img_down(big, w, small_out, stats, stats_slots, N, Hb, Wb, p.flops, (hipStream_t)stream);
   return launch_igemm(prec, p, jck_pad_rows(Cs), 1, cbp == 4 ? 2 : 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                              int N, int Hb, int Wb, int Cb, int Cs, void* stream) {
-  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream);
+  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, stream);
 }
 // Forward statistics per BatchNorm group of `group_images` images (N % group_images == 0): *stats_slots rows, the first
 // *stats_slots / (N / group_images) of them belong to group 0, and so on - the layout jck_bn_finalize_grouped reads.  Large
@@ -424,21 +358,11 @@ extern "C" int jck_conv_down(int prec, const void* big, const void* w, void* sma
 extern "C" int jck_conv_down_grouped(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
                                      int N, int Hb, int Wb, int Cb, int Cs, int group_images, void* stream) {
   if (group_images < 1 || N % group_images) JCK_FAIL(JCK_E_ARG, "conv_down_grouped: N must be a multiple of group_images >= 1");
-  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, group_images);
+  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, stream, group_images);
 }
-extern "C" int jck_conv_down_bnbwd(int prec, const void* big, const void* w, void* small_out, float* stats, int* stats_slots,
-                                   int N, int Hb, int Wb, int Cb, int Cs, const void* bn_y, const float* bn_aux, float slope,
-                                   int group_images, void* stream) {
-  if (!bn_y) JCK_FAIL(JCK_E_ARG, "conv_down_bnbwd: bn_y is NULL");
-  return conv_down_impl(prec, big, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, bn_y, bn_aux, slope, group_images, stream);
-}
-
 static int conv_up_impl(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
-                        int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float bn_slope,
-                        int bn_group_images, void* stream, int fwd_group_images = 0, const BnStatJob* bnj = nullptr,
-                        const float* in_aux = nullptr, int in_group_images = 0, float in_slope = 0.f) {
+                        int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream, int fwd_group_images = 0) {
   const int cbp = jck_pad_chan(Cb);
-  if (bn_y && ((!stats && !bnj) || !bn_aux)) JCK_FAIL(JCK_E_ARG, "conv_up: BatchNorm-backward statistics need stats and aux");
   if (!is_pow2(Cs) || Cs < 16 || !is_pow2(Hs) || !is_pow2(Ws) || cbp % 4 != 0)
     JCK_FAIL(JCK_E_ARG, "conv_up: shapes must be powers of two (Hs,Ws,Cs>=16)");
   if ((long long)N * Hs * Ws * 4 * cbp >= (1ll << 31)) JCK_FAIL(JCK_E_ARG, "conv_up: tensor exceeds 2^31 elements");
@@ -446,16 +370,11 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   p.act = small_in; p.w = w; p.out = big_out; p.stats = stats;
   p.M = N * Hs * Ws; p.NchStore = cbp; p.logC = ilog2(Cs); p.K = 4 << p.logC;
   p.H = Hs; p.W = Ws; p.logOW = ilog2(Ws); p.logOHW = ilog2(Hs * Ws); p.sy = p.sx = 1; p.ntaps = 4;
-  if (in_aux) {
-    if (cbp == 4 || Cs < 64) return JCK_UNFUSED;
-    p.in_aux = in_aux; p.in_slope = in_slope; p.in_group_images = in_group_images;
-    p.in_groups = in_group_images > 0 ? N / in_group_images : 1;
-  }
   if (cbp == 4) {
     // 3/4-channel output: one launch, the four output parities are the 16 MFMA rows, 9 input offsets as taps; every
     // workgroup then writes whole contiguous output rows instead of interleaved 8-byte pixels
     if (Cs % 64) JCK_FAIL(JCK_E_ARG, "conv_up: Cs % 64 != 0 for a <=4-channel output");
-    if (stats || bnj) JCK_FAIL(JCK_E_ARG, "conv_up: statistics are not provided for <=4-channel outputs");
+    if (stats) JCK_FAIL(JCK_E_ARG, "conv_up: statistics are not provided for <=4-channel outputs");
     p.ntaps = 9; p.K = 9 * Cs; p.NchStore = 16; p.rows_are_phases = 1;
     for (int t = 0; t < 9; ++t) { p.dy[0][t] = (signed char)(t / 3 - 1); p.dx[0][t] = (signed char)(t % 3 - 1); }
     for (int ph = 0; ph < 2; ++ph)
@@ -481,82 +400,20 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   p.w_phase_stride = (long long)rows * p.K;
   if (p.K % 64 != 0) JCK_FAIL(JCK_E_ARG, "conv_up: 4*Cs must be a multiple of 64");
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
-  p.bn_y = bn_y; p.bn_aux = bn_aux; p.bn_slope = bn_slope; p.bn_group_rows = bn_group_images > 0 ? bn_group_images * Hs * Ws : 0;
-  if (!bn_y && stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * Hs * Ws; p.stat_accum = 1; }
-  if (bnj) {
-    p.bnj = *bnj;
-    const int gi = bn_y ? bn_group_images : fwd_group_images;
-    p.bn_group_rows = gi > 0 ? gi * Hs * Ws : 0;
-    if (!is_pow2(cbp)) JCK_FAIL(JCK_E_ARG, "conv_up: BN statistics need a power-of-two channel count");
-  }
+  if (stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * Hs * Ws; p.stat_accum = 1; }
   return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                            int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
-  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, epi_tanh, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream);
+  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, epi_tanh, N, Hs, Ws, Cs, Cb, stream);
 }
 extern "C" int jck_conv_up_grouped(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                                    int N, int Hs, int Ws, int Cs, int Cb, int group_images, void* stream) {
   if (group_images < 1 || N % group_images) JCK_FAIL(JCK_E_ARG, "conv_up_grouped: N must be a multiple of group_images >= 1");
-  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, group_images);
+  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, stream, group_images);
 }
-extern "C" int jck_conv_up_bnbwd(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
-                                 int N, int Hs, int Ws, int Cs, int Cb, const void* bn_y, const float* bn_aux, float slope,
-                                 int group_images, void* stream) {
-  if (!bn_y) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: bn_y is NULL");
-  if (jck_pad_chan(Cb) == 4) JCK_FAIL(JCK_E_ARG, "conv_up_bnbwd: not available for <=4-channel outputs");
-  return conv_up_impl(prec, small_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, bn_y, bn_aux, slope, group_images, stream);
-}
-
-// ---- convolutions that consume a BatchNorm'd, activated tensor WITHOUT that tensor being written (round 3) ----
-// y_in / in_aux: the producer's raw conv output and its [groups][4 * C] tables (jck_bn_finalize*); the launch computes the
-// convolution of a = act(scale * y_in + shift) - what jck_bn_act_fwd_grouped(y_in, in_aux, in_slope) would have written, bit for
-// bit - by transforming the operand in LDS (igemm.hpp, IgemmParams::in_aux).  in_group_images: images per BatchNorm group of the
-// INPUT (N % in_group_images == 0).  Output statistics per group of `group_images` images as in the *_grouped entry points.
-// When the kernel the dispatch picks for this shape has no such transform, a is written to a_buf (must then be non-NULL) by the
-// stand-alone pass and the plain launch runs; *a_written (optional) reports which of the two happened.
-template <class F>
-static int conv_in_fallback(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
-                            int* a_written, int N, long long rows_per_image, int C, void* stream, int rc, F&& plain) {
-  if (a_written) *a_written = 0;
-  if (rc != JCK_UNFUSED) return rc;
-  if (!a_buf) JCK_FAIL(JCK_E_ARG, "conv_*_in: this shape has no fused input transform and a_buf is NULL");
-  const int groups = in_group_images > 0 ? N / in_group_images : 1;
-  JCK_TRY(jck_bn_act_fwd_grouped(prec, y_in, in_aux, in_slope, a_buf, (long long)(N / groups) * rows_per_image, C, groups, stream));
-  if (a_written) *a_written = 1;
-  return plain();
-}
-extern "C" int jck_conv_down_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
-                                int* a_written, const void* w, void* small_out, float* stats, int* stats_slots, int N, int Hb, int Wb,
-                                int Cb, int Cs, int group_images, void* stream) {
-  if (!y_in || !in_aux) JCK_FAIL(JCK_E_ARG, "conv_down_in: y_in / in_aux is NULL");
-  if (group_images < 1 || N % group_images || in_group_images < 0 || (in_group_images && N % in_group_images))
-    JCK_FAIL(JCK_E_ARG, "conv_down_in: N must be a multiple of both group sizes");
-  const int rc = (g_conv_in && prec == JCK_PREC_BF16)
-                     ? conv_down_impl(prec, y_in, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream,
-                                      group_images, nullptr, in_aux, in_group_images, in_slope)
-                     : JCK_UNFUSED;
-  return conv_in_fallback(prec, y_in, in_aux, in_group_images, in_slope, a_buf, a_written, N, (long long)Hb * Wb, Cb, stream, rc, [&]() {
-    return conv_down_impl(prec, a_buf, w, small_out, stats, stats_slots, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, group_images);
-  });
-}
-extern "C" int jck_conv_up_in(int prec, const void* y_in, const float* in_aux, int in_group_images, float in_slope, void* a_buf,
-                              int* a_written, const void* w, void* big_out, float* stats, int* stats_slots, int N, int Hs, int Ws,
-                              int Cs, int Cb, int group_images, void* stream) {
-  if (!y_in || !in_aux) JCK_FAIL(JCK_E_ARG, "conv_up_in: y_in / in_aux is NULL");
-  if (group_images < 1 || N % group_images || in_group_images < 0 || (in_group_images && N % in_group_images))
-    JCK_FAIL(JCK_E_ARG, "conv_up_in: N must be a multiple of both group sizes");
-  const int rc = (g_conv_in && prec == JCK_PREC_BF16)
-                     ? conv_up_impl(prec, y_in, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream,
-                                    group_images, nullptr, in_aux, in_group_images, in_slope)
-                     : JCK_UNFUSED;
-  return conv_in_fallback(prec, y_in, in_aux, in_group_images, in_slope, a_buf, a_written, N, (long long)Hs * Ws, Cs, stream, rc, [&]() {
-    return conv_up_impl(prec, a_buf, w, big_out, stats, stats_slots, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, group_images);
-  });
-}
-
 static int g1_fwd_impl(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
-                       int CiPad, int Co, void* stream, const BnStatJob* bnj) {
+                       int CiPad, int Co, void* stream) {
   if (!is_pow2(CiPad) || CiPad < 64 || !is_pow2(Co) || (16 * Co) % 128 != 0)
     JCK_FAIL(JCK_E_ARG, "g1_fwd: CiPad must be a power of two >= 64, Co a power of two");
   IgemmParams p = {};
@@ -568,84 +425,11 @@ static int g1_fwd_impl(int prec, const void* z, const void* w, void* out, float*
   p.cstat = Co; p.ytiles_per_cset = 1; p.epi = 0; p.w_phase_stride = 0;
   if (Co < 128) JCK_FAIL(JCK_E_ARG, "g1_fwd: Co must be >= 128");
   p.flops = 2.0 * B * 16.0 * Co * CiPad;
-  if (bnj) p.bnj = *bnj;
   return launch_igemm(prec, p, 16 * Co, 1, 1, (hipStream_t)stream, stats_slots);
 }
 extern "C" int jck_g1_fwd(int prec, const void* z, const void* w, void* out, float* stats, int* stats_slots, int B,
                           int CiPad, int Co, void* stream) {
-  return g1_fwd_impl(prec, z, w, out, stats, stats_slots, B, CiPad, Co, stream, nullptr);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// statistics produced and finalised by the launch itself (bnstat.hpp)
-// ---------------------------------------------------------------------------------------------------------
-static int bnx_reps(int C) { return std::max(1, std::min(4, 256 / std::max(1, C))); }      // <= 4 (bnstat.hpp: xsum_read)
-extern "C" size_t jck_bnx_bytes(int C, int groups) {
-  return 64 + (size_t)bnx_reps(C) * (size_t)std::max(1, groups) * 2 * 3 * (size_t)C * 8;     // flags + [reps][groups][2][3 limbs][C] u64
-}
-// mode 0: a producer launch (accumulates only); 1 / 2: the forward / backward consumer.  count = rows per group
-static int make_bnj(const jck_bn_job* j, int C, float count, int mode, BnStatJob* out) {
-  if (!j || !j->xbuf) JCK_FAIL(JCK_E_ARG, "bn job: NULL job / xbuf");
-  if (j->groups < 1 || !is_pow2(C) || C < 8) JCK_FAIL(JCK_E_ARG, "bn job: groups >= 1 and a power-of-two channel count >= 8");
-  if (((uintptr_t)j->xbuf) % 16) JCK_FAIL(JCK_E_ARG, "bn job: xbuf must be 16-byte aligned");
-  BnStatJob b = {};
-  b.flags = reinterpret_cast<unsigned*>(j->xbuf);
-  b.xs = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(j->xbuf) + 64);
-  b.reps = bnx_reps(C); b.groups = j->groups; b.C = C; b.mode = mode; b.count = count;
-  if (mode == 0) {            // producer: accumulates only
-  } else if (mode == 1) {
-    if (!j->gamma || !j->beta || !j->aux) JCK_FAIL(JCK_E_ARG, "bn job (forward): gamma, beta and aux are required");
-    if (j->groups > 1 && j->running_mean) JCK_FAIL(JCK_E_ARG, "bn job (forward): in-place running statistics need groups == 1");
-    b.gamma = j->gamma; b.beta = j->beta; b.eps = j->eps; b.momentum = j->momentum; b.aux = j->aux; b.rec = j->rec;
-    b.running_mean = j->running_mean; b.running_var = j->running_var; b.nbt = (long long*)j->num_batches_tracked;
-  } else {
-    if (!j->aux || !j->sums || j->sums_stride < 2 * C) JCK_FAIL(JCK_E_ARG, "bn job (backward): aux, sums and sums_stride >= 2C are required");
-    b.aux = j->aux; b.sums = j->sums; b.sums_stride = j->sums_stride; b.dgamma = j->dgamma; b.dbeta = j->dbeta;
-    b.grad_groups = j->grad_groups;
-  }
-  *out = b;
-  return JCK_OK;
-}
-extern "C" int jck_conv_down_x(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
-                               const jck_bn_job* job, void* stream) {
-  if (!job || job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_down_x: N must be groups * group_images");
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, Cs, (float)((long long)job->group_images * (Hb / 2) * (Wb / 2)), 0, &b));
-  return conv_down_impl(prec, big, w, small_out, nullptr, nullptr, N, Hb, Wb, Cb, Cs, nullptr, nullptr, 0.f, 0, stream, job->group_images, &b);
-}
-extern "C" int jck_conv_up_x(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
-                             const jck_bn_job* job, void* stream) {
-  if (!job || job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_up_x: N must be groups * group_images");
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, jck_pad_chan(Cb), (float)((long long)job->group_images * 4 * Hs * Ws), 0, &b));
-  return conv_up_impl(prec, small_in, w, big_out, nullptr, nullptr, 0, N, Hs, Ws, Cs, Cb, nullptr, nullptr, 0.f, 0, stream, job->group_images, &b);
-}
-extern "C" int jck_g1_fwd_x(int prec, const void* z, const void* w, void* out, int B, int CiPad, int Co, const jck_bn_job* job, void* stream) {
-  if (!job || job->groups != 1) JCK_FAIL(JCK_E_ARG, "g1_fwd_x: one BatchNorm group");
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, Co, (float)((long long)B * 16), 0, &b));
-  return g1_fwd_impl(prec, z, w, out, nullptr, nullptr, B, CiPad, Co, stream, &b);
-}
-extern "C" int jck_conv_up_bnx(int prec, const void* small_in, const void* w, void* big_out, int N, int Hs, int Ws, int Cs, int Cb,
-                               const jck_bn_job* job, void* stream) {
-  if (!job || !job->bn_y) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: bn_y is NULL");
-  if (job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: N must be groups * group_images");
-  if (jck_pad_chan(Cb) == 4) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: not available for <=4-channel outputs");
-  BnStatJob b;
-  if (!job->aux) JCK_FAIL(JCK_E_ARG, "conv_up_bnx: aux (the forward table of the normalised layer) is NULL");
-  JCK_TRY(make_bnj(job, jck_pad_chan(Cb), (float)((long long)job->group_images * 4 * Hs * Ws), 0, &b));
-  return conv_up_impl(prec, small_in, w, big_out, nullptr, nullptr, 0, N, Hs, Ws, Cs, Cb, job->bn_y, job->aux, job->slope,
-                      job->group_images, stream, 0, &b);
-}
-extern "C" int jck_conv_down_bnx(int prec, const void* big, const void* w, void* small_out, int N, int Hb, int Wb, int Cb, int Cs,
-                                 const jck_bn_job* job, void* stream) {
-  if (!job || !job->bn_y) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: bn_y is NULL");
-  if (job->groups < 1 || job->group_images < 1 || N != job->groups * job->group_images) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: N must be groups * group_images");
-  BnStatJob b;
-  if (!job->aux) JCK_FAIL(JCK_E_ARG, "conv_down_bnx: aux (the forward table of the normalised layer) is NULL");
-  JCK_TRY(make_bnj(job, Cs, (float)((long long)job->group_images * (Hb / 2) * (Wb / 2)), 0, &b));
-  return conv_down_impl(prec, big, w, small_out, nullptr, nullptr, N, Hb, Wb, Cb, Cs, job->bn_y, job->aux, job->slope,
-                        job->group_images, stream, 0, &b);
+  return g1_fwd_impl(prec, z, w, out, stats, stats_slots, B, CiPad, Co, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -734,54 +518,6 @@ static int launch_wgrad_p(const WgradParams& p, const WgradPlan& pl, int nsub, h
   JCK_FAIL(JCK_E_ARG, "wgrad: unsupported tile plan");
 }
 
-// ---- tap-reuse plan (wgrad_halo.hpp): a workgroup owns 64 cs x (16 taps x 32 cb); split-K over 64-pixel k-steps ----
-static bool wgrad_halo_shape(int prec, int Hb, int Wb, int Cb, int cbp, int Cs, long long N = 1) {
-  const int OW = Wb / 2;
-  const long long big_bytes = N * Hb * Wb * (long long)Cb * 2, s_bytes = N * (Hb / 2) * (Wb / 2) * (long long)Cs * 2;
-  return prec == JCK_PREC_BF16 && Hb == Wb && (OW == 4 || OW == 8 || OW == 16 || OW == 32) && cbp == Cb && Cb % 32 == 0 &&
-         Cs % 64 == 0 && big_bytes < (1ll << 31) && s_bytes < (1ll << 31);      // 32-bit byte offsets inside the kernel
-}
-static WgradPlan plan_wgrad_halo(long long Mtot, int cbp, int Cs) {
-  WgradPlan pl;
-  pl.ncols = 16 * cbp; pl.BG = 512; pl.BS = 64;
-  pl.gx = cbp / 32; pl.gy = Cs / 64; pl.CsRows = Cs;
-  const long long nsteps = (Mtot + 63) / 64;
-  long long Z = std::max<long long>(1, std::min<long long>(g_wgrad_wgs / (pl.gx * pl.gy), nsteps));
-  const long long per = (nsteps + Z - 1) / Z;
-  Z = (nsteps + per - 1) / per;
-  pl.Z = (int)Z; pl.mchunk = (int)(per * 64);
-  pl.ws = (size_t)Z * pl.CsRows * pl.ncols * sizeof(float);
-  return pl;
-}
-template <int LOGOW>
-static int launch_wgrad_halo_t(const WgradParams& q, int grid, hipStream_t st) {
-  constexpr int LDSB = HaloGeo<LOGOW>::LDS_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo_kernel<LOGOW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((wgrad_halo_kernel<LOGOW>), dim3(grid), dim3(768), LDSB, st, q);
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-static int launch_wgrad_halo(const WgradParams& p, const WgradPlan& pl, float* ws, size_t ws_bytes, hipStream_t st) {
-  if (ws_bytes < pl.ws) JCK_FAIL(JCK_E_WS, "wgrad: workspace too small: need " + std::to_string(pl.ws));
-  ProfScope prof(22, p.flops, st);
-  WgradParams q = p;
-  q.part = ws; q.CsRows = pl.CsRows; q.ncols = pl.ncols; q.mchunk = pl.mchunk;
-  q.gx = pl.gx; q.gy = pl.gy; q.gz = pl.Z;
-  q.loader_prio = g_wgrad_prio;
-  const int grid = pl.gx * pl.gy * pl.Z;
-  switch (q.logOW) {
-    case 2: return launch_wgrad_halo_t<2>(q, grid, st);
-    case 3: return launch_wgrad_halo_t<3>(q, grid, st);
-    case 4: return launch_wgrad_halo_t<4>(q, grid, st);
-    case 5: return launch_wgrad_halo_t<5>(q, grid, st);
-  }
-  JCK_FAIL(JCK_E_ARG, "wgrad_halo: unsupported image width");
-}
-
 static int run_wgrad(int prec, WgradParams& p, const WgradPlan& pl, int nsub, float* ws, size_t ws_bytes, hipStream_t st) {
   if (ws_bytes < pl.ws) JCK_FAIL(JCK_E_WS, "wgrad: workspace too small: need " + std::to_string(pl.ws));
   p.part = ws; p.CsRows = pl.CsRows; p.ncols = pl.ncols; p.mchunk = pl.mchunk;
@@ -818,8 +554,7 @@ extern "C" size_t jck_conv_wgrad_ws_bytes(int N, int Hb, int Wb, int Cb, int Cs)
   const int cbp = jck_pad_chan(Cb);
   // the larger of the two plans, whatever the knobs say right now (a workspace outlives a jck_tune call)
   const bool wide_shape = cbp >= 64 && (16 * cbp) % 256 == 0 && Cs % 128 == 0;
-  const size_t halo = wgrad_halo_shape(JCK_PREC_BF16, Hb, Wb, Cb, cbp, Cs) ? plan_wgrad_halo(M, cbp, Cs).ws : (size_t)0;
-  return std::max(halo, std::max(plan_wgrad(M, 16 * cbp, Cs).ws, wide_shape ? plan_wgrad(M, 16 * cbp, Cs, true).ws : (size_t)0));
+  return std::max(plan_wgrad(M, 16 * cbp, Cs).ws, wide_shape ? plan_wgrad(M, 16 * cbp, Cs, true).ws : (size_t)0);
 }
 
 extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_side, float* ws, size_t ws_bytes,
@@ -837,15 +572,8 @@ extern "C" int jck_conv_wgrad(int prec, const void* small_side, const void* big_
     const long long bb = (long long)N * Hb * Wb * cbp * esz, sbytes = (long long)p.Mtot * Cs * esz;
     if (bb < (1ll << 31) && sbytes < (1ll << 31)) { p.big_bytes = (unsigned)bb; p.s_bytes = (unsigned)sbytes; }
   }
-  // tap-reuse kernel where it measured faster than the per-tap gather (tests/_mb2.py wgrad_halo 0 1 ...): >= 32 k-steps per
-  // workgroup (the 2B-image products of the D phase: +4..12 %; 16 k-steps: -5..-12 %, the 128 KB fp32 tile each workgroup
-  // writes into its split-K slab is then a third of its time).  JCK_WGRAD_HALO=2 forces it for every admissible shape.
-  bool halo = g_wgrad_halo && p.big_bytes && p.s_bytes && wgrad_halo_shape(prec, Hb, Wb, Cb, cbp, Cs, N);
-  if (halo && g_wgrad_halo != 2 && plan_wgrad_halo(p.Mtot, cbp, Cs).mchunk < 32 * 64) halo = false;
-  const WgradPlan pl = halo ? plan_wgrad_halo(p.Mtot, cbp, Cs) : plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
-  int rc = halo ? launch_wgrad_halo(p, pl, ws, ws_bytes, (hipStream_t)stream)
-                : run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream);
-  if (rc) return rc;
+  const WgradPlan pl = plan_wgrad(p.Mtot, 16 * cbp, Cs, conv_wgrad_wide(prec, cbp, Cs));
+  JCK_TRY(run_wgrad(prec, p, pl, cbp == 4 ? 2 : 1, ws, ws_bytes, (hipStream_t)stream));
   JCK_TRY(launch_wgrad_reduce(ws, pl.Z, pl.CsRows, pl.ncols, Cs, Cb, p.logCb, grad, accumulate, (hipStream_t)stream));
   return JCK_OK;
 }
@@ -946,28 +674,12 @@ static int bn_bwd_blocks(long long rows, int rstep, int groups) {
   return (int)std::max<long long>(1, std::min<long long>((rows + rstep * 4 - 1) / (rstep * 4), BN_BWD_MAX_BLOCKS));
 }
 
+static int bn_act_bwd_grouped_ev(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                                 float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, hipStream_t st,
+                                 hipEvent_t done);
 extern "C" int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
                               void* g_y, float* dgamma, float* dbeta, long long rows, int C, void* stream) {
-  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C must be a power of two in [8, 2048]");
-  const int rstep = 256 / (C / 8);
-  if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd: C too large");
-  // stage 1: per-workgroup partial sums -> sums[2C + blk*2C ..];  stage 2: reduce to sums[0..2C) (+ dgamma/dbeta)
-  const int blocks = bn_bwd_blocks(rows, rstep, 1);
-  float* partial = sums + 2 * C;
-  if (g_bn_unr >= 4) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 4>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
-  else if (g_bn_unr == 2) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
-  else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, 0ll)); }
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C);
-  HIPCHK(hipGetLastError());
-  const long long total8 = rows * C / 8;
-  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
-                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, 0ll));
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
+  return bn_act_bwd_grouped_ev(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows, C, 1, 1, (hipStream_t)stream, nullptr);
 }
 
 // Grouped forms: `groups` independent BatchNorm batches stored back to back ([groups][rows][C] tensors, [groups][slots]
@@ -995,6 +707,12 @@ extern "C" int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux,
 extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums,
                                       void* g_y, float* dgamma, float* dbeta, long long rows_per_group, int C, int groups,
                                       int grad_groups, void* stream) {
+  return bn_act_bwd_grouped_ev(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows_per_group, C, groups, grad_groups, (hipStream_t)stream, nullptr);
+}
+// (`done`: completed by the launch that writes g_y)
+static int bn_act_bwd_grouped_ev(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
+                                 float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, hipStream_t stream,
+                                 hipEvent_t done) {
   if (!is_pow2(C) || C < 8 || C > 2048 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd_grouped: C must be a power of two in [8, 2048]");
   const long long rows = rows_per_group;
   const int rstep = 256 / (C / 8);
@@ -1013,8 +731,8 @@ extern "C" int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, 
                      gstride, groups, grad_groups);
   HIPCHK(hipGetLastError());
   const long long total8 = rows * C / 8;
-  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
+  DISPATCH_T(prec, LAUNCH_EV(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream, done,
+                             (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows, (T*)g_y, total8, C, gstride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1061,9 +779,15 @@ static int bnres_plan(int prec, long long rows, int C, int groups, int* nb_out, 
 extern "C" int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,
                                   float* dgamma, float* dbeta, long long rows_per_group, int C, int groups, int grad_groups,
                                   void* sync_ws, void* stream) {
+  return bn_act_bwd_res_ev(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows_per_group, C, groups, grad_groups, sync_ws,
+                           (hipStream_t)stream, nullptr);
+}
+int bn_act_bwd_res_ev(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y, float* dgamma,
+                      float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* sync_ws, hipStream_t stream,
+                      hipEvent_t done) {
   int nb = 0, nsl = 0;
   const int nch = sync_ws ? bnres_plan(prec, rows_per_group, C, groups, &nb, &nsl) : 0;
-  if (!nch) return jck_bn_act_bwd_grouped(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows_per_group, C, groups, grad_groups, stream);
+  if (!nch) return bn_act_bwd_grouped_ev(prec, g_a, y, aux, slope, sums, g_y, dgamma, dbeta, rows_per_group, C, groups, grad_groups, stream, done);
   BnResParams p;
   p.ga = (const bf16_t*)g_a; p.y = (const bf16_t*)y; p.gy = (bf16_t*)g_y; p.aux = aux;
   p.sums = sums; p.sums_stride = (long long)jck_bn_bwd_ws_floats(C);
@@ -1073,7 +797,7 @@ extern "C" int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, cons
   const dim3 grid(nb), block(BNRES_THREADS);
   // groups resident together (one barrier for all of them) while their chunks fit the register file
   const int ng = (groups >= 3 && 3 * nch <= 16) ? 3 : (groups >= 2 && 2 * nch <= 16) ? 2 : 1;
-#define BNRES_CASE(NCH_, NG_) case NCH_ * 4 + NG_: LAUNCH_ARMABLE((bn_bwd_res_kernel<NCH_, NG_>), grid, block, 0, (hipStream_t)stream, p); break
+#define BNRES_CASE(NCH_, NG_) case NCH_ * 4 + NG_: LAUNCH_EV((bn_bwd_res_kernel<NCH_, NG_>), grid, block, 0, stream, done, p); break
   switch (nch * 4 + ng) {
     BNRES_CASE(1, 1); BNRES_CASE(2, 1); BNRES_CASE(4, 1); BNRES_CASE(8, 1); BNRES_CASE(16, 1);
     BNRES_CASE(1, 2); BNRES_CASE(2, 2); BNRES_CASE(4, 2); BNRES_CASE(8, 2);
@@ -1081,81 +805,6 @@ extern "C" int jck_bn_act_bwd_res(int prec, const void* g_a, const void* y, cons
     default: JCK_FAIL(JCK_E_ARG, "bn_act_bwd_res: no kernel for this plan");
   }
 #undef BNRES_CASE
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-
-// Second half of the BatchNorm backward when the statistics came from a dgrad launch (jck_conv_*_bnbwd): reduce the
-// [groups][slots_per_group][2][C] slots, add dgamma / dbeta (groups < grad_groups), apply.
-extern "C" int jck_bn_bwd_finish(int prec, const void* g_a, const void* y, const float* aux, float slope, const float* slots,
-                                 int slots_per_group, float* sums, void* g_y, float* dgamma, float* dbeta, long long rows_per_group,
-                                 int C, int groups, int grad_groups, void* stream) {
-  if (!is_pow2(C) || C < 8 || groups < 1 || slots_per_group < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_finish: bad shape");
-  const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, slots, slots_per_group, sums, dgamma,
-                     dbeta, C, gstride, groups, grad_groups, (long long)slots_per_group * 2 * C);
-  HIPCHK(hipGetLastError());
-  const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
-                                  gstride));
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-
-// The reduction pass of the BatchNorm backward in the exact-sum form (bnstat.hpp): one launch leaves s1 | s2, dgamma, dbeta -
-// for a layer whose incoming gradient was not produced by a dgrad launch of this library (the top layer of a stack)
-extern "C" int jck_bn_bwd_reduce_x(int prec, const void* g_a, const void* y, long long rows_per_group, int C, const jck_bn_job* job,
-                                   void* stream) {
-  if (!is_pow2(C) || C < 8 || C > 2048) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: C must be a power of two in [8, 2048]");
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 0, &b));
-  if (!job->aux) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: aux (the forward table of the layer) is NULL");
-  b.aux = job->aux;
-  const int rstep = 256 / (C / 8);
-  if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_reduce_x: C too large");
-  const int blocks = bn_bwd_blocks(rows_per_group, rstep, b.groups);
-  if (g_bn_unr >= 2) { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 2>), dim3(blocks, b.groups), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, (const float*)b.aux, job->slope, (float*)nullptr, rows_per_group, C, 0ll, b)); }
-  else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks, b.groups), dim3(256), 2 * C * rstep * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, (const float*)b.aux, job->slope, (float*)nullptr, rows_per_group, C, 0ll, b)); }
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-// consumers of the exact sums: the kernel's prologue finalises (ew.hpp), workgroup 0 of a group leaves the tables
-// one round of resident workgroups (8 x 256 threads per CU): every workgroup pays the prologue, so none queues behind another's
-static unsigned x_grid(long long total8, int groups) {
-  return (unsigned)std::max<long long>(1, std::min<long long>((total8 + 511) / 512, 2048 / std::max(1, groups)));
-}
-extern "C" int jck_bn_act_fwd_x(int prec, const void* y, float slope, void* a, long long rows_per_group, int C, const jck_bn_job* job,
-                                void* stream) {
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 1, &b));
-  const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_x_kernel<T>, dim3(x_grid(total8, b.groups), b.groups), dim3(256), 2 * C * sizeof(float),
-                                      (hipStream_t)stream, (const T*)y, b, slope, (T*)a, total8));
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-extern "C" int jck_bn_bwd_apply_x(int prec, const void* g_a, const void* y, void* g_y, long long rows_per_group, int C,
-                                  const jck_bn_job* job, void* stream) {
-  BnStatJob b;
-  JCK_TRY(make_bnj(job, C, (float)rows_per_group, 2, &b));
-  const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_bwd_apply_x_kernel<T>, dim3(x_grid(total8, b.groups), b.groups), dim3(256), 6 * C * sizeof(float),
-                                      (hipStream_t)stream, (const T*)g_a, (const T*)y, b, job->slope, 1.0f / (float)rows_per_group, (T*)g_y,
-                                      total8));
-  HIPCHK(hipGetLastError());
-  return JCK_OK;
-}
-// g_y = scale * (g_z - s1/n - xhat * s2/n) per group from the s1 | s2 rows (g_y may alias g_a)
-extern "C" int jck_bn_bwd_apply(int prec, const void* g_a, const void* y, const float* aux, const float* sums, long long sums_stride,
-                                float slope, void* g_y, long long rows_per_group, int C, int groups, void* stream) {
-  if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_bwd_apply: bad shape");
-  const long long total8 = rows_per_group * C / 8;
-  DISPATCH_T(prec, LAUNCH_ARMABLE(bn_bwd_apply_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                  (const T*)g_a, (const T*)y, (const float*)aux, (const float*)sums, slope, 1.0f / (float)rows_per_group, (T*)g_y, total8, C,
-                                  sums_stride));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1251,9 +900,12 @@ extern "C" int jck_gp_norm(int prec, const void* g, int N, int HW, float* scal, 
   return JCK_OK;
 }
 extern "C" int jck_tanh_bwd(int prec, const void* g, const void* y, float scale, void* out, long long numel, void* stream) {
+  return tanh_bwd_ev(prec, g, y, scale, out, numel, (hipStream_t)stream, nullptr);
+}
+int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done) {
   if (numel % 4) JCK_FAIL(JCK_E_ARG, "tanh_bwd: numel % 4 != 0");
-  DISPATCH_T(prec, LAUNCH_ARMABLE(tanh_bwd_kernel<T>, dim3(ew_grid(numel / 4)), dim3(256), 0, (hipStream_t)stream,
-                                  (const T*)g, (const T*)y, scale, (T*)out, numel / 4));
+  DISPATCH_T(prec, LAUNCH_EV(tanh_bwd_kernel<T>, dim3(ew_grid(numel / 4)), dim3(256), 0, stream, done,
+                             (const T*)g, (const T*)y, scale, (T*)out, numel / 4));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

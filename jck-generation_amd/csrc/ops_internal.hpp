@@ -41,9 +41,11 @@ int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st);
 bool jck_prof_is_on();
-// The next BatchNorm-backward apply / tanh-backward launch of this thread completes `ev` itself (hipExtLaunchKernel's stopEvent:
-// the dispatch packet's own completion signal) - what a hipEventRecord behind it would do with a marker packet of its own,
-// which costs the launch stream ~6-7 us of idle time per record on this runtime.  No-op for ev == nullptr.
-void jck_arm_stop_event(hipEvent_t ev);
-// the armed event if no launch has taken it yet (and disarms): the caller then records it the ordinary way
-hipEvent_t jck_take_stop_event();
+// Internal forms of the two launches whose result another stream waits for: `done` (may be null) is completed by the launch
+// that writes the result - the dispatch packet's own completion signal (hipExtLaunchKernel's stop event) instead of a
+// hipEventRecord behind it, whose marker packet costs the launch stream ~6-7 us of idle time on this runtime.  The event is an
+// explicit argument (round 3 handed it over through a thread-local "armed" slot that the next armable launch consumed).
+int bn_act_bwd_res_ev(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y, float* dgamma,
+                      float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* sync_ws, hipStream_t stream,
+                      hipEvent_t done);
+int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);

@@ -12,7 +12,6 @@
 // fp32 parity path keeps the generic kernel.  Same k order as the tile kernel, so the products are bitwise the same.
 #pragma once
 #include "common.hpp"
-#include "bnstat.hpp"
 
 struct ImgDownParams {
   const void* x;        // [N, H, W, 4] bf16
@@ -22,13 +21,6 @@ struct ImgDownParams {
   int ngroups;          // 16-pixel groups: N * OH * OW / 16
   int H, W, logOH, logG;     // logG = log2(OW / 16)
   unsigned x_bytes;
-  // BatchNorm-backward statistics instead of forward ones (see IgemmParams::bn_y): y = saved conv output of the layer whose
-  // input gradient this launch produces ([pixels][64], same layout as out), aux = [groups][scale|shift|mean|invstd][64]
-  const void* bn_y;
-  const float* bn_aux;
-  float bn_slope;
-  int bn_group_groups;       // 16-pixel groups per BatchNorm group (0: one group)
-  BnStatJob bnj;             // exact sums by atomics instead of the stats rows (bnstat.hpp): forward, or - with bn_y - backward
 };
 
 template <int GPW>
@@ -71,9 +63,7 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
 #pragma unroll
   for (int k = 0; k < 16; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-  const bf16_t* by = reinterpret_cast<const bf16_t*>(p.bn_y);
-  // this lane's channels: k = 0..7 -> 8g + k, k = 8..15 -> 32 + 8g + (k - 8); a wave's groups lie in one BatchNorm group
-  const float* aux = p.bn_aux + (p.bn_group_groups > 0 ? (long long)(g0 / p.bn_group_groups) * 256 : 0);
+  // this lane's channels: k = 0..7 -> 8g + k, k = 8..15 -> 32 + 8g + (k - 8)
 #pragma unroll
   for (int i = 0; i < GPW; ++i) {
     const int gi = g0 + i;
@@ -88,32 +78,10 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
       for (int t = 0; t < 4; ++t) acc[t] = mfma16(wf[t][s], b, acc[t]);
     }
     u32x4 o0, o1;
-    if (by) {
-      float yv[16];
-      {
-        float lo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (gi < p.ngroups) {
-          const bf16_t* yp = by + ((long long)gi * 16 + pcol) * 64 + 8 * g;
-          ld8(yp, lo); ld8(yp + 32, hi);
-        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { yv[k] = lo[k]; yv[8 + k] = hi[k]; }
-      }
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int c = 32 * (k >> 3) + 8 * g + (k & 7);
-        const float v = acc[k >> 2][k & 3];
-        const float zz = yv[k] * aux[c] + aux[64 + c];
-        const float gz = zz > 0.f ? v : p.bn_slope * v;
-        ssum[k] += gz;
-        ssq[k] += p.bnj.xs ? gz * (yv[k] - aux[128 + c]) : gz * ((yv[k] - aux[128 + c]) * aux[192 + c]);
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float v = acc[t][j]; ssum[4 * t + j] += v; ssq[4 * t + j] += v * v; }
-      }
+      for (int j = 0; j < 4; ++j) { const float v = acc[t][j]; ssum[4 * t + j] += v; ssq[4 * t + j] += v * v; }
     }
     o0[0] = pack2bf(acc[0][0], acc[0][1]); o0[1] = pack2bf(acc[0][2], acc[0][3]);
     o0[2] = pack2bf(acc[1][0], acc[1][1]); o0[3] = pack2bf(acc[1][2], acc[1][3]);
@@ -125,7 +93,7 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
       *reinterpret_cast<u32x4*>(d + 32) = o1;
     }
   }
-  if (!p.stats && !p.bnj.xs) return;
+  if (!p.stats) return;
 #pragma unroll
   for (int k = 0; k < 16; ++k) { ssum[k] = row16_sum(ssum[k]); ssq[k] = row16_sum(ssq[k]); }
   if (pcol == 0) {
@@ -138,12 +106,7 @@ static __global__ __launch_bounds__(256) void img_down_kernel(const ImgDownParam
   __syncthreads();
   if (threadIdx.x < 128) {
     const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (p.bnj.xs) {     // a workgroup's 4 * GPW groups lie in one BatchNorm group (launcher)
-      const int grp = p.bn_group_groups > 0 ? (int)(blockIdx.x * 4 * GPW) / p.bn_group_groups : 0;
-      xsum_add(p.bnj, (int)(blockIdx.x % (unsigned)p.bnj.reps), grp, threadIdx.x >> 6, threadIdx.x & 63, t);
-    } else {
-      p.stats[(long long)blockIdx.x * 128 + threadIdx.x] = t;
-    }
+    p.stats[(long long)blockIdx.x * 128 + threadIdx.x] = t;
   }
 }
 

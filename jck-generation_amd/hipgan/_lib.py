@@ -17,13 +17,6 @@ class StepInputs(C.Structure):
                 ("real_u8", vp), ("real_idx", vp)]
 
 
-class BnJob(C.Structure):
-    """jck_bn_job (include/jckgan.h): statistics produced and finalised by the launch that writes the tensor."""
-    _fields_ = [("xbuf", vp), ("groups", i32), ("group_images", i32), ("gamma", vp), ("beta", vp), ("eps", f32), ("momentum", f32),
-                ("aux", vp), ("rec", vp), ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
-                ("bn_y", vp), ("slope", f32), ("sums", vp), ("sums_stride", i64), ("dgamma", vp), ("dbeta", vp), ("grad_groups", i32)]
-
-
 # name -> (restype, argtypes)      (keep in sync with include/jckgan.h; tests/test_abi.py checks the symbol list)
 PROTOS = {
     "jck_last_error": (C.c_char_p, []),
@@ -49,28 +42,13 @@ PROTOS = {
     "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_bn_finalize_grouped": (i32, [vp, i32, f32, vp, vp, f32, vp, vp, i32, i32, vp]),
     "jck_bn_act_fwd_grouped": (i32, [i32, vp, vp, f32, vp, i64, i32, i32, vp]),
-    "jck_conv_up_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
     "jck_conv_down_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jck_conv_up_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "jck_conv_down_in": (i32, [i32, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "jck_conv_up_in": (i32, [i32, vp, vp, i32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "jck_conv_down_bnbwd": (i32, [i32, vp, vp, vp, vp, C.POINTER(C.c_int), i32, i32, i32, i32, i32, vp, vp, f32, i32, vp]),
-    "jck_bn_bwd_finish": (i32, [i32, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
     "jck_grid_sync_bytes": (sz, []),
     "jck_debug_bnres_stamps": (i32, [vp]),
     "jck_grid_sync_error": (i32, [vp]),
     "jck_bn_act_bwd_res": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]),
-    "jck_bnx_bytes": (sz, [i32, i32]),
-    "jck_conv_down_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
-    "jck_conv_up_x": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
-    "jck_g1_fwd_x": (i32, [i32, vp, vp, vp, i32, i32, i32, C.POINTER(BnJob), vp]),
-    "jck_conv_up_bnx": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
-    "jck_conv_down_bnx": (i32, [i32, vp, vp, vp, i32, i32, i32, i32, i32, C.POINTER(BnJob), vp]),
-    "jck_bn_bwd_reduce_x": (i32, [i32, vp, vp, i64, i32, C.POINTER(BnJob), vp]),
-    "jck_bn_act_fwd_x": (i32, [i32, vp, f32, vp, i64, i32, C.POINTER(BnJob), vp]),
-    "jck_bn_bwd_apply_x": (i32, [i32, vp, vp, vp, i64, i32, C.POINTER(BnJob), vp]),
-    "jck_bn_bwd_apply": (i32, [i32, vp, vp, vp, vp, i64, f32, vp, i64, i32, i32, vp]),
     "jck_img_prep": (i32, [i32, vp, vp, f32, f32, vp, i32, i32, vp]),
     "jck_resize_norm": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp]),
     "jck_img_prep_u8": (i32, [i32, vp, vp, vp, f32, f32, vp, vp, i32, i32, i32, vp]),
@@ -125,7 +103,6 @@ PROTOS = {
     "jck_engine_bind": (i32, [vp, vp, sz] + [vp] * 12),
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
-    "jck_engine_grad_bucket": (i32, [vp, i32, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "jck_engine_grad_tail": (i64, [vp, i32]),
     "jck_engine_check": (i32, [vp]),
     "jck_engine_scalars": (vp, [vp]),
@@ -206,10 +183,6 @@ class _Lib:
                     if not a.is_contiguous():
                         raise JckError(f"{name}: non-contiguous tensor argument")
             r = fn(*[_arg(a) for a in args])
-            if fn.restype is i32 and name == "jck_engine_grad_bucket":      # 0 / 1 are answers, negatives are errors
-                if r < 0:
-                    raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
-                return r
             if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect", "jck_grid_sync_error") \
                     and r != 0:
                 raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")

@@ -1,13 +1,15 @@
 """Data-parallel gradient exchange: one flat fp32 all-reduce per network over RCCL (torch.distributed "nccl").
 
-The all-reduce is issued asynchronously: ProcessGroupNCCL runs it on its own HIP stream after the work already queued
-on the issuing stream.  In the batched schedule the tail of D's arena (conv4.weight .. conv5.weight, 76 % of the bytes) is
-final right after the first weight-gradient product of the backward pass: the engine records an event there
-(jck_engine_grad_bucket) and that slice is reduced from a side stream under the rest of the backward; in the per-pass
-schedule the gradient-penalty pass (no gradients in DCGAN) runs under the whole all-reduce.  `start(flat)` returns a callable that makes the compute stream wait for the result.
-Gradients are SUM-reduced; the 1/world factor is folded into the Adam kernel (grad_scale)."""
-import os
+The all-reduce is issued asynchronously: ProcessGroupNCCL runs it on its own HIP stream after the work already queued on the
+issuing stream; `start(flat)` returns a callable that makes the compute stream wait for the result.  Gradients are SUM-reduced;
+the 1/world factor is folded into the Adam kernel (grad_scale).  Where the collectives sit in the step (D's arena in two pieces
+under D's own backward, G's under the next batch's D(real) forward) is the engine's business: hipgan/engine.py step_async.
 
+ReplicaGuard is the safety net under that overlap (the exchange points are train/dcgan_trainer.py:180,189 of the reference,
+under DistributedDataParallel): every rank must hold the same parameters after a step - the all-reduced gradients went through
+the same Adam - so a checksum whose MAX and MIN over the ranks differ means the schedule misbehaved on this machine.  The
+overlapped schedule has been bit-tested against the plain order with one RCCL rank and with two gloo ranks, never on two
+devices; a trainer must not train on silently diverged replicas if real xGMI disagrees."""
 import torch
 import torch.distributed as dist
 
@@ -19,31 +21,56 @@ class GradReducer:
         self.world = world
         self.group = group
         self.force = force
-        self._comm = None
 
-    def start(self, flat, early=None):
-        """All-reduce (SUM) of a flat gradient arena; returns a callable that makes the current stream wait for it.
-        early = (offset, wait_on): flat[offset:] is already final once `wait_on(stream_handle)` has made a stream wait for
-        the engine's bucket event - that slice is reduced on a side stream at once, under the rest of the backward pass,
-        and only flat[:offset] waits for the end of the phase.  EXPERIMENTAL, off by default (JCK_DDP_BUCKETS=1 enables):
-        the ordering of the two collectives on ProcessGroupNCCL's stream is exercised by tests/test_ddp_gpu.py through a
-        world-size-1 RCCL group only - no run on two or more devices has validated it yet (no multi-GPU node was available
-        to the build)."""
+    def start(self, flat):
+        """All-reduce (SUM) of a flat gradient arena (or a slice of one); returns a callable that makes the current stream wait
+        for it, or None when there is nothing to exchange."""
         if self.world == 1 and not self.force:
             return None
-        works = []
-        if early is not None and os.environ.get("JCK_DDP_BUCKETS", "0") == "1":
-            off, wait_on = early
-            if self._comm is None:
-                self._comm = torch.cuda.Stream(device=flat.device)
-            wait_on(self._comm.cuda_stream)
-            with torch.cuda.stream(self._comm):
-                works.append(dist.all_reduce(flat[off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            works.append(dist.all_reduce(flat[:off], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work.wait
 
-        def wait():
-            for w in works:
-                w.wait()
-        return wait
+
+class ReplicaGuard:
+    """check(): True when every rank holds the same parameters.  On a mismatch: rank 0's state (parameters, Adam moments,
+    BatchNorm buffers) is broadcast again, the engines fall back to the plain schedule (one all-reduce per network, waited for
+    before its Adam: engine.ddp_overlap = False) and the event is logged once per occurrence - the run continues on consistent
+    replicas instead of training on diverged ones."""
+    KEYS = ("g_params", "d_params", "g_m", "g_v", "d_m", "d_v", "g_bn", "d_bn")
+
+    def __init__(self, engines, world, group=None, log=None):
+        self.engines = engines if callable(engines) else (lambda e=engines: [e])      # callable -> the engines in use (one per batch size)
+        self.world, self.group, self.log = world, group, log
+        self.mismatches = 0
+
+    def in_sync(self):
+        if self.world <= 1:
+            return True
+        eng = self.engines()[0]
+        eng.join()
+        a = eng.arenas
+        c = torch.stack([a["d_params"].double().sum(), a["g_params"].double().sum(),
+                         a["d_params"].double().abs().sum(), a["g_params"].double().abs().sum()])
+        hi, lo = c.clone(), c.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(torch.equal(hi, lo))
+
+    def check(self, where=""):
+        if self.in_sync():
+            return True
+        self.mismatches += 1
+        engs = self.engines()
+        was_overlapped = any(getattr(e, "ddp_overlap", False) for e in engs)
+        first = engs[0]
+        for key in self.KEYS:
+            if key in first.arenas:
+                dist.broadcast(first.arenas[key], src=0, group=self.group)        # (engines of one trainer share their arenas)
+        for e in engs:
+            e.ddp_overlap = False
+            e.mark_weights_changed()
+        if self.log:
+            self.log(f"data parallel: the replicas' parameters differ {where}- state re-broadcast from rank 0"
+                     + ("; falling back to one all-reduce per network, waited for before its Adam (the overlapped schedule failed the check)"
+                        if was_overlapped else " (plain schedule already in use: check the interconnect / collectives)"))
+        return False

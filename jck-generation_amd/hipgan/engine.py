@@ -106,7 +106,7 @@ class DcganEngine:
         self.prec = _PREC[prec] if share is None else share.prec
         self.batch = batch
         self.size = image_size if share is None else share.size
-        self._shared = share._shared if share is not None else {"t": 0, "version": 0, "g_stream": None, "last_step": 0}
+        self._shared = share._shared if share is not None else {"t": 0, "version": 0, "last_step": 0}
         self._packed_version = -1
         # hipGraph replay of the step (JCK_GRAPH=1 enables): one captured graph per (segment, step parity, input kind).
         # Default: off.  A captured step is linear (see jck_engine_phase), so it gives up the second stream that runs the weight
@@ -115,6 +115,9 @@ class DcganEngine:
         # the eager CGAN step was enqueue-bound at 3.4 ms and the graph was its default).  Replay remains the answer when the host
         # is busy or slow: 0.10-0.13 ms of host time per step.
         self.graphs = os.environ.get("JCK_GRAPH", "0") != "0"
+        # data parallel: D's all-reduce in two pieces under D's own backward + G's under the next batch's D(real) forward;
+        # False = one all-reduce per network, waited for before its Adam (hipgan.dist.ReplicaGuard falls back to it)
+        self.ddp_overlap = os.environ.get("JCK_DDP_SPLIT", "1") == "1"
         # steps without a noise dict draw z / alpha with torch and the two instance-noise tensors INSIDE the image kernels
         # (Philox, jck_engine_set_noise_seed); JCKGAN_FAST_NOISE=0 draws them with torch.randn as round 1 did
         self.fast_noise = os.environ.get("JCKGAN_FAST_NOISE", "1") != "0"
@@ -341,19 +344,11 @@ class DcganEngine:
         for i in range(4):
             nz[f"m{i + 1}"] = m[i]
 
-    # ---- cross-step pipeline -------------------------------------------------------------------------------
-    # The G phase of step k (D pass on the fake batch, backward into G, Adam(G), G's gradient all-reduce) runs on a second
-    # torch stream; the real-batch D pass of step k+1 does not depend on it and starts at once on the caller's stream.
-    def _g_stream(self):
-        if self._shared["g_stream"] is None:
-            self._shared["g_stream"] = torch.cuda.Stream(device=self.device)
-        return self._shared["g_stream"]
-
     def join(self):
-        """Makes the current stream wait for engine work still in flight on the engine's own streams - the G phase of the
-        cross-step pipeline, the graph-replay stream (call before reading weights, scalars, ...)."""
+        """Makes the current stream wait for engine work still in flight on the engine's own stream - the graph-replay stream
+        (call before reading weights, scalars, ...)."""
         cur = torch.cuda.current_stream()
-        for key in ("g_stream", "e_stream"):
+        for key in ("e_stream",):
             s_ = self._shared.get(key)
             if s_ is not None and s_ != cur:
                 cur.wait_stream(s_)
@@ -432,9 +427,6 @@ class DcganEngine:
         est.wait_stream(main)                                       # inputs produced on the caller's stream
         h, st = self._h, est.cuda_stream
         with torch.cuda.stream(est):
-            gs = self._shared["g_stream"]
-            if gs is not None:
-                est.wait_stream(gs)
             real_s, nz = self._fill_static(real, noise, generator, labels)
             self._fallback_inputs = (real_s, nz)        # an eager retry must not draw a second time
             # The caller's tensors were read by copies on THIS stream: the caller's stream waits for those copies, so memory
@@ -508,26 +500,24 @@ class DcganEngine:
         self._packed_version = self._shared["version"]
         self._keep = keep
 
-    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, pipeline=None, graph=None,
+    def step_async(self, real, noise=None, lr=2e-4, reduce_d=None, reduce_g=None, grad_scale=1.0, graph=None,
                    generator=None, labels=None, next_real=None, next_noise=None, lr_g=None):
-        """Enqueues one full step; no host sync.  lr_g: G's learning rate when it differs from D's `lr` (eager launches only).  noise=None draws on the device (generator= / labels= as draw_noise takes
-        them).  graph (default: off, env JCK_GRAPH=1 enables; never with the pipeline or per-launch profiling): replay the
-        step from captured hipGraphs on the engine's own stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss and the
-        optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  pipeline (DCGAN only; default off,
-        env JCK_PIPELINE=1 enables): run the G phase - with G's gradient all-reduce - on a second stream so that the next
-        step's D(real) pass overlaps it.  On one GPU the in-step overlap already saturates the memory system and the
-        pipeline measured 8 % slower; it exists for the multi-GPU case where it hides the G all-reduce.
+        """Enqueues one full step; no host sync.  noise=None draws on the device (generator= / labels= as draw_noise takes
+        them).  lr_g: G's learning rate when it differs from D's `lr` (eager launches only).  graph (default: off, env
+        JCK_GRAPH=1 enables; never with per-launch profiling): replay the step from captured hipGraphs on the engine's own
+        stream - the first step of an engine always runs eagerly.  `reduce_d/reduce_g(flat_grads)` are called between the loss
+        and the optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  With self.ddp_overlap
+        (default; JCK_DDP_SPLIT=0 or hipgan.dist.ReplicaGuard switch it off) the DCGAN step puts D's all-reduce in two pieces
+        under D's own backward, and:
         next_real (with reduce_g; DCGAN, batched schedule, eager launches): the NEXT step's real batch.  The forward half of
         its D(real) pass (input transform, instance noise - next_noise["n1"] when the caller supplies noise tensors -, conv
         stack + BatchNorm statistics) is then enqueued right behind the start of G's gradient all-reduce, so the collective
         runs under ~0.13 ms of compute that needs no G weights, instead of being waited for at once; the next step_async call
         must be given that same batch.  Results are bitwise those of the plain order (PHASE_D_REAL_FWD, include/jckgan.h)."""
-        if pipeline is None:
-            pipeline = self.family == 0 and os.environ.get("JCK_PIPELINE", "0") == "1"
         if self._packed_version != self._shared["version"]:
             self.join()
             self.repack()
-        use_graph = (self.graphs if graph is None else graph) and not pipeline and self._eager_steps >= 1 and lr_g is None
+        use_graph = (self.graphs if graph is None else graph) and self._eager_steps >= 1 and lr_g is None
         pre_key = getattr(self, "_prefetched_real", None)
         if pre_key is not None:
             self._prefetched_real = None
@@ -546,68 +536,47 @@ class DcganEngine:
                 if self._fallback_inputs is not None:      # this step's inputs are already drawn / copied into the static buffers
                     real, noise = self._fallback_inputs
                     self._fallback_inputs = None
-        if lr_g is not None and pipeline:
-            raise JckError("lr_g needs the plain eager schedule")
         self._eager_steps += 1
         noise = noise if noise is not None else self.draw_noise(generator, labels=labels, fast=self.fast_noise)
         si, keep = self._inputs(real, noise, lr, grad_scale)
-        main = torch.cuda.current_stream()
-        st = main.cuda_stream
+        st = torch.cuda.current_stream().cuda_stream
         h = self._h
-        split_done = False
-        if pipeline:
-            gs = self._g_stream()
-            lib.jck_engine_phase(h, PHASE_D_REAL, C.byref(si), st)     # beside the previous step's G phase
-            main.wait_stream(gs)                                       # G weights of the previous step are final
-            lib.jck_engine_phase(h, PHASE_D_FAKE, C.byref(si), st)
-        else:
-            self.join()
-            tail = int(lib.jck_engine_grad_tail(h, 1)) if (reduce_d and self.family == 0 and os.environ.get("JCK_DDP_SPLIT", "1") == "1") else -1
-            if tail > 0:
-                # data parallel, batched schedule: the tail of D's gradient arena (conv4.weight .. conv5.weight, 76 % of its
-                # bytes) is final after the first weight-gradient product of the backward pass - its all-reduce is started
-                # there, in plain stream order, and runs under the remaining ~0.5 ms of the pass; the head follows at the end
-                flat = self.arenas["d_grads"]
-                lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
-                w_tail = reduce_d(flat[tail:])
-                lib.jck_engine_phase(h, PHASE_D_LOSS_B, C.byref(si), st)
-                w_head = reduce_d(flat[:tail])
-                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
-                for w in (w_tail, w_head):
-                    if w is not None:
-                        w()
-                split_done = True
-            else:
-                lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
-        if split_done:
-            handle = None
-        elif self.family == 0:
-            handle = self._reduce_d(reduce_d) if reduce_d else None
-            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
-        else:                                                      # CGAN back-propagates the penalty: reduce after it
+        self.join()
+        tail = int(lib.jck_engine_grad_tail(h, 1)) if (reduce_d and self.family == 0 and self.ddp_overlap) else -1
+        if tail > 0:
+            # data parallel, batched schedule: the tail of D's gradient arena (conv4.weight .. conv5.weight, 76 % of its
+            # bytes) is final after the first weight-gradient product of the backward pass - its all-reduce is started
+            # there, in plain stream order, and runs under the remaining ~0.5 ms of the pass; the head follows at the end
+            flat = self.arenas["d_grads"]
+            lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
+            w_tail = reduce_d(flat[tail:])
+            lib.jck_engine_phase(h, PHASE_D_LOSS_B, C.byref(si), st)
+            w_head = reduce_d(flat[:tail])
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
-            handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
-        if handle is not None:
-            handle()
-        lib.jck_engine_phase(h, PHASE_D_STEP, C.byref(si), st)
-        if pipeline:
-            gs.wait_stream(main)
-            with torch.cuda.stream(gs):
-                lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), gs.cuda_stream)
-                handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
-                if handle is not None:
-                    handle()
-                lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), gs.cuda_stream)
+            for w in (w_tail, w_head):
+                if w is not None:
+                    w()
         else:
-            lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
-            if lr_g is not None:
-                si.lr = lr_g                 # the engine rewrites only the Adam scalars of the step for the new rate
-            handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+            lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
+            if self.family == 0:
+                handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
+                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
+            else:                                                      # CGAN back-propagates the penalty: reduce after it
+                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
+                handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
             if handle is not None:
-                if next_real is not None and self.family == 0 and getattr(self, "_prefetch_ok", True) and not (self.graphs if graph is None else graph):
-                    keep += self._prefetch_real(next_real, next_noise, lr, grad_scale, st)     # runs under G's all-reduce
                 handle()
-            lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
+        lib.jck_engine_phase(h, PHASE_D_STEP, C.byref(si), st)
+        lib.jck_engine_phase(h, PHASE_G_LOSS, C.byref(si), st)
+        if lr_g is not None:
+            si.lr = lr_g                 # the engine rewrites only the Adam scalars of the step for the new rate
+        handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+        if handle is not None:
+            if (next_real is not None and self.family == 0 and self.ddp_overlap and getattr(self, "_prefetch_ok", True)
+                    and not (self.graphs if graph is None else graph)):
+                keep += self._prefetch_real(next_real, next_noise, lr, grad_scale, st)     # runs under G's all-reduce
+            handle()
+        lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1
         self._shared["last_step"] = self.t
         self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
@@ -630,24 +599,10 @@ class DcganEngine:
         self._prefetched_real = self._real_key(next_real)
         return keep2
 
-    def _reduce_d(self, reduce_d):
-        """Starts D's gradient all-reduce; hands the reducer the early bucket of the batched schedule when it takes one."""
-        import inspect
-        flat = self.arenas["d_grads"]
-        off, num = C.c_longlong(), C.c_longlong()
-        try:
-            takes_early = "early" in inspect.signature(reduce_d).parameters
-        except (TypeError, ValueError):
-            takes_early = False
-        if takes_early and lib.jck_engine_grad_bucket(self._h, 1, None, C.byref(off), C.byref(num)) == 1:
-            h = self._h
-            return reduce_d(flat, early=(off.value, lambda stream: lib.jck_engine_grad_bucket(h, 1, stream, None, None)))
-        return reduce_d(flat)
-
     def record_scalars(self, dst_row):
         """Copies the step scalars (device float[8]) into `dst_row` on the stream that produced them - no host sync and no
         stall of the next step's D pass."""
-        gs = self._shared["g_stream"] or self._shared.get("e_stream")
+        gs = self._shared.get("e_stream")
         src = self.scalars_view(joined=False)
         if gs is None:
             dst_row.copy_(src, non_blocking=True)

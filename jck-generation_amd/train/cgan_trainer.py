@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from hipgan.dist import GradReducer
+from hipgan.dist import GradReducer, ReplicaGuard
 from hipgan.engine import SCALAR_NAMES, CganEngine, DeviceBatch
 from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
@@ -55,6 +55,8 @@ class CGANTrainer(DCGANTrainer):
             self.engine.mark_weights_changed()
         self._tail_engines = {}
         self.reducer = GradReducer(self.world) if self.world > 1 else None
+        self.guard = (ReplicaGuard(lambda: [self.engine] + list(self._tail_engines.values()), self.world, log=self.logger.debug)
+                      if self.world > 1 else None)         # replicas must stay identical: hipgan/dist.py
         # per-rank noise stream in data-parallel runs (every rank is seeded alike by main.py; see DCGANTrainer)
         self.noise_gen = self.host_gen = None
         if self.world > 1:
@@ -220,7 +222,10 @@ class CGANTrainer(DCGANTrainer):
                     s = eng.scalars()
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
                                       + f"\tD(x): {s['d_x']:.4f}\tD(G(z)): {s['d_gz1']:.4f} / {s['d_gz2']:.4f}")
-                if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
+                at_eval = (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1))
+                if self.guard is not None and (iters == 2 or (at_eval and iters > 2)):
+                    self.guard.check(f"after iteration {iters} ")
+                if at_eval:
                     self._evaluate(fixed_noise, fixed_labels, iters, best, image_save_path)
                 iters += 1
         self._finish_eval(best, wait=True)

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from hipgan import JckError
-from hipgan.dist import GradReducer
+from hipgan.dist import GradReducer, ReplicaGuard
 from hipgan.engine import SCALAR_NAMES, DcganEngine, DeviceBatch
 from hipgan.optim import EngineAdam
 from logger.main_logger import MainLogger
@@ -128,6 +128,10 @@ class DCGANTrainer(Trainer):
             self.engine.mark_weights_changed()
         self._tail_engines = {}
         self.reducer = GradReducer(self.world) if self.world > 1 else None
+        # every rank must hold the same parameters after a step: checked after the first steps and at every evaluation point; on a
+        # mismatch the state is re-broadcast and the engines fall back to the plain all-reduce schedule (hipgan/dist.py)
+        self.guard = (ReplicaGuard(lambda: [self.engine] + list(self._tail_engines.values()), self.world, log=self.logger.debug)
+                      if self.world > 1 else None)
         # data parallel: main.py seeds every rank alike (identical initial weights), so the NOISE needs its own per-rank stream -
         # otherwise every replica draws the same z / instance noise / alpha, generates the same fake batch, and the all-reduce
         # averages N identical gradients (effective batch B instead of N*B for G and for the fake half of D)
@@ -296,7 +300,10 @@ class DCGANTrainer(Trainer):
                     s = eng.scalars()                                # the only host sync of the iteration
                     self.logger.debug(f"[{epoch}/{self.epoch}][{i}/{len(loader)}]\tloss_d: {s['loss_d']:.4f}\tloss_g: {s['loss_g']:.4f}"
                                       + f"\tD(x): {s['d_x']:.4f}\tD(G(z)): {s['d_gz1']:.4f} / {s['d_gz2']:.4f}")
-                if (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1)):
+                at_eval = (iters % EVAL_EVERY == 0) or ((epoch == self.epoch - 1) and (i == len(loader) - 1))
+                if self.guard is not None and (iters == 2 or (at_eval and iters > 2)):
+                    self.guard.check(f"after iteration {iters} ")
+                if at_eval:
                     self._evaluate(fixed_noise, iters, best)
                 iters += 1
         self._finish_eval(best, wait=True)

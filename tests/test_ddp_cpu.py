@@ -1,4 +1,4 @@
-"""Data-parallel logic on CPU, world_size 2, gloo: (1) GradReducer's async flat all-reduce, (2) N replicas that exchange
+"""Data-parallel logic on CPU, world_size 2, gloo: (1) GradReducer's async flat all-reduce, (3) the replica guard, (2) N replicas that exchange
 gradients through torch.distributed reproduce oracle.ddp_step (N copies, local BatchNorm statistics, averaged gradients -
 the N-rank oracle of SURVEY.md section 8e) and differ from the single-process global-batch run, as expected."""
 import os
@@ -58,6 +58,27 @@ def _worker(rank, world, port, q):
     red.start(flat)()
     orc.apply_g(_unflat(flat / world, ctx["g_grads"]))
     res = orc.finish(ctx)
+    # (3) the replica guard both trainers run (hipgan.dist.ReplicaGuard), on a stand-in for the engine: in-sync passes; a drifted
+    # rank fails the check on every rank, rank 0's state comes back, the overlapped schedule is switched off, one log line
+    from hipgan.dist import ReplicaGuard
+
+    class _Eng:
+        def __init__(self):
+            g = torch.Generator().manual_seed(3)
+            self.arenas = {k: torch.randn(n, generator=g) for k, n in (("g_params", 50), ("d_params", 70), ("g_m", 50), ("d_v", 70))}
+            self.ddp_overlap, self.marked = True, 0
+        def join(self): pass
+        def mark_weights_changed(self): self.marked += 1
+    eng, msgs = _Eng(), []
+    guard = ReplicaGuard(eng, world, log=msgs.append)
+    assert guard.check() and eng.ddp_overlap and not msgs
+    if rank == 1:
+        eng.arenas["d_params"][3] += 1e-3
+        eng.arenas["g_m"][0] = 5.0
+    assert not guard.check("in the test ") and not eng.ddp_overlap and eng.marked == 1 and len(msgs) == 1 and guard.mismatches == 1
+    assert guard.in_sync()
+    ref = _Eng().arenas
+    assert all(torch.equal(eng.arenas[k], ref[k]) for k in ref)          # rank 0's (undisturbed) state everywhere
     np_ = lambda sd: {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}      # numpy: no shared-memory handles
     q.put((rank, np_(orc.g), np_(orc.d), res["loss_d"]))
     dist.barrier()

@@ -1,7 +1,7 @@
 """Two engine replicas as two processes on ONE GPU (gloo carries the CUDA tensors; RCCL needs one device per rank): the
 native step with gradient exchange reproduces the N-replica CPU oracle.  RCCL itself runs here through a ONE-rank "nccl"
 process group (test_rccl_world1_*): that is the real ProcessGroupNCCL stream path - the collectives are enqueued on RCCL's
-stream behind the issuing stream, the early bucket from a side stream - and SUM over one rank must leave every bit unchanged.
+stream behind the issuing stream - and SUM over one rank must leave every bit unchanged.
 No run on two or more devices has happened yet (no multi-GPU node was available to the build; the driver's SCALE run is the
 first)."""
 import os
@@ -26,7 +26,6 @@ def _worker(rank, world, port, q, steps, B):
     for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    os.environ["JCK_DDP_BUCKETS"] = "1"            # experimental early bucket (off by default): keep it under test
     os.environ["JCK_BN_RES"] = "0"                 # two ranks share ONE GPU here: a resident (grid-barrier) launch needs the chip to itself
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hipgan.dist import GradReducer
@@ -61,7 +60,7 @@ def _worker(rank, world, port, q, steps, B):
 @pytest.mark.parametrize("B", [4, 8])
 def test_two_replicas_match_ddp_oracle(B):
     """B = 4: per-pass schedule, one all-reduce per network.  B = 8: batched schedule - the tail of D's gradient arena is
-    all-reduced from a side stream as soon as the engine's bucket event fires, the rest at the end of the phase."""
+    all-reduced between the two halves of D's backward (PHASE_D_LOSS_A / _B), the rest at the end of the phase."""
     from oracle.gan_oracle import GanOracle, ddp_step
     from util import synth_images
     world, steps = 2, 2                  # the second step's D(real) forward is announced by the first (B = 8)
@@ -158,7 +157,6 @@ ROOT = sys.argv[1]
 for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
-os.environ["JCK_DDP_BUCKETS"] = "1"                       # the early-bucket path is what this test is about
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from hipgan.dist import GradReducer
@@ -170,32 +168,32 @@ B = 16
 torch.manual_seed(12345)
 g, d = build_params("dcgan")
 imgs = synth_images(B * 3)
-def run(reduce, pipeline):
+def run(reduce, overlap):
     eng = DcganEngine(batch=B, prec="bf16", device="cuda:0")
+    eng.ddp_overlap = overlap                # D's arena in two pieces under its own backward / one all-reduce per network
     eng.load_state(g, d)
     red = GradReducer(1, force=True) if reduce else None
     for s in range(3):
         nz = {k: v.cuda() for k, v in be.noise_for("dcgan", B, 70 + s).items()}
         kw = dict(reduce_d=red.start, reduce_g=red.start) if red else {}
-        eng.step_async(imgs[s * B:(s + 1) * B].cuda(), nz, 2e-4, pipeline=pipeline, **kw)
+        eng.step_async(imgs[s * B:(s + 1) * B].cuda(), nz, 2e-4, **kw)
     eng.join()
     torch.cuda.synchronize()
     return {k: v.clone() for k, v in eng.arenas.items()}, eng.scalars()
-base, sb = run(False, False)
-for pipe in (False, True):
-    ref, sr = (base, sb) if not pipe else run(False, True)
-    got, sg = run(True, pipe)
-    assert sg == sr, (pipe, sg, sr)
-    for k in ref:
-        assert torch.equal(ref[k], got[k]), (pipe, k)
+base, sb = run(False, True)
+for overlap in (False, True):
+    got, sg = run(True, overlap)
+    assert sg == sb, (overlap, sg, sb)
+    for k in base:
+        assert torch.equal(base[k], got[k]), (overlap, k)
 dist.destroy_process_group()
 print("RCCL1-OK")
 """
 
 
 def test_rccl_world1_reduce_paths_leave_every_bit_unchanged(tmp_path):
-    """GradReducer.start(flat, early=...) and the full step_async(reduce_d=, reduce_g=) through a ONE-rank RCCL group, with
-    and without the cross-step pipeline: the results must equal the no-reduce step bit for bit (SUM over one rank is the
+    """GradReducer.start and the full step_async(reduce_d=, reduce_g=) through a ONE-rank RCCL group, with D's arena reduced
+    in two pieces under its own backward and as one all-reduce: the results must equal the no-reduce step bit for bit (SUM over one rank is the
     identity, the step has no float atomics) - which they only do if every collective is ordered behind the gradient
     kernels it reduces and ahead of the optimiser kernels that read it."""
     import subprocess
@@ -273,3 +271,68 @@ def test_split_d_pass_is_offered_only_where_it_exists():
         si.labels = torch.zeros(16, 100, dtype=torch.int64, device="cuda").data_ptr()
         with pytest.raises(JckError):
             lib.jck_engine_phase(other._h, PHASE_D_LOSS_A, ctypes.byref(si), None)
+
+
+def _guard_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "jck-generation_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["JCK_BN_RES"] = "0"                 # two ranks share ONE GPU here (see _worker)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hipgan.dist import GradReducer, ReplicaGuard
+    from hipgan.engine import DcganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images
+    B = 8
+    torch.manual_seed(12345)
+    g, d = build_params("dcgan")
+    eng = DcganEngine(batch=B, prec="f32", device="cuda:0")
+    eng.load_state(g, d)
+    red = GradReducer(world)
+    msgs = []
+    guard = ReplicaGuard(eng, world, log=msgs.append)
+    imgs = synth_images(B * world * 3)
+
+    def step(s):
+        eng.step_async(imgs[(s * world + rank) * B:(s * world + rank + 1) * B].cuda(),
+                       {k: v.cuda() for k, v in _noise(B, 500 + 10 * s + rank).items()}, 2e-4,
+                       reduce_d=red.start, reduce_g=red.start, grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+    step(0)
+    ok0, over0 = guard.check("after step 0 "), eng.ddp_overlap
+    if rank == 1:                                  # one replica drifts (what a misordered collective would do)
+        eng.arenas["d_params"][7] += 1e-3
+        eng.mark_weights_changed()
+    ok1 = guard.check("after the injected divergence ")
+    over1, ok2 = eng.ddp_overlap, guard.in_sync()
+    step(1)                                        # the plain schedule on re-broadcast state
+    ok3 = guard.in_sync()
+    q.put((rank, ok0, over0, ok1, over1, ok2, ok3, len(msgs), float(eng.arenas["d_params"].double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_guard_detects_a_divergence_and_falls_back():
+    """hipgan.dist.ReplicaGuard (what both trainers call after the first steps and at every evaluation point): in-sync replicas
+    pass and keep the overlapped schedule; once one rank's parameters drift the check fails on EVERY rank, rank 0's state is
+    broadcast again, the engines switch to one all-reduce per network (ddp_overlap False), the event is logged once, and the
+    replicas are - and stay - identical afterwards."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 77) % 2000)
+    procs = [ctx.Process(target=_guard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=240)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        ok0, over0, ok1, over1, ok2, ok3, nmsg, _ = got[rank]
+        assert ok0 and over0, (rank, got[rank])
+        assert not ok1 and not over1 and ok2 and ok3 and nmsg == 1, (rank, got[rank])
+    assert got[0][7] == got[1][7]

@@ -84,17 +84,12 @@ def test_conv_up(G, prec, shape):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("halo", [2, 0])
 @pytest.mark.parametrize("shape", [(2, 8, 64, 128), (3, 64, 3, 64), (2, 16, 128, 256), (4, 8, 256, 512), (7, 8, 64, 128),
                                    (16, 32, 64, 128), (3, 64, 64, 128), (9, 16, 32, 64), (5, 8, 32, 192), (21, 8, 64, 64)])
-def test_conv_wgrad(G, prec, shape, halo):
-    """dW of Conv2d(big->small) == dW of ConvTranspose2d(small->big): one kernel, checked against both.  halo=2: the
-    tap-reuse kernel (wgrad_halo.hpp: all four patch geometries, ragged image counts, split-K over several workgroups) where
-    the shape admits it; halo=0: the per-tap gather kernels."""
+def test_conv_wgrad(G, prec, shape):
+    """dW of Conv2d(big->small) == dW of ConvTranspose2d(small->big): one kernel, checked against both (ragged image
+    counts, split-K over several workgroups)."""
     n, hb, cb, cs = shape
-    if halo == 0 and prec == 1:
-        pytest.skip("the fp32 path has one kernel")
-    G.lib.jck_tune(b"wgrad_halo", halo)
     g = torch.Generator().manual_seed(3)
     big = G.rnd(torch.randn(n, cb, hb, hb, generator=g), prec)
     small = G.rnd(torch.randn(n, cs, hb // 2, hb // 2, generator=g), prec)
@@ -115,7 +110,6 @@ def test_conv_wgrad(G, prec, shape, halo):
                          G.cur_stream())
     torch.cuda.synchronize()
     G.check(grad.cpu(), ref, 3e-6 if prec == 1 else 2e-3, "conv_wgrad(overwrite)")
-    G.lib.jck_tune(b"wgrad_halo", 0)
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -190,67 +184,6 @@ def test_bn_act(G, prec, cfg):
     G.check(G.from_nhwc(gy), y.grad, 2e-5 if prec == 1 else 2e-2, "bn_act_bwd dx")
     G.check(dgam.cpu() - 1, gamma.grad, 2e-5 if prec == 1 else 1e-2, "dgamma")
     G.check(dbet.cpu() - 1, beta.grad, 2e-5 if prec == 1 else 1e-2, "dbeta")
-
-
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("cfg", [("up", 4, 8, 256, 128, 2), ("up", 2, 16, 128, 64, 0), ("down", 4, 16, 128, 256, 0),
-                                 ("down", 4, 64, 3, 64, 2), ("down", 3, 32, 3, 64, 0),
-                                 # large enough for the persistent kernels, whose statistics are accumulated per workgroup and
-                                 # BatchNorm group (igemm.hpp): 128x256 tiles (384), 128x64 tiles (768), 64x128 tiles (1536)
-                                 ("up", 96, 16, 256, 128, 32), ("down", 96, 32, 64, 256, 32), ("up", 48, 16, 128, 64, 16),
-                                 ("up", 64, 16, 256, 128, 0)])
-def test_dgrad_with_bn_backward_stats(G, prec, cfg):
-    """conv dgrad whose epilogue also leaves sum(g_z), sum(g_z*xhat) of the BatchNorm+activation in front of it, followed by
-    jck_bn_bwd_finish, against autograd through batch_norm -> (leaky_)relu -> conv; grouped = independent BN batches."""
-    kind, n, hin, cin, cout, gimg = cfg      # gimg = images per BatchNorm group (0: one group)
-    slope = 0.2 if kind == "up" else 0.0
-    g = torch.Generator().manual_seed(11)
-    groups = n // gimg if gimg else 1
-    hout = 2 * hin if kind == "up" else hin // 2
-    y = G.rnd(torch.randn(n, cout, hout, hout, generator=g) * 1.3 + 0.2, prec).requires_grad_(True)    # saved conv output of layer L
-    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
-    beta = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
-    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
-    wr = G.rnd(w, prec)
-    gin = G.rnd(torch.randn(n, cin, hin, hin, generator=g), prec)            # gradient arriving at the conv that consumed a_L
-    # reference: g_a = dgrad(gin); then backward through act and per-group batch norm
-    ga = F.conv_transpose2d(gin, wr, None, 2, 1) if kind == "up" else F.conv2d(gin, wr, None, 2, 1)
-    per = gimg if gimg else n
-    parts = []
-    for k in range(groups):
-        yy = y[k * per:(k + 1) * per]
-        bn = F.batch_norm(yy, None, None, gamma, beta, True, 0.1, 1e-5)
-        parts.append(F.leaky_relu(bn, slope) if slope else F.relu(bn))
-    torch.cat(parts).backward(ga)
-    # library: aux per group, fused dgrad + statistics, finish
-    yd = G.to_nhwc(y.detach(), prec)
-    c = cout
-    rows = per * hout * hout
-    aux = torch.empty(groups, 4 * c, device="cuda")
-    for k in range(groups):
-        yf = yd[k * per:(k + 1) * per].float().reshape(rows, c)
-        st = torch.stack([yf.sum(0), (yf ** 2).sum(0)]).contiguous()
-        G.lib.jck_bn_finalize(st, 1, float(rows), gamma.detach().cuda(), beta.detach().cuda(), None, None, None, 0.1, 1e-5,
-                              aux[k], c, G.cur_stream())
-    out = torch.empty_like(yd)
-    stats, slots = G.stats_buf(n * hout * hout, c)
-    if kind == "up":
-        G.lib.jck_conv_up_bnbwd(prec, G.to_nhwc(gin, prec), G.pack_up(w, prec), out, stats, ctypes.byref(slots), n, hin, hin, cin,
-                                cout, yd, aux, slope, gimg, G.cur_stream())
-    else:
-        G.lib.jck_conv_down_bnbwd(prec, G.to_nhwc(gin, prec), G.pack_down(w, prec), out, stats, ctypes.byref(slots), n, hin, hin,
-                                  cin, cout, yd, aux, slope, gimg, G.cur_stream())
-    assert slots.value % groups == 0
-    sums = torch.full((groups * G.lib.jck_bn_bwd_ws_floats(c),), float("nan"), device="cuda")
-    dgam, dbet = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
-    gy = torch.empty_like(yd)
-    G.lib.jck_bn_bwd_finish(prec, out, yd, aux, slope, stats, slots.value // groups, sums, gy, dgam, dbet, rows, c, groups,
-                            groups, G.cur_stream())
-    torch.cuda.synchronize()
-    G.check(G.from_nhwc(out), ga, G.TOL[prec], "dgrad")
-    G.check(G.from_nhwc(gy), y.grad, 3e-5 if prec == 1 else 3e-2, "dx")
-    G.check(dgam.cpu(), gamma.grad, 3e-5 if prec == 1 else 1e-2, "dgamma")
-    G.check(dbet.cpu(), beta.grad, 3e-5 if prec == 1 else 1e-2, "dbeta")
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -500,197 +433,4 @@ def test_grouped_forward_statistics(G, cfg):
         G.check(rows[k, :, 1].sum(0), (r * r).sum((0, 2, 3)), 2e-3, f"sum of squares, group {k}")
 
 
-@pytest.mark.parametrize("cfg", [("down", 96, 32, 64, 128, 32, 0.2), ("down", 192, 16, 128, 256, 64, 0.2), ("down", 24, 8, 256, 512, 8, 0.2),
-                                 ("up", 96, 16, 256, 128, 32, 0.0), ("up", 48, 8, 512, 256, 48, 0.0), ("down", 768, 8, 256, 512, 256, 0.2),
-                                 ("down", 6, 16, 128, 256, 2, 0.2), ("up", 10, 4, 512, 256, 5, 0.0), ("down", 256, 32, 64, 128, 64, 0.2),
-                                 ("up", 48, 16, 128, 64, 16, 0.0), ("down", 24, 8, 256, 512, 8, -1.0)])
-def test_conv_with_fused_batchnorm_input(G, cfg):
-    """jck_conv_down_in / jck_conv_up_in (the nn.BatchNorm2d + activation between two convolutions applied to the gathered operand
-    in LDS, reference model/DCGAN.py:30-33,62-65): output and statistic rows must be BIT-identical to the unfused pair
-    jck_bn_act_fwd_grouped -> jck_conv_*_grouped, the activation must not have been written when the fused kernel ran, and the
-    output agrees with PyTorch's conv(act(scale * y + shift)).  Groups of the input (BatchNorm per batch of the batched D pass)
-    with their own tables; small shapes fall back to the stand-alone pass inside the call and say so."""
-    kind, n, hin, cin, cout, gimg, slope = cfg
-    prec = G.PREC_BF16
-    forced_fallback = slope < 0                       # (slope -1: the call's own unfused route, jck_tune "conv_in" 0)
-    slope = 0.2 if forced_fallback else slope
-    g = torch.Generator().manual_seed(33)
-    groups = n // gimg
-    y = G.rnd(torch.randn(n, cin, hin, hin, generator=g) * 1.5 + 0.3, prec)
-    aux = torch.zeros(groups, 4, cin)
-    aux[:, 0] = torch.rand(groups, cin, generator=g) + 0.5
-    aux[:, 1] = torch.randn(groups, cin, generator=g) * 0.5
-    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
-    wp = G.pack_up(w, prec) if kind == "up" else G.pack_down(w, prec)
-    y_d, aux_d = G.to_nhwc(y, prec), aux.cuda()
-    hout = hin * 2 if kind == "up" else hin // 2
-    fn_in = G.lib.jck_conv_up_in if kind == "up" else G.lib.jck_conv_down_in
-    fn_gr = G.lib.jck_conv_up_grouped if kind == "up" else G.lib.jck_conv_down_grouped
-    outs = []
-    for fused in (1, 0):
-        out = torch.empty(n, hout, hout, cout, dtype=torch.bfloat16, device="cuda")
-        stats, slots = G.stats_buf(n * hout * hout, cout)
-        stats.fill_(float("nan"))
-        a_buf = torch.full((n, hin, hin, cin), 7.0, dtype=torch.bfloat16, device="cuda")
-        if fused:
-            written = ctypes.c_int(-1)
-            G.lib.jck_tune(b"conv_in", 0 if forced_fallback else 1)
-            fn_in(prec, y_d, aux_d, gimg, slope, a_buf, ctypes.byref(written), wp, out, stats, ctypes.byref(slots), n, hin, hin, cin,
-                  cout, gimg, G.cur_stream())
-            G.lib.jck_tune(b"conv_in", 1)
-            torch.cuda.synchronize()
-            assert written.value == (1 if forced_fallback else 0), written.value      # every other shape here has the fused kernel
-            if written.value == 0:
-                assert float(a_buf.float().min()) == 7.0 and float(a_buf.float().max()) == 7.0     # never written
-        else:
-            G.lib.jck_bn_act_fwd_grouped(prec, y_d, aux_d, slope, a_buf, gimg * hin * hin, cin, groups, G.cur_stream())
-            fn_gr(prec, a_buf, wp, out, stats, ctypes.byref(slots), n, hin, hin, cin, cout, gimg, G.cur_stream())
-            torch.cuda.synchronize()
-        outs.append((out, stats[:slots.value * 2 * cout].clone(), slots.value, a_buf))
-    (o1, s1, n1, _), (o0, s0, n0, a0) = outs
-    assert n1 == n0 and torch.equal(o1.view(torch.int16), o0.view(torch.int16)), "fused output differs from the unfused pair"
-    assert torch.equal(s1.view(torch.int32), s0.view(torch.int32)), "statistic rows differ"
-    sc = aux[:, 0].repeat_interleave(gimg, 0)[:, :, None, None]
-    sh = aux[:, 1].repeat_interleave(gimg, 0)[:, :, None, None]
-    z = y * sc + sh
-    a = G.rnd(torch.where(z > 0, z, slope * z), prec)
-    G.check(G.from_nhwc(a0), a, 1e-2, "activation")
-    wr = G.rnd(w, prec)
-    ref = F.conv_transpose2d(a, wr, None, 2, 1) if kind == "up" else F.conv2d(a, wr, None, 2, 1)
-    G.check(G.from_nhwc(o1), ref, G.TOL[prec], "conv of the activation")
-
-
 # ---- BatchNorm statistics as exact integer-atomic sums (csrc/bnstat.hpp): the `_x` entry points -------------------------------
-def _bn_job(G, c, groups, gimg, **kw):
-    """jck_bn_job over a zeroed accumulator buffer; keeps the tensors it points at alive on the returned object."""
-    from hipgan._lib import BnJob
-    xbuf = torch.zeros(G.lib.jck_bnx_bytes(c, groups), dtype=torch.uint8, device="cuda")
-    j = BnJob()
-    j.xbuf, j.groups, j.group_images, j.eps, j.momentum = xbuf.data_ptr(), groups, gimg, 1e-5, 0.1
-    keep = [xbuf]
-    for k, v in kw.items():
-        if torch.is_tensor(v):
-            keep.append(v)
-            setattr(j, k, v.data_ptr())
-        else:
-            setattr(j, k, v)
-    j._keep = keep
-    return j
-
-
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("cfg", [("down", 4, 16, 128, 256, 2), ("up", 4, 8, 256, 128, 4), ("down", 6, 64, 3, 64, 2),
-                                 # the persistent kernels (128x256, 128x64, 64x128 tiles) and the one-tile kernels (128x128)
-                                 ("down", 96, 32, 64, 128, 32), ("up", 96, 16, 256, 128, 32), ("up", 48, 16, 128, 64, 16),
-                                 ("up", 64, 8, 256, 128, 64), ("down", 24, 64, 3, 64, 8)])
-def test_forward_statistics_as_exact_sums(G, prec, cfg):
-    """jck_conv_down_x / jck_conv_up_x accumulate sum y, sum y^2 per BatchNorm group while they write y; jck_bn_act_fwd_x
-    finalises them in its prologue and applies BatchNorm + (Leaky)ReLU - against F.batch_norm(training) per group, incl. the
-    aux table, the (mean, unbiased var) record and - one group - the running statistics."""
-    kind, n, hin, cin, cout, gimg = cfg
-    if prec == 1 and n > 8:
-        pytest.skip("large shapes exercise the bf16 persistent kernels")
-    slope = 0.2 if kind == "down" else 0.0
-    g = torch.Generator().manual_seed(31)
-    x = G.rnd(torch.randn(n, cin, hin, hin, generator=g), prec)
-    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
-    wr = G.rnd(w, prec)
-    gamma, beta = 1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)
-    y = F.conv_transpose2d(x, wr, None, 2, 1) if kind == "up" else F.conv2d(x, wr, None, 2, 1)
-    hout, groups = y.shape[-1], n // gimg
-    yr = G.rnd(y, prec)                                               # what the library stores and normalises
-    ref, means, ubs = [], [], []
-    for k in range(groups):
-        yy = y[k * gimg:(k + 1) * gimg]
-        m, v = yy.mean((0, 2, 3)), yy.var((0, 2, 3), unbiased=False)
-        z = (yr[k * gimg:(k + 1) * gimg] - m[None, :, None, None]) / torch.sqrt(v + 1e-5)[None, :, None, None] * gamma[None, :, None, None] + beta[None, :, None, None]
-        ref.append(F.leaky_relu(z, slope) if slope else F.relu(z))
-        means.append(m)
-        ubs.append(yy.var((0, 2, 3), unbiased=True))
-    ref = torch.cat(ref)
-    dt = G.DT[prec]
-    yd = torch.empty(n, hout, hout, cout, dtype=dt, device="cuda")
-    a = torch.empty_like(yd)
-    aux = torch.full((groups, 4 * cout), float("nan"), device="cuda")
-    rec = torch.full((groups, 2 * cout), float("nan"), device="cuda")
-    rm, rv, nbt = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
-    job = _bn_job(G, cout, groups, gimg, gamma=gamma.cuda(), beta=beta.cuda(), aux=aux, rec=rec,
-                  **(dict(running_mean=rm, running_var=rv, num_batches_tracked=nbt) if groups == 1 else {}))
-    if kind == "up":
-        G.lib.jck_conv_up_x(prec, G.to_nhwc(x, prec), G.pack_up(w, prec), yd, n, hin, hin, cin, cout, job, G.cur_stream())
-    else:
-        G.lib.jck_conv_down_x(prec, G.to_nhwc(x, prec), G.pack_down(w, prec), yd, n, hin, hin, cin, cout, job, G.cur_stream())
-    G.lib.jck_bn_act_fwd_x(prec, yd, slope, a, gimg * hout * hout, cout, job, G.cur_stream())
-    torch.cuda.synchronize()
-    G.check(G.from_nhwc(yd), y, G.TOL[prec], "conv")
-    G.check(G.from_nhwc(a), ref, 2e-5 if prec == 1 else 3e-2, "bn + act")
-    for k in range(groups):
-        G.check(aux[k, 2 * cout:3 * cout].cpu(), means[k], 1e-5 if prec == 1 else 2e-3, f"mean, group {k}")
-        G.check(rec[k, cout:].cpu(), ubs[k], 1e-5 if prec == 1 else 4e-3, f"unbiased var, group {k}")
-    if groups == 1:
-        G.check(rm.cpu(), 0.1 * means[0], 1e-5 if prec == 1 else 2e-3, "running mean")
-        assert int(nbt) == 1
-
-
-@pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("cfg", [("up", 4, 8, 256, 128, 2), ("up", 2, 16, 128, 64, 2), ("down", 4, 16, 128, 256, 4),
-                                 ("down", 4, 64, 3, 64, 2), ("up", 96, 16, 256, 128, 32), ("down", 96, 32, 64, 256, 32),
-                                 ("up", 48, 16, 128, 64, 16), ("up", 64, 16, 256, 128, 64)])
-def test_backward_statistics_as_exact_sums(G, prec, cfg):
-    """jck_conv_up_bnx / jck_conv_down_bnx (dgrad + sum g_z, sum g_z (y - mean) of the layer in front, exact sums) and
-    jck_bn_bwd_apply_x (finalises in its prologue: s1 | s2, dgamma, dbeta; writes g_y) against autograd through
-    batch_norm -> (leaky_)relu -> conv; jck_bn_bwd_reduce_x + the same apply for a gradient that came from elsewhere.  Two
-    runs give the same bits."""
-    kind, n, hin, cin, cout, gimg = cfg
-    if prec == 1 and n > 8:
-        pytest.skip("large shapes exercise the bf16 persistent kernels")
-    slope = 0.2 if kind == "up" else 0.0
-    g = torch.Generator().manual_seed(12)
-    groups = n // gimg
-    hout = 2 * hin if kind == "up" else hin // 2
-    y = G.rnd(torch.randn(n, cout, hout, hout, generator=g) * 1.3 + 0.2, prec).requires_grad_(True)
-    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
-    beta = (0.1 * torch.randn(cout, generator=g)).requires_grad_(True)
-    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.05 if kind == "up" else torch.randn(cout, cin, 4, 4, generator=g) * 0.05
-    wr = G.rnd(w, prec)
-    gin = G.rnd(torch.randn(n, cin, hin, hin, generator=g), prec)
-    ga = F.conv_transpose2d(gin, wr, None, 2, 1) if kind == "up" else F.conv2d(gin, wr, None, 2, 1)
-    parts = []
-    for k in range(groups):
-        bn = F.batch_norm(y[k * gimg:(k + 1) * gimg], None, None, gamma, beta, True, 0.1, 1e-5)
-        parts.append(F.leaky_relu(bn, slope) if slope else F.relu(bn))
-    torch.cat(parts).backward(ga)
-    yd = G.to_nhwc(y.detach(), prec)
-    c, rows = cout, gimg * hout * hout
-    aux = torch.empty(groups, 4 * c, device="cuda")
-    for k in range(groups):
-        yf = yd[k * gimg:(k + 1) * gimg].float().reshape(rows, c)
-        st = torch.stack([yf.sum(0), (yf ** 2).sum(0)]).contiguous()
-        G.lib.jck_bn_finalize(st, 1, float(rows), gamma.detach().cuda(), beta.detach().cuda(), None, None, None, 0.1, 1e-5,
-                              aux[k], c, G.cur_stream())
-    stride = G.lib.jck_bn_bwd_ws_floats(c)
-    results = []
-    for mode in ("fused", "fused", "reduce"):
-        out = torch.empty_like(yd)
-        sums = torch.full((groups * stride,), float("nan"), device="cuda")
-        dgam, dbet = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
-        job = _bn_job(G, c, groups, gimg, bn_y=yd, aux=aux, slope=slope, sums=sums, sums_stride=stride, dgamma=dgam, dbeta=dbet,
-                      grad_groups=groups)
-        if mode == "fused":
-            if kind == "up":
-                G.lib.jck_conv_up_bnx(prec, G.to_nhwc(gin, prec), G.pack_up(w, prec), out, n, hin, hin, cin, cout, job, G.cur_stream())
-            else:
-                G.lib.jck_conv_down_bnx(prec, G.to_nhwc(gin, prec), G.pack_down(w, prec), out, n, hin, hin, cin, cout, job, G.cur_stream())
-        else:
-            out = G.to_nhwc(ga, prec)
-            G.lib.jck_bn_bwd_reduce_x(prec, out, yd, rows, c, job, G.cur_stream())
-        gy = torch.empty_like(yd)
-        G.lib.jck_bn_bwd_apply_x(prec, out, yd, gy, rows, c, job, G.cur_stream())
-        torch.cuda.synchronize()
-        G.check(G.from_nhwc(out), ga, G.TOL[prec], f"dgrad ({mode})")
-        G.check(G.from_nhwc(gy), y.grad, 3e-5 if prec == 1 else 3e-2, f"dx ({mode})")
-        G.check(dgam.cpu(), gamma.grad, 3e-5 if prec == 1 else 1e-2, f"dgamma ({mode})")
-        G.check(dbet.cpu(), beta.grad, 3e-5 if prec == 1 else 1e-2, f"dbeta ({mode})")
-        results.append((gy.clone(), dgam.clone(), dbet.clone(), sums.view(groups, stride)[:, :2 * c].clone()))
-    for a_, b_ in zip(results[0], results[1]):                      # order-independent integer sums: the same bits
-        assert torch.equal(a_, b_)
