@@ -27,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, "jck-generation_amd")):
         sys.path.insert(0, p)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0              # same guide: HBM3E peak 8.0 TB/s (6.29 TB/s measured for a float4 copy)
 # algorithmic MACs per image: D forward, G forward and their pieces
 D_FWD, D_CONV1, G_FWD, G_CONV1 = 103_817_216, 3_145_728, 104_628_224, 819_200
 
@@ -58,9 +59,10 @@ def step_flops_per_image(dead_wgrad=False):
 # profiler variant label (csrc/ops.hip PROF_NAMES) -> substring of the kernel symbol rocprofv3 reports
 _SYMBOL = {"igemm<bf16,128,256>": "_kernel<128, 256,", "igemm<bf16,128,128>": "igemm_dma_kernel<128, 128,",
            "igemm<bf16,128,64>": "_kernel<128, 64,", "igemm<bf16,64,128>": "_kernel<64, 128,",      # igemm_dma_kernel / igemm_dma_persist_kernel
-           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>", "wgrad_halo<bf16,64,512>": "wgrad_halo_kernel<",
+           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>",
            "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2>",
-           "wgrad<bf16,64,64,img>": "wgrad_kernel<PrecBf16, 64, 64, 2>", "img_down<bf16>": "img_down_kernel", "img_up<bf16>": "img_up_kernel"}
+           "wgrad<bf16,64,64,img>": "wgrad_kernel<PrecBf16, 64, 64, 2>", "img_down<bf16>": "img_down_kernel", "img_up<bf16>": "img_up_kernel",
+           "bn_act_fwd": "bn_act_fwd_kernel<", "bn_bwd_resident": "bn_bwd_res_kernel<"}
 
 
 def pmc_traffic(kernel):
@@ -319,34 +321,56 @@ def measure(a, model, world, rank, dev, dist):
     if rank == 0 and not a.no_roofline:
         import ctypes as C
         lib.jck_prof_enable(0)
-        cap = 32
+        cap = 40
         names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
-        n = lib.jck_prof_collect(cap, names, cnt, msv, flv)
-        rows = [{"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i],
-                 "ms_per_step": msv[i] / 3, "tflops": flv[i] / (msv[i] * 1e-3) / 1e12} for i in range(n)]
+        byv, stv = (C.c_double * cap)(), (C.c_void_p * cap)()
+        n = lib.jck_prof_collect(cap, names, cnt, msv, flv, byv, stv)
+        main_stream = torch.cuda.current_stream().cuda_stream
+        rows = []
+        for i in range(n):
+            r = {"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i], "ms_per_step": msv[i] / 3,
+                 # the HIP stream the launches were issued on, from the launch records themselves: the engine's
+                 # second stream carries the weight-gradient products beside the dgrad / BatchNorm chain
+                 "stream": "main" if (stv[i] or 0) == main_stream else ("main + side" if (stv[i] or 0) == 2 ** 64 - 1 else "side (beside the main stream)")}
+            if byv[i] > 0:
+                r["bound"], r["gbs"] = "hbm", byv[i] / (msv[i] * 1e-3) / 1e9
+            else:
+                r["bound"], r["tflops"] = "mfma", flv[i] / (msv[i] * 1e-3) / 1e12
+            rows.append(r)
         rows.sort(key=lambda r: -r["ms_per_step"])
-        # The weight-gradient products run on the engine's second HIP stream BESIDE the dgrad / BatchNorm chain (these eager steps
-        # always have it unless JCK_WGRAD_SIDE / JCK_CGAN_SIDE = 0): their launch durations are those of a kernel sharing the chip,
-        # and they are off the step's critical path.  The dominant kernel is the largest one ON the critical (main) stream; the
-        # weight-gradient rows stay in `kernels` with their stream named.
-        side_on = os.environ.get("JCK_WGRAD_SIDE", "1") != "0" and not (model == "cgan" and os.environ.get("JCK_CGAN_SIDE", "1") == "0")
-        for r in rows:
-            r["stream"] = "side (beside the main stream)" if side_on and r["kernel"].startswith("wgrad") else "main"
-        crit = [r for r in rows if r["stream"] == "main"] or rows
-        if rows:
-            d = crit[0]
+        method = "HIP events around every launch on the stream it is launched on, 3 extra (eagerly launched) steps after the timed region"
+
+        def mfma_obj(d, selection):
             tr = pmc_traffic(d["kernel"])
-            res["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2),
-                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                               "traffic": (tr or {}).get("bytes_per_launch"),      # HBM bytes per launch (PMC)
-                               "traffic_detail": tr, "avg_launch_ms": round(d["avg_ms"], 5),
-                               "launches_per_step": d["launches_per_step"],
-                               "selection": "largest ms/step among the MFMA kernels of the step's critical (main) stream; the weight "
-                                            "gradients overlap it on the second stream (kernels[].stream)",
-                               "method": "HIP events around every launch on the launch stream, 3 extra (eagerly launched) steps "
-                                         "after the timed region"}
+            return {"bound": "mfma", "kernel": d["kernel"], "achieved": round(d["tflops"], 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,      # HBM bytes per launch (PMC)
+                    "avg_launch_ms": round(d["avg_ms"], 5), "launches_per_step": d["launches_per_step"], "ms_per_step": round(d["ms_per_step"], 5),
+                    "stream": d["stream"], "selection": selection, "method": method}
+        mf = [r for r in rows if r["bound"] == "mfma"]
+        hb = [r for r in rows if r["bound"] == "hbm"]
+        if mf:
+            # (1) the kernel with the largest total time in the step, whatever stream it runs on; (2) the largest one on the
+            # step's critical (main) stream - the weight gradients overlap that chain on the second stream, so their launch
+            # durations are those of a kernel sharing the chip; (3) the largest HBM-bound kernel (the BatchNorm side of the step)
+            res["roofline"] = mfma_obj(mf[0], "largest total time per step among the MFMA kernels, any stream")
+            crit = [r for r in mf if r["stream"] == "main"] or mf
+            res["roofline_critical"] = mfma_obj(crit[0], "largest total time per step among the MFMA kernels launched on the step's main stream")
+        if hb:
+            d = hb[0]
+            tr = pmc_traffic(d["kernel"])
+            res["roofline_hbm"] = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(d["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(d["gbs"] / HBM_PEAK_GBS, 4), "traffic": (tr or {}).get("bytes_per_launch"), "traffic_detail": tr,
+                                   "algorithmic_bytes_per_launch": round(d["gbs"] * 1e9 * d["avg_ms"] * 1e-3),
+                                   "avg_launch_ms": round(d["avg_ms"], 5), "launches_per_step": d["launches_per_step"],
+                                   "ms_per_step": round(d["ms_per_step"], 5), "stream": d["stream"],
+                                   "selection": "largest total time per step among the streaming BatchNorm kernels; algorithmic bytes = "
+                                                "forward: read y + write a; backward: read g_a and y + write g_y",
+                                   "method": method}
+        if rows:
             res["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
-            res["mfma_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in rows), 4)
+            res["mfma_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in mf), 4)
+            res["bn_kernels_ms_per_step"] = round(sum(r["ms_per_step"] for r in hb), 4)
     del eng
     torch.cuda.empty_cache()
     return res

@@ -369,7 +369,8 @@ int jck_tune(const char* key, int value);
 /* per-launch HIP-event timing of the MFMA kernels (bench.py roofline leg).  enable(1) ... run ... collect():
  * per kernel variant: launches, total milliseconds, total algorithmic FLOPs.  Returns the number of rows. */
 int jck_prof_enable(int on);
-int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out);
+int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out, double* bytes_out,
+                     void** stream_out);
 
 /* debug probe: lane l of one wave returns the 8 elements wgrad's transposed LDS read hands it from a
  * [32][ld] 16-bit tile: out[l*8+j] must equal in[(8*(l>>4)+j)*ld + (l&15)] */

@@ -33,6 +33,7 @@ static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neu
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);
+static int g_bn_res_mb = env_int("JCK_BN_RES_MB", 120);         // multi-group passes: resident form above this many MB of (g_a, y)
 static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
@@ -42,7 +43,7 @@ static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
 static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}};
@@ -74,7 +75,8 @@ extern "C" int jck_tune(const char* key, int value) {
 // ---------------------------------------------------------------------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { int variant; double flops; hipEvent_t e0, e1; };
+// a launch is priced in algorithmic FLOPs (MFMA kernels) or algorithmic bytes (the streaming BatchNorm kernels: bytes > 0)
+struct ProfRec { int variant; double flops, bytes; hipStream_t st; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "igemm<bf16,64,128,img>", "igemm<bf16,64,128>",
@@ -82,12 +84,16 @@ const char* const PROF_NAMES[] = {"igemm<bf16,128,128>", "igemm<bf16,128,64>", "
                                   "igemm<f32,64,128>",   "igemm<f32,16,256>",  "wgrad<bf16,128,128>",    "wgrad<bf16,128,64>",
                                   "wgrad<bf16,64,64,img>", "wgrad<bf16,64,64>", "wgrad<f32,128,128>",    "wgrad<f32,128,64>",
                                   "wgrad<f32,64,64,img>", "wgrad<f32,64,64>",  "img_down<bf16>",         "img_up<bf16>",
-                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>"};
+                                  "igemm<bf16,128,256>",  "wgrad<bf16,256,128>", "bn_act_fwd",           "bn_bwd_resident",
+                                  "bn_bwd_3launch"};
+#define PROF_BN_ACT_FWD 22
+#define PROF_BN_BWD_RES 23
+#define PROF_BN_BWD_3L 24
 struct ProfScope {
   ProfRec r; bool on; hipStream_t st;
-  ProfScope(int variant, double flops, hipStream_t s) : on(g_prof_on), st(s) {
+  ProfScope(int variant, double flops, hipStream_t s, double bytes = 0.0) : on(g_prof_on), st(s) {
     if (!on) return;
-    r.variant = variant; r.flops = flops;
+    r.variant = variant; r.flops = flops; r.bytes = bytes; r.st = s;
     (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e0, st);
   }
@@ -103,22 +109,34 @@ extern "C" int jck_prof_enable(int on) {
   g_prof_on = on != 0;
   return JCK_OK;
 }
-// Synchronises the recorded events, accumulates per kernel variant: count, total ms, total algorithmic FLOPs.
-// Returns the number of variants written (<= cap).  name_out[i] points at a static string.
-extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out) {
+// Synchronises the recorded events, accumulates per kernel variant: count, total ms, total algorithmic FLOPs, total algorithmic
+// bytes (streaming kernels) and the HIP stream the launches ran on (all ones when a variant ran on several).  Returns the number of
+// variants written (<= cap).  name_out[i] points at a static string.
+extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out, double* bytes_out,
+                                void** stream_out) {
   constexpr int NV = sizeof(PROF_NAMES) / sizeof(PROF_NAMES[0]);
-  int cnt[NV] = {0}; double ms[NV] = {0}, fl[NV] = {0};
+  int cnt[NV] = {0}; double ms[NV] = {0}, fl[NV] = {0}, by[NV] = {0};
+  hipStream_t sv[NV] = {nullptr}; bool mixed[NV] = {false};
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.e1);
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.e0, r.e1);
-    if (r.variant >= 0 && r.variant < NV) { cnt[r.variant]++; ms[r.variant] += t; fl[r.variant] += r.flops; }
+    if (r.variant >= 0 && r.variant < NV) {
+      const int v = r.variant;
+      if (cnt[v] == 0) sv[v] = r.st; else if (sv[v] != r.st) mixed[v] = true;
+      cnt[v]++; ms[v] += t; fl[v] += r.flops; by[v] += r.bytes;
+    }
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
   int n = 0;
   for (int v = 0; v < NV && n < cap; ++v)
-    if (cnt[v]) { name_out[n] = PROF_NAMES[v]; count_out[n] = cnt[v]; ms_out[n] = ms[v]; flops_out[n] = fl[v]; ++n; }
+    if (cnt[v]) {
+      name_out[n] = PROF_NAMES[v]; count_out[n] = cnt[v]; ms_out[n] = ms[v]; flops_out[n] = fl[v];
+      if (bytes_out) bytes_out[n] = by[v];
+      if (stream_out) stream_out[n] = mixed[v] ? (void*)~(uintptr_t)0 : (void*)sv[v];      // all ones: several streams
+      ++n;
+    }
   return n;
 }
 
@@ -661,6 +679,7 @@ extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float s
                               void* stream) {
   if (!is_pow2(C) || C < 8) JCK_FAIL(JCK_E_ARG, "bn_act_fwd: C must be a power of two >= 8");
   const long long total8 = rows * C / 8;
+  ProfScope prof(PROF_BN_ACT_FWD, 0.0, (hipStream_t)stream, 2.0 * rows * C * (prec == JCK_PREC_F32 ? 4 : 2));
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8)), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)y, aux, slope, (T*)a, total8, C));
   HIPCHK(hipGetLastError());
@@ -699,6 +718,7 @@ extern "C" int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux,
                                       int C, int groups, void* stream) {
   if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_act_fwd_grouped: C must be a power of two >= 8");
   const long long total8 = rows_per_group * C / 8;
+  ProfScope prof(PROF_BN_ACT_FWD, 0.0, (hipStream_t)stream, 2.0 * groups * rows_per_group * C * (prec == JCK_PREC_F32 ? 4 : 2));
   DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
                                       (const T*)y, aux, slope, (T*)a, total8, C));
   HIPCHK(hipGetLastError());
@@ -717,6 +737,8 @@ static int bn_act_bwd_grouped_ev(int prec, const void* g_a, const void* y, const
   const long long rows = rows_per_group;
   const int rstep = 256 / (C / 8);
   if (rstep < 1) JCK_FAIL(JCK_E_ARG, "bn_act_bwd_grouped: C too large");
+  // algorithmic bytes of the backward: read g_a and y once, write g_y (what the resident form moves; this form reads twice)
+  ProfScope prof(PROF_BN_BWD_3L, 0.0, (hipStream_t)stream, 3.0 * groups * rows * C * (prec == JCK_PREC_F32 ? 4 : 2));
   const int blocks = bn_bwd_blocks(rows, rstep, groups);
   const long long gstride = (long long)jck_bn_bwd_ws_floats(C);
   float* partial = sums + 2 * C;
@@ -763,8 +785,8 @@ static int bnres_plan(int prec, long long rows, int C, int groups, int* nb_out, 
   // Several groups in one pass (the batched D pass): the three-launch form's second read of (g_a, y) comes out of the
   // Infinity Cache while all groups fit it, and then it is as fast or faster in the step (measured, DESIGN.md section 5.3:
   // D.conv2's layer at 3 x 256 images 60 vs 70 us alone, the step 1.744 vs 1.733 ms); the resident form wins where they do not
-  // fit (D.conv1's layer: 3 x 2 x 33.5 MB).  bn_res = 2 takes the resident form whenever it fits the registers.
-  if (g_bn_res == 1 && groups > 1 && (long long)groups * rows * C * 4 <= (160ll << 20)) return 0;
+  // fit (D.conv1's layer: 3 x 2 x 33.5 MB, or 2 x 2 x 33.5 MB for its loss groups alone).  bn_res = 2 takes the resident form whenever it fits the registers.
+  if (g_bn_res == 1 && groups > 1 && (long long)groups * rows * C * 4 <= ((long long)g_bn_res_mb << 20)) return 0;
   const int nsl = C / 64;
   int nb = std::min(bnres_cus(), 256);
   nb -= nb % std::max(nsl, 8);
@@ -795,6 +817,7 @@ int bn_act_bwd_res_ev(int prec, const void* g_a, const void* y, const float* aux
   p.rows = rows_per_group; p.C = C; p.groups = groups; p.grad_groups = grad_groups; p.nb = nb; p.nsl = nsl;
   p.slope = slope; p.inv_count = 1.0f / (float)rows_per_group;
   const dim3 grid(nb), block(BNRES_THREADS);
+  ProfScope prof(PROF_BN_BWD_RES, 0.0, stream, 3.0 * groups * rows_per_group * C * 2);
   // groups resident together (one barrier for all of them) while their chunks fit the register file
   const int ng = (groups >= 3 && 3 * nch <= 16) ? 3 : (groups >= 2 && 2 * nch <= 16) ? 2 : 1;
 #define BNRES_CASE(NCH_, NG_) case NCH_ * 4 + NG_: LAUNCH_EV((bn_bwd_res_kernel<NCH_, NG_>), grid, block, 0, stream, done, p); break

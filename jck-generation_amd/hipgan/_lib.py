@@ -129,7 +129,7 @@ PROTOS = {
     "jck_graph_launch": (i32, [vp, vp]),
     "jck_graph_destroy": (None, [vp]),
     "jck_prof_enable": (i32, [i32]),
-    "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64)]),
+    "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(vp)]),
 }
 
 
