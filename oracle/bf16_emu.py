@@ -16,8 +16,17 @@ places where the HIP path stores a tensor in bf16:
 
 `tests/test_bf16_envelope.py` uses it two ways: (1) the HIP bf16 step must agree with THIS restatement much more
 closely than with the fp32 oracle (what is left is summation order), and (2) the distance emulation <-> fp32 oracle is the
-envelope for the distance HIP <-> fp32 oracle, per step and along a free-running trajectory.  DCGAN only: the CGAN penalty
-is a double backward, which custom autograd Functions with rounding do not reproduce.
+envelope for the distance HIP <-> fp32 oracle, per step and along a free-running trajectory.
+
+CGAN (round 4; model/CGAN.py:109-123,151-162, train/cgan_trainer.py:200-203): its penalty is BACK-PROPAGATED - a double backward
+through conv, train-mode BatchNorm, LeakyReLU, Linear, Dropout, Sigmoid - which custom Functions with a hand-written first
+backward do not reproduce.  The CGAN nets below are therefore written with plain differentiable ops and two primitives that stay
+differentiable to any order: st(x) (forward value bf16(x), gradient the identity: straight-through rounding) for a tensor that is
+STORED in bf16, and grad_st(x) (identity forward, st() applied to the gradient) for a tensor whose GRADIENT is stored in bf16.
+The forward and first-backward storage points are those of the HIP path (conv outputs, activations, dgrad / BatchNorm-backward
+outputs, the concat / hidden / dropped rows of the label head and their gradients, the three images and the penalty's image
+gradient); the intermediates of the penalty's second-order sweep (the v-chain of csrc/engine.hip gp_double_backward, bf16 in
+HBM on the device) are left in fp32 here - an envelope for the storage format, not a bit-level restatement of that sweep.
 """
 from __future__ import annotations
 
@@ -146,3 +155,87 @@ def discriminator_bf16(p, x, labels=None, drop_mask=None, drop_p=0.25):
         h = _bn_act(p, f"norm{i}", h, LRELU)
     # head: fp32 weights on the bf16 a4; the gradient w.r.t. a4 is rounded by _BnAct.backward of the last layer
     return torch.sigmoid(F.conv2d(h, p[f"conv{n + 1}.weight"], None, 1, 0))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# CGAN: the same storage points with primitives that autograd can differentiate twice (the back-propagated penalty)
+# ------------------------------------------------------------------------------------------------------------------------------
+def st(x: torch.Tensor) -> torch.Tensor:
+    """straight-through rounding: the value stored in bf16, the gradient passed through unchanged - differentiable to any order"""
+    return x + (bf(x) - x).detach()
+
+
+class _GradSt(Function):
+    """identity whose gradient is stored in bf16 (st() on the way back, so a second backward differentiates through it)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return st(g)
+
+
+def grad_st(x):
+    return _GradSt.apply(x)
+
+
+def store_dd(x):
+    """an image-side tensor kept in bf16 together with its gradient (real_noisy / fake / x_hat), twice differentiable"""
+    return grad_st(st(x))
+
+
+def _bn_act_dd(p, name, y_acc, slope, update_stats=True):
+    """_BnAct with plain ops: statistics from the fp32 accumulators, y and a stored bf16, g_a and g_y stored bf16"""
+    y_in = grad_st(y_acc)                                       # g_y (BatchNorm backward output) is stored in bf16
+    n = y_in.numel() // y_in.shape[1]
+    yd = y_in.double()
+    mean_d = yd.mean((0, 2, 3))
+    var_d = ((yd * yd).mean((0, 2, 3)) - mean_d * mean_d).clamp_min(0.0)
+    mean, var = mean_d.float(), var_d.float()
+    invstd = 1.0 / torch.sqrt(var + BN_EPS)
+    sc = p[f"{name}.weight"] * invstd
+    sh = p[f"{name}.bias"] - mean * sc
+    z = st(y_in) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    a = grad_st(st(torch.where(z > 0, z, slope * z)))           # a stored bf16; g_a (the dgrad output) stored bf16
+    if update_stats:
+        with torch.no_grad():
+            p[f"{name}.num_batches_tracked"] += 1
+            p[f"{name}.running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean.detach())
+            p[f"{name}.running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * (var * (n / max(n - 1.0, 1.0))).detach())
+    return a
+
+
+def generator_cgan_bf16(p, z, labels=None):
+    """model/CGAN.py:151-162: [z | one-hot] written in bf16 into the operand rows of conv1 (cgan_z_kernel), then the DCGAN stack"""
+    assert labels is not None
+    n = _n_norm(p)
+    h = st(torch.cat([z, labels.reshape(-1, 100, 1, 1).float()], 1))
+    h = F.conv_transpose2d(h, st(p["conv1.weight"]), None, 1, 0)
+    h = _bn_act_dd(p, "norm1", h, 0.0)
+    for i in range(2, n + 1):
+        h = F.conv_transpose2d(h, st(p[f"conv{i}.weight"]), None, 2, 1)
+        h = _bn_act_dd(p, f"norm{i}", h, 0.0)
+    acc = grad_st(F.conv_transpose2d(h, st(p[f"conv{n + 1}.weight"]), None, 2, 1))      # tanh backward's output is stored bf16
+    return st(torch.tanh(acc))                                                         # fake_raw stored bf16
+
+
+def discriminator_cgan_bf16(p, x, labels=None, drop_mask=None, drop_p=0.25):
+    """model/CGAN.py:109-123 with the engine's storage (csrc/engine.hip cg_head_forward / d_head_backward): conv stack as DCGAN;
+    the label embedding is computed in fp32 and stored bf16 beside flatten(a4) in the concat rows; Linear(8392, 256) on packed
+    bf16 weights with fp32 accumulation, its output and the dropped rows stored bf16 (linear_finish_kernel: both from the fp32
+    sum); Linear(256, 1) + sigmoid on fp32 weights; the gradients of the dropped rows, the hidden rows and the concat rows are
+    stored bf16.  x must already be a stored image (store_dd)."""
+    assert labels is not None and drop_mask is not None
+    n = _n_norm(p)
+    h = x
+    for i in range(1, n + 1):
+        h = F.conv2d(h, st(p[f"conv{i}.weight"]), None, 2, 1)
+        h = _bn_act_dd(p, f"norm{i}", h, LRELU)
+    e = F.leaky_relu(F.linear(labels.float(), p["label_embedding.weight"], p["label_embedding.bias"]), LRELU)
+    con = grad_st(torch.cat([h.flatten(1), st(e)], 1))
+    s = F.linear(con, st(p["linear1.weight"]), p["linear1.bias"])
+    s = grad_st(s)                                              # g_h stored bf16
+    hd = grad_st(st(s * drop_mask / (1.0 - drop_p)))            # h_drop stored bf16 (from the fp32 sum); g_hd stored bf16
+    return torch.sigmoid(F.linear(hd, p["linear2.weight"], p["linear2.bias"]))

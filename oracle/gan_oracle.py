@@ -174,12 +174,15 @@ def bce(prob, target: float):
     return F.binary_cross_entropy(prob, torch.full_like(prob, target))
 
 
-def gradient_penalty(d_state, real, fake, alpha, labels=None, drop_mask=None, create_graph=True, disc=None, store=None):
-    """train/dcgan_trainer.py:110-127.  disc / store: the bf16-storage emulation's net and rounding (oracle/bf16_emu.py)."""
+def gradient_penalty(d_state, real, fake, alpha, labels=None, drop_mask=None, create_graph=True, disc=None, store=None, grad_store=None):
+    """train/dcgan_trainer.py:110-127.  disc / store / grad_store: the bf16-storage emulation's net, its rounding of the
+    interpolated image and of the image gradient the norm is taken of (oracle/bf16_emu.py)."""
     inter = alpha * real + ((1 - alpha) * fake)
     inter = (store(inter) if store is not None else inter).requires_grad_(True)
     di = (disc or discriminator)(d_state, inter, labels, drop_mask)
     grads = torch.autograd.grad(di, inter, torch.ones_like(di), create_graph=create_graph, retain_graph=True)[0]
+    if grad_store is not None:
+        grads = grad_store(grads)
     grads = grads.view(grads.size(0), -1)
     return ((grads.norm(2, dim=1) - 1) ** 2).mean()
 
@@ -219,12 +222,16 @@ class GanOracle:
 
     def __init__(self, family="dcgan", lr=2e-4, seed: Optional[int] = 12345, skip_dead_wgrad=False, emulate_bf16=False,
                  image_size=64):
-        """emulate_bf16: round to bf16 wherever the HIP fast path stores a tensor in bf16 (oracle/bf16_emu.py; DCGAN only) -
+        """emulate_bf16: round to bf16 wherever the HIP fast path stores a tensor in bf16 (oracle/bf16_emu.py) -
         the envelope for the fast path's distance from this fp32 restatement.  Default off = the pinned oracle."""
         assert family in ("dcgan", "cgan")
-        assert not (emulate_bf16 and family != "dcgan"), "the bf16 emulation covers DCGAN only"
         self.emu = emulate_bf16
-        if emulate_bf16:
+        self._grad_store = None
+        if emulate_bf16 and family == "cgan":       # twice-differentiable restatement: the penalty is back-propagated
+            from . import bf16_emu
+            self._gen, self._disc, self._store = bf16_emu.generator_cgan_bf16, bf16_emu.discriminator_cgan_bf16, bf16_emu.store_dd
+            self._grad_store = bf16_emu.st          # the penalty's image gradient is stored in bf16 before its norm is taken
+        elif emulate_bf16:
             from . import bf16_emu
             self._gen, self._disc, self._store = bf16_emu.generator_bf16, bf16_emu.discriminator_bf16, bf16_emu.store
         else:
@@ -293,7 +300,8 @@ class GanOracle:
             gp = gradient_penalty(self.d, real, fake, alpha, create_graph=not self.emu, disc=self._disc, store=self._store).detach()
         else:
             # train/cgan_trainer.py:200-203: one backward over real + fake + 10*GP (double backward).
-            gp = gradient_penalty(self.d, real.detach(), fake.detach(), alpha, labels, mask("m3"))
+            gp = gradient_penalty(self.d, real.detach(), fake.detach(), alpha, labels, mask("m3"), disc=self._disc, store=self._store,
+                                  grad_store=self._grad_store)
             dg = torch.autograd.grad(e_real + e_fake + LAMBDA_GP * gp, dpl)
             gp = gp.detach()
         e_d = (e_real + e_fake).detach() + LAMBDA_GP * gp

@@ -6,7 +6,7 @@ on every run and every MI355X: the recorded numbers reproduce exactly and the 2x
 
 Three runs of one step from IDENTICAL state (weights, Adam moments, BN statistics, batch, noise):
     ref  fp32 CPU oracle (oracle/gan_oracle.py, pinned to the reference)
-    emu  the same oracle with bf16 rounding wherever the HIP path stores bf16 (oracle/bf16_emu.py; DCGAN only)
+    emu  the same oracle with bf16 rounding wherever the HIP path stores bf16 (oracle/bf16_emu.py)
     hip  the engine, JCK_PREC_BF16
 and three distances per gradient tensor (relative L2) and per logged scalar (relative):
     hip_vs_ref   what the fast path costs in accuracy            (asserted <= 2x table)
@@ -72,7 +72,7 @@ def measure(family, B, steps=2, lr=2e-4, with_emu=True, size=64):
     from oracle.gan_oracle import GanOracle
     from util import synth_images
     ref = GanOracle(family, lr=lr, seed=12345, image_size=size)
-    emu = GanOracle(family, lr=lr, seed=12345, emulate_bf16=True, image_size=size) if (with_emu and family == "dcgan") else None
+    emu = GanOracle(family, lr=lr, seed=12345, emulate_bf16=True, image_size=size) if with_emu else None
     eng = (CganEngine if family == "cgan" else DcganEngine)(batch=B, prec="bf16", **({"image_size": size} if size != 64 else {}))
     imgs = synth_images(B * steps) if size == 64 else torch.nn.functional.interpolate(synth_images(B * steps), size=size, mode="nearest")
     out = []

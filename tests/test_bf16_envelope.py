@@ -6,7 +6,7 @@
       matched, what is left is summation order amplified by bf16 rounding-boundary flips (a 1e-6 relative perturbation of the
       EMULATION's own conv outputs moves its D gradients by ~2e-2, measured with the CPU oracle alone, DESIGN.md section 2);
     - hip vs ref <= 1.25 x emu vs ref per tensor: the fast path's distance from the reference IS the storage format's;
-    - CGAN (no emulation of its double backward): hip vs ref against stated limits.
+    - CGAN goes through the same gates: its emulation differentiates twice through the rounding (round 4).
   (Round 2 gated every tensor at 2x a table recorded from the HIP path - a regression gate, not parity; the table is still
   produced by tests/golden/make_bf16_error_table.py as a report, profiles/r03_bf16_error_table.md, and gates nothing.)
 * envelope along a 30-step free-running trajectory: within 2x the emulation's own divergence from the fp32 oracle;
@@ -18,39 +18,37 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("dcgan", 8, 2), ("dcgan", 64, 2), ("dcgan", 256, 1), ("cgan", 8, 2), ("cgan", 64, 2), ("cgan", 256, 1)]
 FLOOR = {"scalars": 2e-4, "d_grads": 1e-3, "g_grads": 1e-3}      # absolute slack under which a distance is rounding noise
-# hip vs emu (DCGAN): relative L2 per gradient tensor / relative per scalar.  The flips thin out as the batch grows.
+# hip vs emu (both families): relative L2 per gradient tensor / relative per scalar.  The flips thin out as the batch grows.
 LIM_EMU = {8: {"d_grads": 0.11, "g_grads": 0.16, "scalars": 3.0e-2},
            64: {"d_grads": 0.08, "g_grads": 0.14, "scalars": 2.0e-2},
            256: {"d_grads": 0.05, "g_grads": 0.12, "scalars": 5.0e-3}}
-# hip vs ref (CGAN, whose penalty is back-propagated: no storage emulation of the double backward exists)
-LIM_REF_CGAN = {8: {"d_grads": 0.16, "g_grads": 0.26, "scalars": 3.0e-2},
-                64: {"d_grads": 0.12, "g_grads": 0.22, "scalars": 2.0e-2},
-                256: {"d_grads": 0.08, "g_grads": 0.20, "scalars": 1.0e-2}}
 
 
 @pytest.mark.parametrize("family,B,steps", CASES)
 def test_bf16_step_against_the_storage_emulation(family, B, steps):
+    """Both families (round 4: the CGAN emulation is written with twice-differentiable rounding primitives, so its back-propagated
+    penalty goes through the same storage points - oracle/bf16_emu.py; round 3 held CGAN's gradients to limits recorded from the
+    HIP path itself)."""
     import bf16_error as be
     rows = be.measure(family, B, steps)
     bad = []
-    metric, lim = ("hip_vs_emu", LIM_EMU[B]) if family == "dcgan" else ("hip_vs_ref", LIM_REF_CGAN[B])
+    lim = LIM_EMU[B]
     for group in ("scalars", "d_grads", "g_grads"):
         for k in rows[0][group]:
-            got = max(r[group][k][metric] for r in rows)
+            got = max(r[group][k]["hip_vs_emu"] for r in rows)
             if not got <= lim[group] + FLOOR[group]:
-                bad.append(f"{group}:{k}:{metric}: {got:.3e} > {lim[group]:.3e}")
+                bad.append(f"{group}:{k}:hip_vs_emu: {got:.3e} > {lim[group]:.3e}")
     assert not bad, "\n".join(bad)
-    if family == "dcgan":
-        # the storage format explains the distance from the fp32 oracle: tensor by tensor hip is no further from it than the
-        # emulation is (measured: equal within a few %), and with the format matched hip and the emulation are closer to each
-        # other than either is to the fp32 oracle
-        for group in ("d_grads", "g_grads"):
-            for k in rows[0][group]:
-                h = max(r[group][k]["hip_vs_ref"] for r in rows)
-                e = max(r[group][k]["emu_vs_ref"] for r in rows)
-                assert h <= 1.25 * e + FLOOR[group], (group, k, h, e)
-        for group in ("d_grads", "g_grads"):
-            assert be.worst(rows, group, "hip_vs_emu") <= 0.75 * be.worst(rows, group, "hip_vs_ref") + FLOOR[group], group
+    # the storage format explains the distance from the fp32 oracle: tensor by tensor hip is no further from it than the
+    # emulation is (measured: equal within a few %), and with the format matched hip and the emulation are closer to each
+    # other than either is to the fp32 oracle
+    for group in ("d_grads", "g_grads"):
+        for k in rows[0][group]:
+            h = max(r[group][k]["hip_vs_ref"] for r in rows)
+            e = max(r[group][k]["emu_vs_ref"] for r in rows)
+            assert h <= 1.25 * e + FLOOR[group], (group, k, h, e)
+    for group in ("d_grads", "g_grads"):
+        assert be.worst(rows, group, "hip_vs_emu") <= 0.75 * be.worst(rows, group, "hip_vs_ref") + FLOOR[group], group
 
 
 @pytest.mark.parametrize("family,prec,B", [("dcgan", "bf16", 16), ("dcgan", "f32", 16), ("dcgan", "bf16", 256), ("cgan", "bf16", 16),
