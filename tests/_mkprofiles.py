@@ -44,7 +44,7 @@ def cgan_summary(tag):
 
     def part(keys):
         return sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys)) / n / 1e6
-    gemm = part(("igemm", "wgrad_dma", "wgrad_halo", "wgrad_kernel", "img_down", "img_up"))
+    gemm = part(("igemm", "wgrad_dma", "wgrad_kernel", "img_down", "img_up"))
     bn = part(("bn_", "bn2_"))
     md = [f"# CGAN bench (eager launches, two HIP streams: the default), rocprofv3 --kernel-trace --stats, {n} traced steps ({tag})", "",
           f"Sum of kernel durations {tot:.3f} ms/step over {calls:.0f} launches/step: GEMM-shaped {gemm:.2f}, BatchNorm {bn:.2f}, "
@@ -86,6 +86,14 @@ def main():
           f"HIP stream beside the dgrad chain, so the sum can exceed the wall time); the profiled run itself reported "
           f"{prof_bench['ms_per_step']} ms/step, the un-profiled bench is in `profiles/{tag}_bench.json`.", "",
           "| ms/step | launches/step | avg us | kernel |", "|---|---|---|---|"]
+
+    def part(keys):
+        return sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys)) / nsteps / 1e6
+    md.insert(3, f"By class (ms/step): gather-GEMMs {part(('igemm',)):.3f}, weight gradients {part(('wgrad',)):.3f} (second stream), "
+                 f"BatchNorm backward {part(('bn_bwd',)):.3f} (resident form {part(('bn_bwd_res',)):.3f}), BatchNorm forward "
+                 f"{part(('bn_act_fwd', 'bn_finalize')):.3f}, image-side convs {part(('img_down', 'img_up')):.3f}; "
+                 f"{sum(int(r['Calls']) for r in rows) / nsteps:.0f} launches/step.")
+    md.insert(4, "")
     for r in rows[:40]:
         n, t = int(r["Calls"]), float(r["TotalDurationNs"])
         md.append(f"| {t / nsteps / 1e6:.4f} | {n / nsteps:.1f} | {t / n / 1e3:.2f} | `{r['Name'][:100]}` |")
@@ -99,7 +107,7 @@ def main():
     md += ["", "## SQ counters, averages per launch", "",
            "| kernel | " + " | ".join(c.replace("SQ_", "") for c in cols + cols2) + " |", "|" + "---|" * (len(cols + cols2) + 1)]
     for k in sq:
-        if not any(s in k for s in ("igemm", "wgrad", "img_")):
+        if not any(s in k for s in ("igemm", "wgrad", "img_", "bn_")):
             continue
         vals = [sq[k].get(c, []) for c in cols] + [mf.get(k, {}).get(c, []) for c in cols2]
         md.append(f"| `{k}` | " + " | ".join(f"{sum(v) / len(v):.3g}" if v else "-" for v in vals) + " |")
