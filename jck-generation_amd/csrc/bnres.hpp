@@ -128,8 +128,9 @@ __global__ __launch_bounds__(BNRES_THREADS) void bn_bwd_res_kernel(const BnResPa
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         const unsigned off = bnres_off(voff0, kstep, k, gbytes);
-        vg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0);
-        vy[j][k] = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0);
+        // (g_a, y) are read exactly once - y is dead after this pass, g_a is overwritten by g_y: non-temporal loads (aux 2)
+        vg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 2);
+        vy[j][k] = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 2);
       }
     }
   }
@@ -287,8 +288,9 @@ __global__ __launch_bounds__(BNRES_THREADS) void bn_bwd_res_kernel(const BnResPa
         const unsigned off = bnres_off(voff0, kstep, k, gbytes);
         __builtin_amdgcn_raw_buffer_store_b128(o, ro, (int)off, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        vg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 0);
-        vy[j][k] = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 0);
+        // (g_a, y) are read exactly once - y is dead after this pass, g_a is overwritten by g_y: non-temporal loads (aux 2)
+        vg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rg, (int)off, 0, 2);
+        vy[j][k] = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)off, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -300,3 +302,4 @@ __global__ __launch_bounds__(BNRES_THREADS) void bn_bwd_res_kernel(const BnResPa
     if (p.dbeta) p.dbeta[c] += sm_grad[1][threadIdx.x];
   }
 }
+

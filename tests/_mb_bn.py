@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import gpu_util as G
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+G.lib.jck_tune(b"bn_res", 2)
 ws = torch.zeros(G.lib.jck_grid_sync_bytes() // 4, dtype=torch.int32, device="cuda")
 flush = torch.empty(300 << 20, dtype=torch.uint8, device="cuda")
 for name, hw, c in (("L1", 32, 64), ("L2", 16, 128), ("L3", 8, 256), ("L4", 4, 512)):

@@ -8,8 +8,10 @@ ws = torch.zeros(G.lib.jck_grid_sync_bytes() // 4, dtype=torch.int32, device="cu
 st = torch.zeros(256 * 8, dtype=torch.int64, device="cuda")
 G.lib.jck_debug_bnres_stamps(st)
 flush = torch.empty(300 << 20, dtype=torch.uint8, device="cuda")
-for name, hw, c in (("L1", 32, 64), ("L2", 16, 128), ("L4", 4, 512)):
-    rows, groups = B * hw * hw, 1
+G.lib.jck_tune(b"bn_res", 2)
+GROUPS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for name, hw, c in (("L1", 32, 64), ("L2", 16, 128), ("L3", 8, 256), ("L4", 4, 512)):
+    rows, groups = B * hw * hw, GROUPS
     y = (torch.randn(groups, rows, c, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)
     ga = torch.randn(groups, rows, c, device="cuda").to(torch.bfloat16)
     aux = torch.cat([torch.ones(groups, c), torch.zeros(groups, c), torch.full((groups, c), 0.3), torch.full((groups, c), 0.66)], 1).cuda().contiguous()
