@@ -288,6 +288,11 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
  * arena.  Same kernels in the same order on every tensor: bitwise the results of PHASE_D_LOSS. */
 #define JCK_PHASE_D_LOSS_A 8
 #define JCK_PHASE_D_LOSS_B 9
+/* OR-ed into PHASE_D_LOSS / PHASE_D_GP (CGAN): the caller reads nothing of D's gradient arena before PHASE_D_STEP (no
+ * all-reduce in between), so the phase need not wait for the weight-gradient stream before it returns.  PHASE_D_STEP then
+ * runs Adam over everything but the bottom conv weight - the last product of that stream - while it finishes, and that one
+ * tensor behind it.  Any other phase that follows joins first.  Same kernels on the same values: bitwise the plain order. */
+#define JCK_PHASE_LAZY_JOIN 0x100
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */

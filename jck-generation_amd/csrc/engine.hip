@@ -159,8 +159,9 @@ struct jck_engine {
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, evWmid = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
   bool overlap = true, gp_inflight = false, defer_join = true;
+  bool join_pending = false, mid_recorded = false;    // PHASE_LAZY_JOIN: evWdone (and evWmid) recorded on sA, not yet waited for
   // cross-stream hand-overs of the backward: the producing launch completes the event itself (the `done` argument of
   // bn_act_bwd_res_ev / tanh_bwd_ev: hipExtLaunchKernel's stop event) instead of a
   // hipEventRecord behind it; JCK_EXT_EVENTS=0 restores the records
@@ -346,9 +347,9 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
-    for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral
-    hipEvent_t* ev[5 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = &e->evW[i];
+    for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral (r1-r4)
+    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
   }
   *out = e;
@@ -359,8 +360,8 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[5 + JCK_MAX_STAGES] = {e->evWdone, e->ev0, e->evF, e->evReal, e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = e->evW[i];
+    hipEvent_t ev[6 + JCK_MAX_STAGES] = {e->evWdone, e->evWmid, e->ev0, e->evF, e->evReal, e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = e->evW[i];
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -427,8 +428,7 @@ extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, 
 }
 
 // all conv operands of one network in one launch (ew.hpp: pack_multi_kernel); the two Linear operands of CGAN's D follow
-extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
-  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+static int repack_convs(jck_engine* e, int net, void* stream) {
   PackJobs jobs = {};
   int n = 0, chunk = 0;
   auto add = [&](int kind, const float* w, void* wp, long long total, int a, int b, int c) {
@@ -464,11 +464,18 @@ extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
   if (e->prec == JCK_PREC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
   else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
   HIPCHK(hipGetLastError());
-  if (net == 1 && e->family == 1) {
-    const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
-    JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
-    JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
-  }
+  return JCK_OK;
+}
+static int repack_linear(jck_engine* e, void* stream) {
+  const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
+  JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
+  JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
+  return JCK_OK;
+}
+extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  JCK_TRY(repack_convs(e, net, stream));
+  if (net == 1 && e->family == 1) JCK_TRY(repack_linear(e, stream));
   return JCK_OK;
 }
 
@@ -642,7 +649,7 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
 // layer (joined into `st`: the tail of D's gradient arena - conv4.weight, norm4.*, conv5.weight - is then final in `st` order and
 // its all-reduce can start) / everything after it.
 static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int gw, bool xgrad_last, hipStream_t st, hipStream_t side,
-                              bool with_gp_norm = false, int part = 0) {
+                              bool with_gp_norm = false, int part = 0, bool lazy_join = false) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
@@ -682,7 +689,11 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
   }
   // the penalty's norm does not need the weight gradients: it runs while the side stream finishes the last of them
   if (with_gp_norm) JCK_TRY(jck_gp_norm(e->prec, e->d_gx, B, TT.HW, e->acc, 6, e->acc_ld, e->norms, st));
-  if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+  if (side) {
+    HIPCHK(hipEventRecord(e->evWdone, side));
+    if (lazy_join) { e->join_pending = true; e->mid_recorded = false; }      // JCK_PHASE_LAZY_JOIN: whoever comes next waits
+    else HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0));
+  }
   return JCK_OK;
 }
 
@@ -745,7 +756,7 @@ static GpSrc gp_src_group(jck_engine* e, int g, int B) {
 }
 
 static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, int B, float lambda, const float* drop_mask, hipStream_t st,
-                              hipStream_t side = nullptr) {
+                              hipStream_t side = nullptr, bool lazy_join = false) {
   const size_t esz = e->esz;
   auto fork = [&](int k) -> hipStream_t {            // work enqueued on the returned stream starts after everything on st so far
     if (!side) return st;
@@ -800,10 +811,14 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
                             LRELU, e->bn2_ws_rev, e->d_v[i], e->P(e->LD, e->dg, NWN[i]), e->P(e->LD, e->dg, NBN[i]), rows, cs, st));
     const void* big = i == 0 ? xhat : P.a[i - 1];
     JCK_TRY(jck_conv_wgrad(e->prec, e->d_v[i], big, e->wg_ws, e->wg_ws_bytes, e->P(e->LD, e->dg, CWN[i]), 1, B, hb, hb, cb, cs, fork(i)));
+    // everything but the bottom conv weight's gradient is final on the side stream here (lazy join: the optimiser phase starts
+    // behind this point and takes that one tensor last)
+    if (side && lazy_join && i == 1) { (void)hipEventRecord(e->evWmid, side); e->mid_recorded = true; }
     if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, e->d_v[i], e->d_up[i], e->d_v[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
   }
-  join();
+  if (side && lazy_join) { (void)hipEventRecord(e->evWdone, side); e->join_pending = true; }
+  else join();
   return JCK_OK;
 }
 
@@ -916,6 +931,14 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   hipStream_t st = (hipStream_t)stream;
   const int B = e->B, HW = TT.HW;
   const bool cg = e->family == 1;
+  const bool lazy = (phase & JCK_PHASE_LAZY_JOIN) && cg && !e->capturing;
+  phase &= ~JCK_PHASE_LAZY_JOIN;
+  // a join left open by the phase before (JCK_PHASE_LAZY_JOIN): the penalty's double backward keeps using the weight-gradient
+  // stream in order and the optimiser phase closes it tensor by tensor; anything else waits here
+  if (e->join_pending && !(phase == JCK_PHASE_D_STEP || (phase == JCK_PHASE_D_GP && cg && e->gp_done))) {
+    HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0));
+    e->join_pending = e->mid_recorded = false;
+  }
   if (cg) {
     if (!in->labels) JCK_FAIL(JCK_E_ARG, "CGAN phases need labels");
     e->cur_labels = in->labels;
@@ -1002,7 +1025,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           e->head_row0 = 2 * B;                        // where PHASE_D_GP finds the penalty group's head state
           e->head_wrow0 = 0;
         }
-        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true));
+        JCK_TRY(d_batched_backward(e, e->real_noisy, B, 3, 2, true, st, sA, true, 0, lazy));
         e->gp_done = true;
         return JCK_OK;
       }
@@ -1091,7 +1114,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
       if (e->gp_done && cg) {                         // forward and first backward ran as group 2 of the batched pass
         e->gp_done = false;
-        JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, sA));
+        JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, sA, lazy));
+        if (!(lazy && sA)) e->join_pending = e->mid_recorded = false;      // it joined the stream itself
         e->head_row0 = 0;
         JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
         return JCK_OK;
@@ -1112,7 +1136,21 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_D_STEP: {                                                                      // :180
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
       if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));   // (eager callers)
-      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
+      const float* hp = e->hp2 + 8 * e->parity;
+      if (e->join_pending) {
+        // the weight-gradient stream is still on its last products: Adam and the Linear repack for everything behind the bottom
+        // conv weight in the arena now, [label embedding | conv1.weight] and the conv repack once that stream is through
+        const TensorInfo* c1 = find(e->LD, CWN[0]);
+        const long long cut = c1->offset + c1->numel;
+        HIPCHK(hipStreamWaitEvent(st, e->mid_recorded ? e->evWmid : e->evWdone, 0));
+        JCK_TRY(jck_adam_hp(e->dp + cut, e->dg + cut, e->dm + cut, e->dv + cut, e->LD.n_params - cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
+        JCK_TRY(repack_linear(e, st));
+        if (e->mid_recorded) HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0));
+        e->join_pending = e->mid_recorded = false;
+        JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
+        return repack_convs(e, 1, st);
+      }
+      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
@@ -1242,14 +1280,15 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
       HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
     }
     // ... and so may the events recorded inside it
-    hipEvent_t* ev[5 + JCK_MAX_STAGES] = {&e->evWdone, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[5 + i] = &e->evW[i];
+    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;
       HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
     }
     e->gp_inflight = false;
+    e->join_pending = e->mid_recorded = false;
     (void)hipGetLastError();
   }
   return JCK_OK;

@@ -14,6 +14,7 @@ from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, lo
 
 (PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD, PHASE_D_LOSS_A,
  PHASE_D_LOSS_B) = range(10)
+PHASE_LAZY_JOIN = 0x100
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
@@ -117,6 +118,7 @@ class DcganEngine:
         self.graphs = os.environ.get("JCK_GRAPH", "0") != "0"
         # data parallel: D's all-reduce in two pieces under D's own backward + G's under the next batch's D(real) forward;
         # False = one all-reduce per network, waited for before its Adam (hipgan.dist.ReplicaGuard falls back to it)
+        self.lazy_join = os.environ.get("JCK_LAZY_JOIN", "1") != "0"
         self.ddp_overlap = os.environ.get("JCK_DDP_SPLIT", "1") == "1"
         # steps without a noise dict draw z / alpha with torch and the two instance-noise tensors INSIDE the image kernels
         # (Philox, jck_engine_set_noise_seed); JCKGAN_FAST_NOISE=0 draws them with torch.randn as round 1 did
@@ -557,12 +559,15 @@ class DcganEngine:
                 if w is not None:
                     w()
         else:
-            lib.jck_engine_phase(h, PHASE_D_LOSS, C.byref(si), st)
+            # CGAN without an all-reduce in between: nothing reads D's gradients before PHASE_D_STEP, which then closes the join
+            # with the weight-gradient stream itself (include/jckgan.h: JCK_PHASE_LAZY_JOIN)
+            lazy = PHASE_LAZY_JOIN if (self.family == 1 and not reduce_d and self.lazy_join) else 0
+            lib.jck_engine_phase(h, PHASE_D_LOSS | lazy, C.byref(si), st)
             if self.family == 0:
                 handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
                 lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
             else:                                                      # CGAN back-propagates the penalty: reduce after it
-                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
+                lib.jck_engine_phase(h, PHASE_D_GP | lazy, C.byref(si), st)
                 handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
             if handle is not None:
                 handle()

@@ -99,3 +99,34 @@ def test_cgan_per_pass_schedule_still_matches(monkeypatch):
     """JCK_BATCHED=0 keeps the separate real / fake passes (also what batches that are not a multiple of 8 run)."""
     monkeypatch.setenv("JCK_BATCHED", "0")
     test_cgan_step_parity("f32", 8, 1e-3, 2e-2)
+
+
+@pytest.mark.parametrize("prec,B", [("bf16", 256), ("f32", 16)])
+def test_lazy_join_with_the_weight_gradient_stream_is_bitwise_the_plain_order(prec, B):
+    """JCK_PHASE_LAZY_JOIN (include/jckgan.h; the default of a single-GPU CGAN step): D's loss and penalty phases return
+    without waiting for the weight-gradient stream and the optimiser phase takes the bottom conv weight last.  Same kernels
+    on the same values: three steps with and without it leave bit-identical weights, Adam moments, gradients and scalars
+    (a missing dependency shows here as a difference - the small exact-fp32 case has the shortest kernels)."""
+    from hipgan.engine import CganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images, synth_onehot
+    torch.manual_seed(12345)
+    g, d = build_params("cgan")
+    imgs = synth_images(B * 3)
+    onehot, _ = synth_onehot(B * 3)
+    runs = []
+    for lazy in (True, False):
+        eng = CganEngine(batch=B, prec=prec)
+        eng.lazy_join = lazy
+        eng.load_state(g, d)
+        sc = []
+        for s in range(3):
+            lab = onehot[s * B:(s + 1) * B]
+            nz = _noise(B, 700 + s, lab)
+            sc.append(eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4))
+        torch.cuda.synchronize()
+        runs.append((sc, {k: v.clone() for k, v in eng.arenas.items()}))
+    (s0, a0), (s1, a1) = runs
+    assert s0 == s1, (s0, s1)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k
