@@ -584,8 +584,11 @@ static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const
 
 // D backward on set `D`.  With `side` != nullptr the weight-gradient products run on that stream beside the dgrad chain
 // (both only READ gy_i and the saved activations); the main stream waits for them before returning.
+// resident = false: the pass runs beside another pass of the step on a second stream.  Two resident BatchNorm launches in flight
+// at once would share the engine's barrier words and could each hold CUs the other's missing workgroups need: such a pass takes
+// the three-launch form.
 static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
-                      hipStream_t st, hipStream_t side, bool join = true) {
+                      hipStream_t st, hipStream_t side, bool join = true, bool resident = true) {
   JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[TT.NS - 1], st));
   const bool par = want_wgrad && side != nullptr;
   for (int i = TT.NS - 1; i >= 0; --i) {
@@ -596,7 +599,7 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     // the launch that writes g_y hands it to the weight-gradient stream by completing evW[i] itself
     hipEvent_t done = par && e->ext_events ? e->evW[i] : nullptr;
     JCK_TRY(bn_act_bwd_res_ev(e->prec, D.g[i], D.y[i], D.bn[i].aux, LRELU, D.bn[i].sums, D.g[i], dgam, dbet, rows, cs, 1, 1,
-                              e->bn_res ? e->gsync : nullptr, st, done));
+                              e->bn_res && resident ? e->gsync : nullptr, st, done));
     const void* big = i == 0 ? x_in : D.a[i - 1];
     if (want_wgrad) {
       hipStream_t ws = st;
@@ -974,7 +977,9 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     JCK_TRY(jck_interp(e->prec, e->real_noisy, e->fake, in->alpha, e->xhat, B, HW, s));
     JCK_TRY(d_forward(e, D, e->xhat, B, 2, in->drop_mask[2], s));
     JCK_TRY(d_head(e, D, B, 0.f, 1, -1, -1, s));
-    JCK_TRY(d_backward(e, D, e->xhat, B, false, true, in->drop_mask[2], s, nullptr));
+    // DCGAN's per-pass schedule runs this pass on its own stream beside D(fake): three-launch BatchNorm backward (d_backward),
+    // whatever the stream layout of this call (a captured one-stream step stays launch for launch the eager one)
+    JCK_TRY(d_backward(e, D, e->xhat, B, false, true, in->drop_mask[2], s, nullptr, true, cg));
     JCK_TRY(jck_gp_norm(e->prec, D.gx, B, HW, e->acc, 6, e->acc_ld, D.norms, s));
     return JCK_OK;
   };

@@ -1,11 +1,9 @@
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_cgan_gpu.py tests/test_bf16_envelope.py -q -x -k "cgan" > gpurun_out/t_lazy.log 2>&1; echo "tests rc=$?" 
+# development aid: A/B runs of the bench under two settings of one environment switch on the same box
+# usage (on the GPU box): bash tests/_ab.sh VAR A B [--model cgan]
+cd "$GRAFT_REPO_ROOT"
+VAR=$1; A=$2; B=$3; shift 3
 for i in 1 2; do
-JCK_LAZY_JOIN=0 python bench.py --model cgan --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lazy0', d['ms_per_step'], d['value'])"
-JCK_LAZY_JOIN=1 python bench.py --model cgan --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lazy1', d['ms_per_step'], d['value'])"
+  for v in "$A" "$B"; do
+    env "$VAR=$v" python bench.py --steps 300 --warmup 40 --no-cpu-baseline --no-roofline --no-secondary "$@" | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v', d['ms_per_step'], d['value'])"
+  done
 done
-for p in 0 1 -1; do
-JCK_SIDE_PRIO=$p python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-roofline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prio$p', d['ms_per_step'], d['value'])"
-JCK_SIDE_PRIO=$p python bench.py --model cgan --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cgan prio$p', d['ms_per_step'], d['value'])"
-done
-tail -5 gpurun_out/t_lazy.log

@@ -274,6 +274,30 @@ def test_per_pass_schedule_at_the_8gpu_tail_batch():
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
 
 
+def test_per_pass_schedule_in_bf16_keeps_one_resident_launch_in_flight(monkeypatch):
+    """bf16 at batch 106: the per-pass schedule runs the penalty pass on its own stream beside D(fake).  Two resident BatchNorm
+    backward launches at once would share the engine's barrier words (and could starve each other of CUs), so that pass takes the
+    three-launch form: the barrier never times out (engine.scalars() raises if one did), and tensor by tensor the step is no
+    further from the fp32 oracle than the all three-launch step (JCK_BN_RES=0) and closer to that step than either is to the
+    oracle (another summation order of the per-channel sums, amplified by bf16 rounding through the layers below)."""
+    runs = []
+    for res in ("1", "0"):
+        monkeypatch.setenv("JCK_BN_RES", res)
+        orc, eng, out = _run(106, 1, "bf16")
+        torch.cuda.synchronize()
+        runs.append((out[-1][1], {t: {k: v.detach().float().cpu().clone() for k, v in eng.named_views(t, "grads").items()} for t in "dg"}))
+    ref = {"d": out[-1][2], "g": out[-1][3]}
+    (s1, g1), (s0, g0) = runs
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(s1[k], s0[k]) < 2e-3, (k, s1[k], s0[k])
+    l2 = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
+    for t in "dg":
+        for k, r in ref[t].items():
+            d1, d0, d10 = l2(g1[t][k].view(r.shape), r), l2(g0[t][k].view(r.shape), r), l2(g1[t][k], g0[t][k])
+            assert d1 <= 1.25 * d0 + 1e-3, (t, k, d1, d0)
+            assert d10 <= max(2e-2, 0.75 * max(d0, d1)), (t, k, d10, d0, d1)
+
+
 def test_separate_generator_learning_rate_keeps_the_step_scalars():
     """an optimiser phase called with another learning rate than the step's loss phases used to re-run
     jck_engine_set_step, which zeroed the step's accumulator rows - loss_d / loss_g / gp were then logged as 0.  Two engines from
