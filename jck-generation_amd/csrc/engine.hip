@@ -168,6 +168,8 @@ struct jck_engine {
   bool ext_events = true;
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
+  bool fold_zero = true;                // zero_grad() of both networks inside neighbouring launches (JCK_FOLD_ZERO=0: memsets)
+  bool fuse_tanh = true;                // G's loss pass: tanh backward in the epilogue of D.conv1's input gradient (JCK_FUSE_TANH=0: a launch of its own)
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
   void *real_noisy, *xhat;
   // small buffers
@@ -185,6 +187,9 @@ struct jck_engine {
   float hp_lr[2] = {-1.f, -1.f};        // ... and at which learning rate they were computed (a scheduler may change it between steps)
   bool hp_holds(int step, float lr) const { return hp_step[step & 1] == step && hp_lr[step & 1] == lr; }
   int acc_clean_step = -1;              // the step whose accumulator rows jck_engine_set_step has just cleared (consumed by its first D phase)
+  // zero_grad() without a launch of its own: D's gradient arena (+ CGAN's permuted Linear gradient) is cleared by the set-step
+  // launch of the step's first D phase, G's by D's Adam launch; the step whose arena is clean (consumed by the phase that would memset)
+  int dg_clean_step = -1, gg_clean_step = -1;
   bool capturing = false;
   float* g1_ws = nullptr; size_t g1_ws_bytes = 0;
   float* wg_ws; size_t wg_ws_bytes;
@@ -345,6 +350,8 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->carve(nullptr);
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
+  e->fold_zero = !(getenv("JCK_FOLD_ZERO") && atoi(getenv("JCK_FOLD_ZERO")) == 0);
+  e->fuse_tanh = !(getenv("JCK_FUSE_TANH") && atoi(getenv("JCK_FUSE_TANH")) == 0);
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral (r1-r4)
@@ -587,8 +594,11 @@ static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const
 // resident = false: the pass runs beside another pass of the step on a second stream.  Two resident BatchNorm launches in flight
 // at once would share the engine's barrier words and could each hold CUs the other's missing workgroups need: such a pass takes
 // the three-launch form.
+// xe (G's loss pass): the input gradient is wanted only as the operand of the tanh + noise-mix backward of G's output - that
+// product rides in the epilogue of the launch that computes it (conv_up_tanh_bwd_ev) when the layer runs on the image-side kernel
+struct XgradEpi { const void* tanh_y; float scale; void* out; hipEvent_t done; bool fused; };
 static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
-                      hipStream_t st, hipStream_t side, bool join = true, bool resident = true) {
+                      hipStream_t st, hipStream_t side, bool join = true, bool resident = true, XgradEpi* xe = nullptr) {
   JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[TT.NS - 1], st));
   const bool par = want_wgrad && side != nullptr;
   for (int i = TT.NS - 1; i >= 0; --i) {
@@ -608,8 +618,11 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
     }
     if (i > 0)
       JCK_TRY(jck_conv_up(e->prec, D.g[i], e->d_up[i], D.g[i - 1], nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
-    else if (want_xgrad)
-      JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+    else if (want_xgrad) {
+      if (xe) JCK_TRY(conv_up_tanh_bwd_ev(e->prec, D.g[0], e->d_up[0], xe->tanh_y, xe->scale, xe->out, B, hb / 2, hb / 2, cs, cb, st, xe->done, &xe->fused));
+      if (!xe || !xe->fused)
+        JCK_TRY(jck_conv_up(e->prec, D.g[0], e->d_up[0], D.gx, nullptr, nullptr, 0, B, hb / 2, hb / 2, cs, cb, st));
+    }
   }
   // join = false: the caller's NEXT d_backward/g_backward with a side stream (or its own join) orders the main stream
   // behind these weight gradients - nothing on the main stream reads them before the optimiser step
@@ -857,11 +870,13 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
 }
 
 // g_fake = gradient w.r.t. the noisy fake image (NHWC4); fills G's grads arena (accumulating)
-static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side) {
+// raw_ready: g_raw was written by the launch that computed g_fake (XgradEpi), which also completed the first stage's event
+static int g_backward(jck_engine* e, const void* g_fake, int B, hipStream_t st, hipStream_t side, bool raw_ready = false) {
   // every launch that writes a gradient the weight-gradient stream reads (tanh backward, then the BatchNorm backward of each
   // stage) completes that stage's event itself
   const bool ext = side && e->ext_events;
-  JCK_TRY(tanh_bwd_ev(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st, ext ? e->evW[TT.NS - 1] : nullptr));
+  if (!raw_ready)
+    JCK_TRY(tanh_bwd_ev(e->prec, g_fake, e->fake_raw, 0.9f, e->g_raw, (long long)B * TT.HW * 4, st, ext ? e->evW[TT.NS - 1] : nullptr));
   const void* gbig = e->g_raw;       // gradient w.r.t. the output of conv(i+2)
   for (int i = TT.NS - 1; i >= 0; --i) {     // stage i: conv(i+2): small = g_a[i] (C = TT.G_CS[i]), big side has TT.G_CB[i] channels
     const int hs = TT.G_HS[i], cs = TT.G_CS[i], cb = TT.G_CB[i];
@@ -910,6 +925,16 @@ static int refresh_adam_scalars(jck_engine* e, int step, float lr, hipStream_t s
   e->hp_lr[q] = lr;
   return JCK_OK;
 }
+static int set_step_impl(jck_engine* e, int step, float lr, void* stream, bool zero_d);
+// D.zero_grad() (:155): cleared by the step's set-step launch when that has just run for this step (zero_d), else by a memset
+static int zero_d_grads(jck_engine* e, int step, hipStream_t st) {
+  const bool clean = e->dg_clean_step == step && !e->capturing;
+  e->dg_clean_step = -1;
+  if (clean) return JCK_OK;
+  HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
+  if (e->family == 1) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+  return JCK_OK;
+}
 static int clear_acc(jck_engine* e, int step, hipStream_t st) {
   if (e->acc_clean_step == step && !e->capturing) { e->acc_clean_step = -1; return JCK_OK; }
   HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
@@ -954,7 +979,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
   // (a phase called with another learning rate than the step's earlier phases - separate G and D rates - rewrites the Adam
   // scalars only: the step's accumulator rows and random inputs are live)
   if (!e->capturing) {
-    if (e->hp_step[in->step & 1] != in->step) JCK_TRY(jck_engine_set_step(e, in->step, in->lr, st));
+    if (e->hp_step[in->step & 1] != in->step)
+      JCK_TRY(set_step_impl(e, in->step, in->lr, st, (phase & 0xff) == JCK_PHASE_D_LOSS || (phase & 0xff) == JCK_PHASE_D_LOSS_A || (phase & 0xff) == JCK_PHASE_D_REAL));
     else if (e->hp_lr[in->step & 1] != in->lr) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
   }
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
@@ -996,8 +1022,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         // expects them.
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         JCK_TRY(clear_acc(e, in->step, st));
-        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+        JCK_TRY(zero_d_grads(e, in->step, st));
         JCK_TRY(prep_real(e, in, B, st));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
@@ -1048,7 +1073,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         const bool pre = e->real_fwd_step == (long long)in->step;
         e->real_fwd_step = -1;
         JCK_TRY(clear_acc(e, in->step, st));
-        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                     // D.zero_grad()  :155
+        JCK_TRY(zero_d_grads(e, in->step, st));                                                   // D.zero_grad()  :155
         if (!pre) JCK_TRY(prep_real(e, in, B, st));   // :160
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));                                             // :171, :111-113
@@ -1066,8 +1091,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       if (phase != JCK_PHASE_D_FAKE) {              // ---- D on the real batch (:155-165); independent of G
         if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL needs real_nchw (or real_u8)");
         JCK_TRY(clear_acc(e, in->step, st));
-        HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));                   // D.zero_grad()  :155
-        if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+        JCK_TRY(zero_d_grads(e, in->step, st));                                                 // D.zero_grad()  :155
       }
       hipStream_t sG = st;
       if (phase == JCK_PHASE_D_LOSS || phase == JCK_PHASE_D_FAKE) {   // G forward: beside D(real) when both are in this call
@@ -1142,29 +1166,35 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       if (e->gp_inflight) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP must be called before PHASE_D_STEP");
       if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));   // (eager callers)
       const float* hp = e->hp2 + 8 * e->parity;
+      // G.zero_grad() (:182) rides on D's Adam launch: G's gradient arena is dead between G's optimiser step and PHASE_G_LOSS
+      float* zg = (e->fold_zero && !e->capturing && e->LG.n_params % 4 == 0) ? e->gg : nullptr;
+      if (zg) e->gg_clean_step = in->step;
       if (e->join_pending) {
         // the weight-gradient stream is still on its last products: Adam and the Linear repack for everything behind the bottom
         // conv weight in the arena now, [label embedding | conv1.weight] and the conv repack once that stream is through
         const TensorInfo* c1 = find(e->LD, CWN[0]);
         const long long cut = c1->offset + c1->numel;
         HIPCHK(hipStreamWaitEvent(st, e->mid_recorded ? e->evWmid : e->evWdone, 0));
-        JCK_TRY(jck_adam_hp(e->dp + cut, e->dg + cut, e->dm + cut, e->dv + cut, e->LD.n_params - cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
+        JCK_TRY(jck_adam_hp(e->dp + cut, e->dg + cut, e->dm + cut, e->dv + cut, e->LD.n_params - cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st,
+                            zg, e->LG.n_params));
         JCK_TRY(repack_linear(e, st));
         if (e->mid_recorded) HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0));
         e->join_pending = e->mid_recorded = false;
         JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
         return repack_convs(e, 1, st);
       }
-      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
+      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, hp, st, zg, e->LG.n_params));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
-      HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
+      if (!(e->gg_clean_step == in->step && !e->capturing)) HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
+      e->gg_clean_step = -1;
       JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st));
       JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
-      JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr));
-      JCK_TRY(g_backward(e, D0.gx, B, st, sA));
+      XgradEpi xe = {e->fake_raw, 0.9f, e->g_raw, (sA && e->ext_events) ? e->evW[TT.NS - 1] : nullptr, false};
+      JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr, true, true, e->fuse_tanh ? &xe : nullptr));
+      JCK_TRY(g_backward(e, D0.gx, B, st, sA, xe.fused));
       return JCK_OK;
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
@@ -1195,18 +1225,23 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
 // torch.optim.Adam does) -> device memory of parity step & 1.  Call once per step BEFORE its phases when the phases are
 // replayed from a captured graph (the graph bakes every kernel argument); eager callers may skip it - the optimiser phases
 // then write the scalars themselves.
-extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stream) {
+// zero_d: the caller is the step's first D-loss phase - the same launch clears D's gradient arena (D.zero_grad(), :155)
+static int set_step_impl(jck_engine* e, int step, float lr, void* stream, bool zero_d) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
   const int q = step & 1;
+  zero_d = zero_d && e->fold_zero && e->LD.n_params % 4 == 0;
   JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream, e->rz[q], (long long)e->B * 100,
                             e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f,
-                            e->acc2 + (size_t)8 * e->acc_ld * q, (long long)8 * e->acc_ld));
+                            e->acc2 + (size_t)8 * e->acc_ld * q, (long long)8 * e->acc_ld,
+                            zero_d ? e->dg : nullptr, e->LD.n_params, zero_d && e->family == 1 ? e->gw1p : nullptr, (long long)L1_OUT * L1_KPAD));
+  if (zero_d) e->dg_clean_step = step;
   e->acc_clean_step = step;
   e->hp_step[step & 1] = step;
   e->hp_lr[step & 1] = lr;
   return JCK_OK;
 }
+extern "C" int jck_engine_set_step(jck_engine* e, int step, float lr, void* stream) { return set_step_impl(e, step, lr, stream, false); }
 // Seed of the in-kernel instance noise (steps whose jck_step_inputs carry no noise tensors draw 0.1*N(0,1) inside the image
 // kernels: Philox4x32-10 keyed by this seed, counter = pixel | tensor | optimiser step).  Data-parallel ranks pass seed + rank.
 extern "C" int jck_engine_set_noise_seed(jck_engine* e, unsigned long long seed) {

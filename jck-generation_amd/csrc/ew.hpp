@@ -637,8 +637,11 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // (train/dcgan_trainer.py:168), alpha [nalpha] ~ U[0,1) (:111), CGAN's Dropout keep masks [nmask] in {0,1} with P(keep) = keep_p
 // (model/CGAN.py:105) - Philox4x32-10, counter = (index/4, tensor id 8 / 9 / 10, step), key = seed.  No ATen launch is left
 // in the step, and a captured step replays with fresh draws without any copy into static buffers.
-struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; float* zero; long long nzero; };
-// (zero / nzero: a small buffer the same launch clears - the engine's per-step accumulator rows, instead of a memset node)
+struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; float* zero; long long nzero;
+                 float* zbig[2]; long long nzbig[2]; };
+// (zero / nzero: a small buffer the same launch clears - the engine's per-step accumulator rows, instead of a memset node;
+// zbig: up to two large 16-byte aligned ranges, counts % 4 == 0 - D's gradient arena and CGAN's permuted Linear gradient, which
+// D.zero_grad() (train/dcgan_trainer.py:155) would clear with a launch of its own a few microseconds later)
 __device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, float bc2_sqrt, unsigned seed_lo, unsigned seed_hi,
                                       unsigned step, const StepRng r) {
@@ -649,6 +652,10 @@ static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, f
   }
   const long long q0 = (r.nz + 3) / 4, q1 = (r.nalpha + 3) / 4, q2 = (r.nmask + 3) / 4;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < r.nzero; i += (long long)gridDim.x * blockDim.x) r.zero[i] = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (r.nzbig[b] >> 2); i += (long long)gridDim.x * blockDim.x)
+      reinterpret_cast<f32x4*>(r.zbig[b])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q0 + q1 + q2; i += (long long)gridDim.x * blockDim.x) {
     unsigned o[4];
     if (i < q0) {                                                     // four normals: two Box-Muller pairs
@@ -688,8 +695,12 @@ __device__ __forceinline__ void adam_one(float& pi, float gi_raw, float& mi_io, 
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float w1 /*1-beta1*/, float beta2, float omb2 /*1-beta2*/,
                             float eps, float step_size, float bc2_sqrt, float grad_scale, const float* __restrict__ hp = nullptr,
-                            int vec = 1) {
+                            int vec = 1, float* __restrict__ zero = nullptr, long long nzero4 = 0) {
   if (hp) { step_size = hp[0]; bc2_sqrt = hp[1]; }
+  // zero (optional): a 16-byte aligned range of nzero4 float4 the same launch clears - the OTHER network's gradient arena, whose
+  // zero_grad() (train/dcgan_trainer.py:182) is the next thing in the step
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nzero4; i += (long long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(zero)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long long n4 = vec ? (n >> 2) : 0;                 // vec = 0: a pointer is not 16-byte aligned -> element by element
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];

@@ -334,13 +334,14 @@ static int launch_img_down(const void* x, const void* w, void* out, float* stats
   return JCK_OK;
 }
 #define IMG_UP_R 8
-static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, int N, int Hs, int Ws, double flops, hipStream_t st) {
+static int launch_img_up(const void* a, const void* w, void* out, int epi_tanh, int N, int Hs, int Ws, double flops, hipStream_t st,
+                         const void* mul_t = nullptr, float mul_scale = 1.f, hipEvent_t done = nullptr) {
   ImgUpParams q = {};
-  q.a = a; q.w = w; q.out = out; q.epi_tanh = epi_tanh;
+  q.a = a; q.w = w; q.out = out; q.epi_tanh = epi_tanh; q.mul_t = mul_t; q.mul_scale = mul_scale;
   q.nunits = N * (Hs / IMG_UP_R) * (Ws / 16); q.Hs = Hs; q.Ws = Ws; q.logYB = ilog2(Hs / IMG_UP_R); q.logG = ilog2(Ws / 16);
   q.a_bytes = (unsigned)((long long)N * Hs * Ws * 64 * 2);
   ProfScope prof(19, flops, st);
-  hipLaunchKernelGGL(img_up_kernel<IMG_UP_R>, dim3(cdiv(q.nunits, 4)), dim3(256), 0, st, q);
+  LAUNCH_EV(img_up_kernel<IMG_UP_R>, dim3(cdiv(q.nunits, 4)), dim3(256), 0, st, done, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -420,6 +421,16 @@ static int conv_up_impl(int prec, const void* small_in, const void* w, void* big
   p.flops = 2.0 * p.M * 4.0 * Cb * 4.0 * Cs;
   if (stats && fwd_group_images > 0) { p.bn_group_rows = fwd_group_images * Hs * Ws; p.stat_accum = 1; }
   return launch_igemm(prec, p, rows, 4, 1, (hipStream_t)stream, stats_slots);
+}
+// D.conv1's input gradient with the tanh + instance-noise-mix backward of G's output in its epilogue (thin.hpp: ImgUpParams::mul_t):
+// out = scale * bf16(convT(small_in)) * (1 - tanh_y^2), bit for bit jck_conv_up followed by tanh_bwd_ev.  *fused = false (and
+// nothing launched) when the layer does not run on the image-side streaming kernel: the caller then issues the two launches.
+int conv_up_tanh_bwd_ev(int prec, const void* small_in, const void* w, const void* tanh_y, float scale, void* out, int N, int Hs, int Ws,
+                        int Cs, int Cb, hipStream_t stream, hipEvent_t done, bool* fused) {
+  *fused = g_use_thin && prec == JCK_PREC_BF16 && jck_pad_chan(Cb) == 4 && Cs == 64 && Ws % 16 == 0 && Hs % IMG_UP_R == 0 &&
+           is_pow2(Hs) && is_pow2(Ws) && (long long)N * Hs * Ws * 16 < (1ll << 31);
+  if (!*fused) return JCK_OK;
+  return launch_img_up(small_in, w, out, 0, N, Hs, Ws, 2.0 * N * Hs * Ws * 4.0 * Cb * 4.0 * Cs, stream, tanh_y, scale, done);
 }
 extern "C" int jck_conv_up(int prec, const void* small_in, const void* w, void* big_out, float* stats, int* stats_slots,
                            int epi_tanh, int N, int Hs, int Ws, int Cs, int Cb, void* stream) {
@@ -1017,12 +1028,14 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
 // ... and (rz / ralpha / rmasks, each optional) the step's small random inputs, drawn by the same launch (ew.hpp: adam_hp_kernel)
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st, float* rz,
                       long long nz, float* ralpha, long long nalpha, float* rmasks, long long nmask, float keep_p, float* zero,
-                      long long nzero) {
+                      long long nzero, float* zbig0, long long nzbig0, float* zbig1, long long nzbig1) {
   if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
+  if (((uintptr_t)zbig0 | (uintptr_t)zbig1) & 15 || (nzbig0 | nzbig1) & 3) JCK_FAIL(JCK_E_ARG, "set_step: large zero ranges must be 16-byte aligned, counts % 4 == 0");
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
-  StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p, zero, zero ? nzero : 0};
-  const long long quads = (r.nz + 3) / 4 + (r.nalpha + 3) / 4 + (r.nmask + 3) / 4;
-  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 512));
+  StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p, zero, zero ? nzero : 0,
+               {zbig0, zbig1}, {zbig0 ? nzbig0 : 0, zbig1 ? nzbig1 : 0}};
+  const long long quads = std::max((r.nz + 3) / 4 + (r.nalpha + 3) / 4 + (r.nmask + 3) / 4, std::max(r.nzbig[0], r.nzbig[1]) / 16);
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 1024));
   hipLaunchKernelGGL(adam_hp_kernel, dim3(blocks), dim3(256), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,
                      (unsigned)(seed >> 32), (unsigned)step, r);
   HIPCHK(hipGetLastError());
@@ -1036,10 +1049,11 @@ extern "C" int jck_step_rng(float* hp, int step, unsigned long long seed, float*
   return jck_adam_set_step(hp, 2e-4, 0.5, 0.999, step, seed, (hipStream_t)stream, z, nz, alpha, nalpha, masks, nmask, keep_p);
 }
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
-                float grad_scale, const float* hp, hipStream_t st) {
+                float grad_scale, const float* hp, hipStream_t st, float* zero, long long nzero) {
   const int vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  if (zero && (((uintptr_t)zero & 15) || (nzero & 3))) JCK_FAIL(JCK_E_ARG, "adam: the zero range must be 16-byte aligned, count % 4 == 0");
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp, vec);
+                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp, vec, zero, zero ? nzero / 4 : 0);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

@@ -37,9 +37,10 @@ int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int ns
 // Adam with {step_size, bc2_sqrt} in device memory (ops.hip): the engine's step has no per-step kernel argument
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st,
                       float* rz = nullptr, long long nz = 0, float* ralpha = nullptr, long long nalpha = 0, float* rmasks = nullptr,
-                      long long nmask = 0, float keep_p = 0.75f, float* zero = nullptr, long long nzero = 0);
+                      long long nmask = 0, float keep_p = 0.75f, float* zero = nullptr, long long nzero = 0, float* zbig0 = nullptr,
+                      long long nzbig0 = 0, float* zbig1 = nullptr, long long nzbig1 = 0);
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
-                float grad_scale, const float* hp, hipStream_t st);
+                float grad_scale, const float* hp, hipStream_t st, float* zero = nullptr, long long nzero = 0);
 bool jck_prof_is_on();
 // Internal forms of the two launches whose result another stream waits for: `done` (may be null) is completed by the launch
 // that writes the result - the dispatch packet's own completion signal (hipExtLaunchKernel's stop event) instead of a
@@ -48,4 +49,6 @@ bool jck_prof_is_on();
 int bn_act_bwd_res_ev(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y, float* dgamma,
                       float* dbeta, long long rows_per_group, int C, int groups, int grad_groups, void* sync_ws, hipStream_t stream,
                       hipEvent_t done);
+int conv_up_tanh_bwd_ev(int prec, const void* small_in, const void* w, const void* tanh_y, float scale, void* out, int N, int Hs, int Ws,
+                        int Cs, int Cb, hipStream_t stream, hipEvent_t done, bool* fused);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);

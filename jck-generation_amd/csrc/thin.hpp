@@ -118,6 +118,11 @@ struct ImgUpParams {
   int Hs, Ws, logYB, logG;   // logYB = log2(Hs / R), logG = log2(Ws / 16)
   unsigned a_bytes;
   int epi_tanh;
+  // optional epilogue of G's loss pass (train/dcgan_trainer.py:186-187): this launch computes D's gradient w.r.t. the noisy fake
+  // image; the next op of the chain rule is the tanh + 0.9-mix backward, out = scale * bf16(acc) * (1 - t^2) with t = G's tanh
+  // output at the same pixel (same layout).  The accumulator is rounded to bf16 first - the storage point the separate
+  // tanh_bwd_kernel reads - so the result is bit for bit the two launches'.
+  const void* mul_t; float mul_scale;
 };
 
 #define IMGUP_WLD 584     // padded LDS row (elements): 1168 B = 292 dwords, 292 % 64 = 36 -> conflict-free 16-byte row reads
@@ -215,6 +220,12 @@ static __global__ __launch_bounds__(256) void img_up_kernel(const ImgUpParams p)
     // lane group g = output parity (py, px): rows 4g..4g+3 are its 4 channels
     const int y = y0 + i;
     const long long o = (((long long)n * 2 * Hs + 2 * y + (g >> 1)) * 2 * Ws + 2 * x + (g & 1)) * 4;
+    if (p.mul_t) {
+      float t[4];
+      ld4(reinterpret_cast<const bf16_t*>(p.mul_t) + o, t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = p.mul_scale * bf2f(f2bf(v[r])) * (1.f - t[r] * t[r]);
+    }
     st4(outp + o, v);
   }
 }
