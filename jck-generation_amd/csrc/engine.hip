@@ -159,7 +159,7 @@ struct jck_engine {
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, evWmid = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, evWmid = nullptr, evHead = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
   bool overlap = true, gp_inflight = false, defer_join = true;
   bool join_pending = false, mid_recorded = false;    // PHASE_LAZY_JOIN: evWdone (and evWmid) recorded on sA, not yet waited for
   // cross-stream hand-overs of the backward: the producing launch completes the event itself (the `done` argument of
@@ -355,8 +355,8 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral (r1-r4)
-    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
+    hipEvent_t* ev[7 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = &e->evW[i];
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
   }
   *out = e;
@@ -367,8 +367,8 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[6 + JCK_MAX_STAGES] = {e->evWdone, e->evWmid, e->ev0, e->evF, e->evReal, e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = e->evW[i];
+    hipEvent_t ev[7 + JCK_MAX_STAGES] = {e->evWdone, e->evWmid, e->evHead, e->ev0, e->evF, e->evReal, e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = e->evW[i];
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -736,8 +736,11 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
     JCK_TRY(jck_head_fwd_grouped(e->prec, S.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, G, tg, md, S.prob, S.ds, e->acc, sl, sp, e->acc_ld, st));
   }
   // loss groups (input + weight gradient) and the penalty group (input gradient only), one launch
-  JCK_TRY(jck_head_bwd_conv2(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
-                             e->head_ws, st));
+  // (the ordered sum of conv5's weight-gradient rows is wanted by the optimiser only: weight-gradient stream, 10 us off the main one)
+  static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
+  const bool hs = side && e->ext_events && head_side;
+  JCK_TRY(head_bwd_conv2_ev(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
+                            e->head_ws, st, hs ? side : nullptr, hs ? e->evHead : nullptr));
   JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part));
   return JCK_OK;
 }
@@ -1320,8 +1323,8 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
       HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
     }
     // ... and so may the events recorded inside it
-    hipEvent_t* ev[6 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[6 + i] = &e->evW[i];
+    hipEvent_t* ev[7 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = &e->evW[i];
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;

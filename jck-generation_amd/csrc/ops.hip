@@ -994,16 +994,26 @@ extern "C" int jck_head_bwd_conv(int prec, const float* ds, const float* wp, con
 // B + B_more rows; the weight gradient sums the first B only) - the loss groups and the penalty group of the batched D pass
 extern "C" int jck_head_bwd_conv2(int prec, const float* ds, const float* wp, const void* a4, int B, int B_more, int C, void* g_a4,
                                   float* grad, float* ws, void* stream) {
+  return head_bwd_conv2_ev(prec, ds, wp, a4, B, B_more, C, g_a4, grad, ws, (hipStream_t)stream, nullptr, nullptr);
+}
+// side / handover (both or neither): the ordered sum of the weight-gradient partial rows - wanted by the optimiser only - runs on
+// `side` behind `handover`, which the launch that writes the rows completes itself
+int head_bwd_conv2_ev(int prec, const float* ds, const float* wp, const void* a4, int B, int B_more, int C, void* g_a4, float* grad, float* ws,
+                      hipStream_t stream, hipStream_t side, hipEvent_t handover) {
   if (C % 8) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: C % 8 != 0");
+  if ((side != nullptr) != (handover != nullptr)) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: side stream and hand-over event go together");
   if (B_more < 0 || (B_more > 0 && !g_a4)) JCK_FAIL(JCK_E_ARG, "head_bwd_conv2: the extra rows produce an input gradient only");
   if (!g_a4 && !grad) return JCK_OK;
   if (grad && !ws) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: the weight gradient needs a workspace of jck_head_bwd_ws_floats(16*C) floats");
   const int K = 16 * C;
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, (hipStream_t)stream, ds, wp,
-                                      (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr, B_more));
+  hipEvent_t ev = grad ? handover : nullptr;
+  DISPATCH_T(prec, LAUNCH_EV(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, stream, ev, ds, wp,
+                             (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr, B_more));
   HIPCHK(hipGetLastError());
   if (grad) {
-    hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, ws, HEAD_CONV_NS, K, C, grad, 1);
+    hipStream_t rs = stream;
+    if (ev) { HIPCHK(hipStreamWaitEvent(side, ev, 0)); rs = side; }
+    hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, rs, ws, HEAD_CONV_NS, K, C, grad, 1);
     HIPCHK(hipGetLastError());
   }
   return JCK_OK;

@@ -274,35 +274,45 @@ def test_per_pass_schedule_at_the_8gpu_tail_batch():
     _cmp_tensors(eng.named_views("g", "grads"), ggr, 3e-2, "g_grads", 2e-2)
 
 
-@pytest.mark.parametrize("family,B", [("dcgan", 64), ("cgan", 32), ("dcgan", 24)])
-def test_launches_folded_into_their_neighbours_leave_the_step_bit_for_bit(family, B, monkeypatch):
-    """Round 4 folds three small launches into their neighbours: D.zero_grad() into the step's set-step launch, G.zero_grad()
-    into D's Adam launch, and the tanh + noise-mix backward of G's output into the epilogue of D.conv1's input gradient (the
-    accumulator rounded to bf16 first, as the separate launch read it).  JCK_FUSE_TANH=0 / JCK_FOLD_ZERO=0 keep the launches.  Three
-    bf16 steps each way: bit-identical weights,
-    moments, gradients and scalars."""
+@pytest.mark.parametrize("family,B,inkernel,env", [("dcgan", 64, False, {}), ("dcgan", 64, True, {}), ("cgan", 32, True, {}), ("dcgan", 24, False, {}),
+                                                   ("dcgan", 40, True, {"JCK_BATCHED": "0"})])
+def test_launches_folded_into_their_neighbours_leave_the_step_bit_for_bit(family, B, inkernel, env, monkeypatch):
+    """Round 4 folds small launches into their neighbours: D.zero_grad() into the step's set-step launch, G.zero_grad() into D's
+    Adam launch, the tanh + noise-mix backward of G's output into the epilogue of D.conv1's input gradient (on the value as the
+    separate launch read it: rounded to bf16 first).  JCK_FOLD_ZERO=0 / JCK_FUSE_TANH=0 keep the launches.  Three bf16 steps each
+    way, with explicit noise tensors and with the instance noise drawn inside the kernels (as the trainers and bench.py run):
+    bit-identical weights, moments, gradients and scalars (batched schedule, CGAN, per-pass schedule)."""
     import bf16_error as be
     from hipgan.engine import CganEngine, DcganEngine
     from oracle.gan_oracle import build_params
     from util import synth_images
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     torch.manual_seed(12345)
     g, d = build_params(family)
     imgs = synth_images(B * 3)
     runs = []
     for plain in (False, True):
-        monkeypatch.setenv("JCK_FUSE_TANH", "0" if plain else "1")
-        monkeypatch.setenv("JCK_FOLD_ZERO", "0" if plain else "1")
+        for k in ("JCK_FUSE_TANH", "JCK_FOLD_ZERO"):
+            monkeypatch.setenv(k, "0" if plain else "1")
         eng = (CganEngine if family == "cgan" else DcganEngine)(batch=B, prec="bf16")
         eng.load_state(g, d)
+        eng.set_noise_seed(4242)
         sc = []
         for s in range(3):
             lab = be.labels_for(B, 5 + s) if family == "cgan" else None
-            nz = be.noise_for(family, B, 40 + s, lab)
-            sc.append(eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4))
+            real = imgs[s * B:(s + 1) * B].cuda()
+            if inkernel:
+                eng.step_async(real, None, 2e-4, labels=lab.cuda() if lab is not None else None)
+                sc.append(eng.scalars())
+            else:
+                nz = be.noise_for(family, B, 40 + s, lab)
+                sc.append(eng.step(real, {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4))
         torch.cuda.synchronize()
-        runs.append((sc, {k: v.clone() for k, v in eng.arenas.items()}))
-    (s0, a0), (s1, a1) = runs
+        runs.append((sc, {k: v.clone() for k, v in eng.arenas.items()}, eng.tensor("fake").clone()))
+    (s0, a0, f0), (s1, a1, f1) = runs
     assert s0 == s1, (s0, s1)
+    assert torch.equal(f0, f1)
     for k in a0:
         assert torch.equal(a0[k], a1[k]), k
 
