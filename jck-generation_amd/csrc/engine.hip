@@ -435,7 +435,8 @@ extern "C" int jck_engine_bind(jck_engine* e, void* workspace, size_t ws_bytes, 
 }
 
 // all conv operands of one network in one launch (ew.hpp: pack_multi_kernel); the two Linear operands of CGAN's D follow
-static int repack_convs(jck_engine* e, int net, void* stream) {
+// tail (optional): the end-of-step job rides in the same launch (ew.hpp: pack_tail_kernel)
+static int repack_convs(jck_engine* e, int net, void* stream, const TailJobs* tail = nullptr, int tail_x = 0) {
   PackJobs jobs = {};
   int n = 0, chunk = 0;
   auto add = [&](int kind, const float* w, void* wp, long long total, int a, int b, int c) {
@@ -468,7 +469,11 @@ static int repack_convs(jck_engine* e, int net, void* stream) {
   }
   jobs.first_chunk[n] = chunk;
   jobs.n = n;
-  if (e->prec == JCK_PREC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
+  if (tail) {
+    const int nblk = chunk + tail_x * (tail->nl + 1);
+    if (e->prec == JCK_PREC_BF16) hipLaunchKernelGGL(pack_tail_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, jobs, chunk, *tail, tail_x);
+    else hipLaunchKernelGGL(pack_tail_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, jobs, chunk, *tail, tail_x);
+  } else if (e->prec == JCK_PREC_BF16) hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
   else hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(chunk), dim3(256), 0, (hipStream_t)stream, jobs);
   HIPCHK(hipGetLastError());
   return JCK_OK;
@@ -574,19 +579,36 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
 // The head backward of the real | fake | penalty groups as ONE pass over 3B rows (forward: cg_head_forward(rows = 3B)): input
 // gradients for all three, parameter gradients from the first two (the penalty's come from its double backward, PHASE_D_GP).
 // 11 launches instead of 26; the penalty group's rows [2B, 3B) stay behind as gp_double_backward expects them.
-static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const float* drop_mask, void* ga4_out, hipStream_t st) {
+// side (optional): the parameter gradients of the head (linear2, linear1, the label embedding: 8 launches, ~80 us that only the
+// optimiser waits for) run on the weight-gradient stream - idle at this point of the step - beside the chain that carries the input
+// gradient down to the conv stack; evHead marks their end on that stream (PHASE_D_GP's main-stream writers of the same gradients
+// wait for it).
+static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const float* drop_mask, void* ga4_out, hipStream_t st,
+                                    hipStream_t side = nullptr) {
   const int R3 = 3 * B, R2 = 2 * B;
   const float* w2 = e->P(e->LD, e->dp, "linear2.weight");
+  hipStream_t ws = st;
+  auto fork = [&](int k) -> int {                     // `ws` work enqueued from here on starts behind everything on st so far
+    if (!side) return JCK_OK;
+    HIPCHK(hipEventRecord(e->evW[k], st));
+    HIPCHK(hipStreamWaitEvent(side, e->evW[k], 0));
+    ws = side;
+    return JCK_OK;
+  };
   JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R3, L1_OUT, e->g_hd, nullptr, 1, e->head_ws, st));
-  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, st));
-  JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), st));
+  JCK_TRY(fork(0));
+  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
+  JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), ws));
   JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)R3 * L1_OUT, st));
-  JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, R2, L1_OUT, st));
-  JCK_TRY(jck_colsum(e->prec, e->g_h, R2, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
+  JCK_TRY(fork(1));
+  JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, R2, L1_OUT, ws));
+  JCK_TRY(jck_colsum(e->prec, e->g_h, R2, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), ws));
   JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, R3, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
-  JCK_TRY(jck_split_rows(e->prec, e->gc, L1_KPAD, TT.FEAT, ga4_out, R3, st));
-  return jck_label_embed_bwd_tiled(e->prec, e->gc, L1_KPAD, TT.FEAT, e->pre_e, e->cur_labels, LRELU, R2, N_CLASS, EMB,
-                                   e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), B, st);
+  JCK_TRY(fork(2));
+  JCK_TRY(jck_label_embed_bwd_tiled(e->prec, e->gc, L1_KPAD, TT.FEAT, e->pre_e, e->cur_labels, LRELU, R2, N_CLASS, EMB,
+                                    e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), B, ws));
+  if (side) HIPCHK(hipEventRecord(e->evHead, side));
+  return jck_split_rows(e->prec, e->gc, L1_KPAD, TT.FEAT, ga4_out, R3, st);
 }
 
 // D backward on set `D`.  With `side` != nullptr the weight-gradient products run on that stream beside the dgrad chain
@@ -791,6 +813,9 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   // the first backward's gradient at the Linear(8392,256) output and the penalty pass's probabilities: read in place after a
   // batched head (its penalty rows [2B, 3B) are not written again: the head backward below writes rows [0, B)), copied aside
   // otherwise (the per-pass head backward below overwrites g_h)
+  // the head's parameter gradients of PHASE_D_LOSS may still be queued on the weight-gradient stream (cg_head_backward_batched, no
+  // join in between under JCK_PHASE_LAZY_JOIN): this pass adds to the same tensors from the main stream
+  if (side) (void)hipStreamWaitEvent(st, e->evHead, 0);
   const void* gh1 = e->gh_b1;
   const float* prob1 = e->prob_gp;
   if (e->head_row0 > 0) {
@@ -1054,7 +1079,8 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           if (!head3) JCK_TRY(d_head_backward(e, e->dset[0], S.ds + g * B, B, !pen, in->drop_mask[g], g4, st));
         }
         if (head3) {
-          JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st));
+          static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
+          JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st, head_side ? sA : nullptr));
           e->head_row0 = 2 * B;                        // where PHASE_D_GP finds the penalty group's head state
           e->head_wrow0 = 0;
         }
@@ -1203,8 +1229,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
     case JCK_PHASE_G_STEP: {                                                                      // :189
       if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
       JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
-      JCK_TRY(jck_engine_repack(e, 0, st));
-      {   // the four D passes' BatchNorm records in the reference's order + the logged scalars, one launch
+      {   // G's repack, the four D passes' BatchNorm records in the reference's order and the logged scalars: one launch
         TailJobs t = {};
         for (int i = 0; i < TT.NS; ++i) {
           const int cs = TT.D_CS[i];
@@ -1215,8 +1240,7 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
           t.l[i].C = cs;
         }
         t.nl = TT.NS; t.npass = 4; t.momentum = BN_MOM; t.acc = e->acc; t.acc_ld = e->acc_ld; t.B = B; t.invB = 1.0f / (float)B; t.lambda_gp = 10.0f; t.out = e->scal_out;
-        hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(TT.G_C1, 256), TT.NS + 1), dim3(256), 0, st, t);
-        HIPCHK(hipGetLastError());
+        JCK_TRY(repack_convs(e, 0, st, &t, cdiv(TT.G_C1, 256)));
       }
       return JCK_OK;
     }

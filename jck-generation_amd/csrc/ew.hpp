@@ -806,11 +806,11 @@ static __global__ void pack_head_kernel(const float* __restrict__ w, int C, floa
 struct PackJob { const float* w; void* wp; long long total; int kind, a, b, c; };   // kind: 0 down 1 up 2 up16 3 g1 4 head
 struct PackJobs { PackJob j[PACK_MAX_JOBS]; int first_chunk[PACK_MAX_JOBS + 1]; int n; };
 template <typename W>
-__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
+__device__ __forceinline__ void pack_multi_block(const PackJobs& jobs, int bx) {
   int ji = 0;
-  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.first_chunk[ji + 1]) ++ji;
+  while (ji + 1 < jobs.n && bx >= jobs.first_chunk[ji + 1]) ++ji;
   const PackJob& J = jobs.j[ji];
-  const long long u = (long long)(blockIdx.x - jobs.first_chunk[ji]) * PACK_CHUNK + threadIdx.x;
+  const long long u = (long long)(bx - jobs.first_chunk[ji]) * PACK_CHUNK + threadIdx.x;
   if (u >= J.total) return;
   W* wp = reinterpret_cast<W*>(J.wp);
   float v[16];
@@ -869,6 +869,8 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) {
     } break;
   }
 }
+template <typename W>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobs jobs) { pack_multi_block<W>(jobs, (int)blockIdx.x); }
 
 template <typename T>
 __global__ void cast_f32_kernel(const float* __restrict__ in, T* __restrict__ out, long long n) {
@@ -900,9 +902,9 @@ struct TailLayer { const float* rec; float* rm; float* rv; long long* nbt; int C
 // acc is the per-image table [7][acc_ld] (head_fwd / gp_norm write one entry per image): each row is summed here in a fixed
 // order (thread-strided partial sums, wavefront shuffles, 4 wave totals), so the logged scalars are bitwise reproducible.
 struct TailJobs { TailLayer l[5]; int nl; int npass; float momentum; const float* acc; int acc_ld, B; float invB, lambda_gp; float* out; };
-static __global__ __launch_bounds__(256) void step_tail_kernel(const TailJobs t) {
-  if ((int)blockIdx.y == t.nl) {
-    if (blockIdx.x != 0) return;
+__device__ __forceinline__ void step_tail_block(const TailJobs& t, int bx, int by) {
+  if (by == t.nl) {
+    if (bx != 0) return;
     __shared__ float sm[4];
     float tot[7];
 #pragma unroll
@@ -924,8 +926,8 @@ static __global__ __launch_bounds__(256) void step_tail_kernel(const TailJobs t)
     }
     return;
   }
-  const TailLayer& L = t.l[blockIdx.y];
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const TailLayer& L = t.l[by];
+  const int c = bx * blockDim.x + threadIdx.x;
   if (c == 0 && L.nbt) *L.nbt += t.npass;
   if (c >= L.C) return;
   float rm = L.rm[c], rv = L.rv[c];
@@ -935,6 +937,14 @@ static __global__ __launch_bounds__(256) void step_tail_kernel(const TailJobs t)
   }
   L.rm[c] = rm;
   L.rv[c] = rv;
+}
+// G's repack and the end of the step in one launch (two independent jobs at the very end of the step, each near the launch
+// floor): workgroups [0, pack_chunks) repack, the next tail_x * (nl + 1) are step_tail_block's grid (tail_x, nl + 1) row-major
+template <typename W>
+__global__ __launch_bounds__(256) void pack_tail_kernel(const PackJobs jobs, int pack_chunks, const TailJobs t, int tail_x) {
+  if ((int)blockIdx.x < pack_chunks) { pack_multi_block<W>(jobs, (int)blockIdx.x); return; }
+  const int q = (int)blockIdx.x - pack_chunks;
+  step_tail_block(t, q % tail_x, q / tail_x);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -117,7 +117,7 @@ def main():
     tr = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"], r["Kernel_Name"], r["Grid_Size_X"])
           for r in csv.DictReader(open(os.path.join(SRC, "bench_kernel_trace.csv")))]
     tr.sort()
-    marks = [e[0] for e in tr if "step_tail" in e[3]]
+    marks = [e[0] for e in tr if "step_tail" in e[3] or "pack_tail" in e[3]]
     if len(marks) >= 3:
         a, b = marks[-3], marks[-2]
         lines = [f"# one traced step of `bench.py` ({(b - a) / 1e3:.1f} us under rocprofv3): start us | duration us | HIP stream | kernel | grid"]
