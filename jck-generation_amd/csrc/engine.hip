@@ -549,7 +549,9 @@ static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slo
 }
 
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
-static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st) {
+// side (family 1, optional): the parameter gradients run there (see cg_head_backward_batched)
+static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st,
+                           hipStream_t side = nullptr) {
   if (e->family == 0)
     return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, ga4_out, want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr,
                              e->head_ws, st);
@@ -560,20 +562,34 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
   void *h_drop = hb(e->h_drop, r0, L1_OUT), *cbuf = hb(e->cbuf, r0, L1_KPAD);
   void *g_hd = hb(e->g_hd, w0, L1_OUT), *g_h = hb(e->g_h, w0, L1_OUT), *gc = hb(e->gc, w0, L1_KPAD);
   const float* pre_e = e->pre_e + r0 * EMB;
-  JCK_TRY(jck_head_bwd(e->prec, ds, e->P(e->LD, e->dp, "linear2.weight"), h_drop, B, L1_OUT, g_hd,
-                       want_wgrad ? e->P(e->LD, e->dg, "linear2.weight") : nullptr, 1, e->head_ws, st));
-  if (want_wgrad) JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), st));
+  hipStream_t ws = st;
+  auto fork = [&](int k) -> int {                     // `ws` work enqueued from here on starts behind everything on st so far
+    if (!side || !want_wgrad) return JCK_OK;
+    HIPCHK(hipEventRecord(e->evW[k], st));
+    HIPCHK(hipStreamWaitEvent(side, e->evW[k], 0));
+    ws = side;
+    return JCK_OK;
+  };
+  const float* w2 = e->P(e->LD, e->dp, "linear2.weight");
+  JCK_TRY(jck_head_bwd(e->prec, ds, w2, h_drop, B, L1_OUT, g_hd, nullptr, 1, e->head_ws, st));
+  if (want_wgrad) {
+    JCK_TRY(fork(0));
+    JCK_TRY(jck_head_bwd(e->prec, ds, w2, h_drop, B, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
+    JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), ws));
+  }
   JCK_TRY(jck_dropout(e->prec, g_hd, drop_mask, 1.0f / 0.75f, g_h, (long long)B * L1_OUT, st));
   if (want_wgrad) {
-    JCK_TRY(jck_linear_wgrad(e->prec, g_h, L1_OUT, cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, st));
-    JCK_TRY(jck_colsum(e->prec, g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), st));
+    JCK_TRY(fork(1));
+    JCK_TRY(jck_linear_wgrad(e->prec, g_h, L1_OUT, cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, ws));
+    JCK_TRY(jck_colsum(e->prec, g_h, B, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), ws));
   }
   JCK_TRY(jck_linear_fwd(e->prec, g_h, e->l1_wT, nullptr, gc, B, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
-  JCK_TRY(jck_split_rows(e->prec, gc, L1_KPAD, TT.FEAT, ga4_out, B, st));
-  if (want_wgrad)
+  if (want_wgrad) {
+    JCK_TRY(fork(2));
     JCK_TRY(jck_label_embed_bwd(e->prec, gc, L1_KPAD, TT.FEAT, pre_e, e->cur_labels, LRELU, B, N_CLASS, EMB,
-                                e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), st));
-  return JCK_OK;
+                                e->P(e->LD, e->dg, "label_embedding.weight"), e->P(e->LD, e->dg, "label_embedding.bias"), ws));
+  }
+  return jck_split_rows(e->prec, gc, L1_KPAD, TT.FEAT, ga4_out, B, st);
 }
 
 // The head backward of the real | fake | penalty groups as ONE pass over 3B rows (forward: cg_head_forward(rows = 3B)): input
@@ -843,11 +859,17 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   JCK_TRY(jck_linear_wgrad(e->prec, gh1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
-  JCK_TRY(jck_gp_head2(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
-                       e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st));
+  // (the head's parameter gradients - the dw2 sum here, linear2 / linear1 / the label embedding in d_head_backward below: ~75 us of
+  // launches that only the optimiser waits for - go to the weight-gradient stream; JCK_HEAD_SIDE=0 keeps them on the main one)
+  static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
+  hipStream_t hs = head_side && e->ext_events ? side : nullptr;
+  JCK_TRY(gp_head2_ev(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
+                      e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st, hs, hs ? e->evHead : nullptr));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
   join();
-  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st));
+  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st, hs));
+  // the last sum into the permuted Linear gradient is enqueued: back to the reference's layout, on the stream that holds it
+  JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, hs ? hs : st));
   for (int i = TT.NS - 1; i >= 0; --i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
@@ -1175,7 +1197,6 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         JCK_TRY(gp_double_backward(e, gp_src_group(e, 2, B), e->xhat, B, 10.0f, in->drop_mask[2], st, sA, lazy));
         if (!(lazy && sA)) e->join_pending = e->mid_recorded = false;      // it joined the stream itself
         e->head_row0 = 0;
-        JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
         return JCK_OK;
       }
       if (e->gp_done) { e->gp_done = false; return JCK_OK; }    // computed inside the batched pass of PHASE_D_LOSS
@@ -1187,7 +1208,6 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
       JCK_TRY(penalty_pass(D0, st));
       if (cg) {                                      // CGAN back-propagates the penalty (train/cgan_trainer.py:200-203)
         JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 10.0f, in->drop_mask[2], st, sA));
-        JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, st));
       }
       return JCK_OK;
     }

@@ -1219,16 +1219,23 @@ extern "C" int jck_gp_grad(int prec, const void* g, const float* norms, float co
 // ws: float[B + jck_head_bwd_ws_floats(K)] (pq[n] = p(1-p), then the partial rows of the dw2 sum)
 extern "C" int jck_gp_head2(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2,
                             float* ws, void* stream) {
+  return gp_head2_ev(prec, ughd, w2, prob, B, K, rs, dw2, ws, (hipStream_t)stream, nullptr, nullptr);
+}
+// side / handover (both or neither): the dw2 sum - wanted by the optimiser only - runs on `side` behind `handover`, which the
+// launch that writes rs and pq completes itself
+int gp_head2_ev(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, float* ws,
+                hipStream_t stream, hipStream_t side, hipEvent_t handover) {
   if (K % 8 || !ws) JCK_FAIL(JCK_E_ARG, "gp_head2: K % 8 != 0 or no workspace");
-  DISPATCH_T(prec, hipLaunchKernelGGL(gp_head2_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, (const T*)ughd, w2, prob, B, K,
-                                      rs, ws));
+  if ((side != nullptr) != (handover != nullptr)) JCK_FAIL(JCK_E_ARG, "gp_head2: side stream and hand-over event go together");
+  DISPATCH_T(prec, LAUNCH_EV(gp_head2_kernel<T>, dim3(B), dim3(256), 0, stream, handover, (const T*)ughd, w2, prob, B, K, rs, ws));
   HIPCHK(hipGetLastError());
+  hipStream_t gs = stream;
+  if (side) { HIPCHK(hipStreamWaitEvent(side, handover, 0)); gs = side; }
   // dw2[j] += sum_n pq[n] * ughd[n][j]
   float* part = ws + (B + 63) / 64 * 64;
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_NS), dim3(256), 0, (hipStream_t)stream, ws,
-                                      (const T*)ughd, B, K, part));
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_NS), dim3(256), 0, gs, ws, (const T*)ughd, B, K, part));
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, part, HEAD_NS, K, 0, dw2, 1);
+  hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, gs, part, HEAD_NS, K, 0, dw2, 1);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

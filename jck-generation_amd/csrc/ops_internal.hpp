@@ -53,4 +53,6 @@ int conv_up_tanh_bwd_ev(int prec, const void* small_in, const void* w, const voi
                         int Cs, int Cb, hipStream_t stream, hipEvent_t done, bool* fused);
 int head_bwd_conv2_ev(int prec, const float* ds, const float* wp, const void* a4, int B, int B_more, int C, void* g_a4, float* grad, float* ws,
                       hipStream_t stream, hipStream_t side, hipEvent_t handover);
+int gp_head2_ev(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, float* ws,
+                hipStream_t stream, hipStream_t side, hipEvent_t handover);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);
