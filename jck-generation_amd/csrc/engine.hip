@@ -168,6 +168,7 @@ struct jck_engine {
   bool ext_events = true;
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
+  bool cbuf_direct = true;              // CGAN: D's last BatchNorm+LeakyReLU writes straight into the head's concat buffer (JCK_CBUF_DIRECT=0: a copy)
   bool fold_zero = true;                // zero_grad() of both networks inside neighbouring launches (JCK_FOLD_ZERO=0: memsets)
   bool fuse_tanh = true;                // G's loss pass: tanh backward in the epilogue of D.conv1's input gradient (JCK_FUSE_TANH=0: a launch of its own)
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
@@ -350,6 +351,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->carve(nullptr);
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
+  e->cbuf_direct = family == 1 && !(getenv("JCK_CBUF_DIRECT") && atoi(getenv("JCK_CBUF_DIRECT")) == 0);
   e->fold_zero = !(getenv("JCK_FOLD_ZERO") && atoi(getenv("JCK_FOLD_ZERO")) == 0);
   e->fuse_tanh = !(getenv("JCK_FUSE_TANH") && atoi(getenv("JCK_FUSE_TANH")) == 0);
   if (e->overlap) {
@@ -480,9 +482,7 @@ static int repack_convs(jck_engine* e, int net, void* stream, const TailJobs* ta
 }
 static int repack_linear(jck_engine* e, void* stream) {
   const float* w1 = e->P(e->LD, e->dp, "linear1.weight");
-  JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, 0, 512, 16, e->l1_w, stream));
-  JCK_TRY(jck_pack_linear(e->prec, w1, L1_OUT, L1_K, L1_KPAD, L1_OUT, 1, 512, 16, e->l1_wT, stream));
-  return JCK_OK;
+  return pack_linear_pair(e->prec, w1, L1_OUT, L1_K, L1_OUT, L1_KPAD, e->l1_w, L1_KPAD, L1_OUT, e->l1_wT, 512, 16, (hipStream_t)stream);
 }
 extern "C" int jck_engine_repack(jck_engine* e, int net, void* stream) {
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
@@ -502,7 +502,9 @@ typedef jck_engine::DSet DSet;
 // conv stack of D on activation set `D`; BatchNorm running statistics are NOT touched here: (mean, unbiased var) go to the
 // deferred record of `pass` (0 real, 1 fake, 2 penalty, 3 G phase) and are applied in that order at the end of the step,
 // which keeps the result bitwise independent of how the passes overlap on streams.
-static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st) {
+// to_cbuf (CGAN): the last layer's activation goes to rows [0, B) of the head's concat buffer instead of D.a (cg_head_forward then
+// has nothing to copy)
+static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, hipStream_t st, bool to_cbuf = false) {
   const void* in = x_in;
   for (int i = 0; i < TT.NS; ++i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
@@ -512,7 +514,8 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
-    JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
+    if (to_cbuf && i == TT.NS - 1) JCK_TRY(bn_act_fwd_pitched(e->prec, D.y[i], D.bn[i].aux, LRELU, e->cbuf, rows, cs, 1, TT.FEAT, L1_KPAD, st));
+    else JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
     in = D.a[i];
   }
   return JCK_OK;
@@ -525,7 +528,7 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 // [B][256] masks back to back)
 static int cg_head_forward(jck_engine* e, const void* a4, int rows, const float* drop_mask, hipStream_t st, int label_period = 0) {
   if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
-  JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, rows, st));
+  if (a4) JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, rows, st));      // null: the conv stack wrote the rows itself
   JCK_TRY(jck_label_embed_fwd_tiled(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
                                     e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, rows, N_CLASS, EMB, e->cbuf, L1_KPAD, TT.FEAT,
                                     e->pre_e, label_period, st));
@@ -535,8 +538,9 @@ static int cg_head_forward(jck_engine* e, const void* a4, int rows, const float*
 }
 
 static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
-  JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st));
-  if (e->family == 1) return cg_head_forward(e, e->d_a[TT.NS - 1], B, drop_mask, st);
+  const bool direct = e->family == 1 && e->cbuf_direct;
+  JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st, direct));
+  if (e->family == 1) return cg_head_forward(e, direct ? nullptr : e->d_a[TT.NS - 1], B, drop_mask, st);
   return JCK_OK;
 }
 
@@ -674,7 +678,7 @@ static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want
 // contribute weight gradients; the LAST group is the penalty pass (head mode 1, gradient w.r.t. its input image -> dset[0].gx,
 // norms -> dset[0].norms).  Group g writes BatchNorm record pass0 + g.  Weight gradients run on `side`.
 // forward of the conv stack for groups [g0, g0 + n) of the batched set (x_in = first image of group g0); own slot range
-static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int n, int pass0, hipStream_t st) {
+static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int n, int pass0, hipStream_t st, bool to_cbuf = false) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   auto at = [&](void* p, size_t elems) { return (void*)((unsigned char*)p + elems * esz); };
@@ -689,8 +693,12 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
-    JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
-                                   at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
+    if (to_cbuf && i == TT.NS - 1)      // CGAN: rows [g0 * B, (g0 + n) * B) of the head's concat buffer
+      JCK_TRY(bn_act_fwd_pitched(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
+                                 at(e->cbuf, (size_t)g0 * B * L1_KPAD), rows, cs, n, TT.FEAT, L1_KPAD, st));
+    else
+      JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
+                                     at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
     in = at(S.a[i], (size_t)g0 * rows * cs);
   }
   return JCK_OK;
@@ -1076,14 +1084,15 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         JCK_TRY(prep_real(e, in, B, st));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
-        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st));
-        auto& S = e->bset;
-        const float tg[2] = {0.9f, 0.1f};
         // the three dropout masks back to back (hipgan/engine.py hands them over that way): the head runs once over 3B rows
         const bool head3 = in->drop_mask[0] && in->drop_mask[1] == in->drop_mask[0] + (size_t)B * L1_OUT &&
                            in->drop_mask[2] == in->drop_mask[0] + (size_t)2 * B * L1_OUT;
+        const bool direct = head3 && e->cbuf_direct;
+        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st, direct));
+        auto& S = e->bset;
+        const float tg[2] = {0.9f, 0.1f};
         e->head_row0 = 0;
-        if (head3) JCK_TRY(cg_head_forward(e, S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B));
+        if (head3) JCK_TRY(cg_head_forward(e, direct ? nullptr : S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B));
         if (head3) {
           const float tg3[3] = {tg[0], tg[1], 0.f};
           const int md3[3] = {0, 0, 1}, sl3[3] = {0, 1, -1}, sp3[3] = {3, 4, -1};

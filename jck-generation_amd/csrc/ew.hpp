@@ -313,11 +313,14 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
 }
 
 // a = act(scale[c]*y + shift[c]), act = x>0 ? x : slope*x
+// pitch > 0: the output rows of 2^log_row elements are written `pitch` elements apart - the last layer of CGAN's D lands in the
+// concat buffer of the Linear head ([rows][8448], model/CGAN.py:119-121) without a copy
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ aux, float slope,
-                                  T* __restrict__ a, long long total8, int C) {
+                                  T* __restrict__ a, long long total8, int C, int log_row = 0, long long pitch = 0) {
   __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
-  y += (long long)blockIdx.y * total8 * 8; a += (long long)blockIdx.y * total8 * 8; aux += (long long)blockIdx.y * 4 * C;   // group
+  const long long g0 = (long long)blockIdx.y * total8 * 8;      // first element of this group
+  y += g0; aux += (long long)blockIdx.y * 4 * C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)((i * 8) & (C - 1));
     float v[8];
@@ -327,7 +330,8 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
       const float z = v[k] * aux[c + k] + aux[C + c + k];
       v[k] = z > 0.f ? z : slope * z;
     }
-    st8(a + i * 8, v);
+    const long long e = g0 + i * 8;
+    st8(a + (pitch ? (e >> log_row) * pitch + (e & ((1ll << log_row) - 1)) : e), v);
   }
 }
 
@@ -958,6 +962,28 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const PackJobs jobs, int
 template <typename W>
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, int rows, int cols, int transpose, int permC,
                                    int permHW, W* __restrict__ wp) {
+  const long long total = (long long)rows * cols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const int n = transpose ? c : r, kp = transpose ? r : c;
+    float v = 0.f;
+    if (n < N && kp < K) {
+      int k = kp;
+      if (permC > 0 && kp < permC * permHW) { const int hw = kp / permC, ch = kp % permC; k = ch * permHW + hw; }
+      v = w[(long long)n * K + k];
+    }
+    stf(wp + i, v);
+  }
+}
+
+// both layouts of one nn.Linear weight in ONE launch: blockIdx.y = 0 the forward operand wp0[rows0][cols0], 1 the dgrad operand
+// wp1[rows1][cols1] (pack_linear_kernel with transpose = blockIdx.y)
+template <typename W>
+__global__ void pack_linear_pair_kernel(const float* __restrict__ w, int N, int K, int rows0, int cols0, W* __restrict__ wp0, int rows1,
+                                        int cols1, W* __restrict__ wp1, int permC, int permHW) {
+  const int transpose = blockIdx.y;
+  const int rows = transpose ? rows1 : rows0, cols = transpose ? cols1 : cols0;
+  W* wp = transpose ? wp1 : wp0;
   const long long total = (long long)rows * cols;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i % cols);

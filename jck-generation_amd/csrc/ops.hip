@@ -727,11 +727,18 @@ extern "C" int jck_bn_finalize_grouped(const float* stats, int slots_per_group, 
 }
 extern "C" int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group,
                                       int C, int groups, void* stream) {
+  return bn_act_fwd_pitched(prec, y, aux, slope, a, rows_per_group, C, groups, 0, 0, (hipStream_t)stream);
+}
+// out_pitch > 0: every out_row (a power of two, >= 8) elements of the output start out_pitch elements apart (ew.hpp)
+int bn_act_fwd_pitched(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group, int C, int groups,
+                       long long out_row, long long out_pitch, hipStream_t stream) {
   if (!is_pow2(C) || C < 8 || groups < 1) JCK_FAIL(JCK_E_ARG, "bn_act_fwd_grouped: C must be a power of two >= 8");
+  if (out_pitch && (out_row < 8 || (out_row & (out_row - 1)) || out_pitch < out_row || out_pitch % 8))
+    JCK_FAIL(JCK_E_ARG, "bn_act_fwd: a pitched output needs rows of a power of two >= 8 elements, pitch >= row, pitch % 8 == 0");
   const long long total8 = rows_per_group * C / 8;
-  ProfScope prof(PROF_BN_ACT_FWD, 0.0, (hipStream_t)stream, 2.0 * groups * rows_per_group * C * (prec == JCK_PREC_F32 ? 4 : 2));
-  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, (hipStream_t)stream,
-                                      (const T*)y, aux, slope, (T*)a, total8, C));
+  ProfScope prof(PROF_BN_ACT_FWD, 0.0, stream, 2.0 * groups * rows_per_group * C * (prec == JCK_PREC_F32 ? 4 : 2));
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total8), groups), dim3(256), 0, stream,
+                                      (const T*)y, aux, slope, (T*)a, total8, C, out_pitch ? ilog2((int)out_row) : 0, out_pitch));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1097,6 +1104,16 @@ extern "C" int jck_pack_linear(int prec, const float* w, int N, int K, int rows,
   const long long total = (long long)rows * cols;
   DISPATCH_T(prec, hipLaunchKernelGGL(pack_linear_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, N, K, rows,
                                       cols, transpose, permC, permHW, (T*)wp));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
+// jck_pack_linear(transpose = 0) into wp0[rows0][cols0] and jck_pack_linear(transpose = 1) into wp1[rows1][cols1], one launch
+int pack_linear_pair(int prec, const float* w, int N, int K, int rows0, int cols0, void* wp0, int rows1, int cols1, void* wp1, int permC,
+                     int permHW, hipStream_t stream) {
+  const long long total = std::max((long long)rows0 * cols0, (long long)rows1 * cols1);
+  DISPATCH_T(prec, hipLaunchKernelGGL(pack_linear_pair_kernel<T>, dim3(ew_grid(total), 2), dim3(256), 0, stream, w, N, K, rows0, cols0,
+                                      (T*)wp0, rows1, cols1, (T*)wp1, permC, permHW));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

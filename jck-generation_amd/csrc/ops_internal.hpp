@@ -55,4 +55,8 @@ int head_bwd_conv2_ev(int prec, const float* ds, const float* wp, const void* a4
                       hipStream_t stream, hipStream_t side, hipEvent_t handover);
 int gp_head2_ev(int prec, const void* ughd, const float* w2, const float* prob, int B, int K, float* rs, float* dw2, float* ws,
                 hipStream_t stream, hipStream_t side, hipEvent_t handover);
+int pack_linear_pair(int prec, const float* w, int N, int K, int rows0, int cols0, void* wp0, int rows1, int cols1, void* wp1, int permC,
+                     int permHW, hipStream_t stream);
+int bn_act_fwd_pitched(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group, int C, int groups,
+                       long long out_row, long long out_pitch, hipStream_t stream);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);
