@@ -169,6 +169,7 @@ struct jck_engine {
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
   bool cbuf_direct = true;              // CGAN: D's last BatchNorm+LeakyReLU writes straight into the head's concat buffer (JCK_CBUF_DIRECT=0: a copy)
+  bool real_side = true;                // batched D pass: D(real)'s forward beside G's forward on the weight-gradient stream (JCK_REAL_SIDE=0: one 3B forward)
   bool fold_zero = true;                // zero_grad() of both networks inside neighbouring launches (JCK_FOLD_ZERO=0: memsets)
   bool fuse_tanh = true;                // G's loss pass: tanh backward in the epilogue of D.conv1's input gradient (JCK_FUSE_TANH=0: a launch of its own)
   void *g_z, *g_y[JCK_MAX_STAGES], *g_a[JCK_MAX_STAGES], *g_gr[JCK_MAX_STAGES], *fake_raw, *fake, *g_raw;
@@ -352,6 +353,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
   e->cbuf_direct = family == 1 && !(getenv("JCK_CBUF_DIRECT") && atoi(getenv("JCK_CBUF_DIRECT")) == 0);
+  e->real_side = !(getenv("JCK_REAL_SIDE") && atoi(getenv("JCK_REAL_SIDE")) == 0);
   e->fold_zero = !(getenv("JCK_FOLD_ZERO") && atoi(getenv("JCK_FOLD_ZERO")) == 0);
   e->fuse_tanh = !(getenv("JCK_FUSE_TANH") && atoi(getenv("JCK_FUSE_TANH")) == 0);
   if (e->overlap) {
@@ -1081,14 +1083,22 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         if ((!in->real_nchw && !in->real_u8) || !in->z || !in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_LOSS needs real_nchw (or real_u8), z and alpha");
         JCK_TRY(clear_acc(e, in->step, st));
         JCK_TRY(zero_d_grads(e, in->step, st));
-        JCK_TRY(prep_real(e, in, B, st));
-        JCK_TRY(g_forward(e, in->z, in->labels, B, st));
-        JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
         // the three dropout masks back to back (hipgan/engine.py hands them over that way): the head runs once over 3B rows
         const bool head3 = in->drop_mask[0] && in->drop_mask[1] == in->drop_mask[0] + (size_t)B * L1_OUT &&
                            in->drop_mask[2] == in->drop_mask[0] + (size_t)2 * B * L1_OUT;
         const bool direct = head3 && e->cbuf_direct;
-        JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st, direct));
+        // D(real)'s conv stack beside G's forward, [fake | penalty] as a 2B forward behind it (see the DCGAN branch below)
+        const bool split = e->real_side, beside = split && sA;
+        hipStream_t sr = beside ? sA : st;
+        if (beside) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(sA, e->ev0, 0)); }
+        JCK_TRY(prep_real(e, in, B, sr));
+        if (split) JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr, direct));
+        if (beside) HIPCHK(hipEventRecord(e->evReal, sA));
+        JCK_TRY(g_forward(e, in->z, in->labels, B, st));
+        if (beside) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
+        JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
+        if (split) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st, direct));
+        else JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 3, 0, st, direct));
         auto& S = e->bset;
         const float tg[2] = {0.9f, 0.1f};
         e->head_row0 = 0;
@@ -1134,13 +1144,26 @@ extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs*
         e->real_fwd_step = -1;
         JCK_TRY(clear_acc(e, in->step, st));
         JCK_TRY(zero_d_grads(e, in->step, st));                                                   // D.zero_grad()  :155
-        if (!pre) JCK_TRY(prep_real(e, in, B, st));   // :160
+        // D(real)'s forward needs nothing of G, and G's forward is a chain of small launches that leaves most of the chip idle: the
+        // real batch's input transform and conv stack run on the weight-gradient stream (idle at the start of a step) beside it,
+        // [fake | penalty] follow as one 2B forward - the split PHASE_D_REAL_FWD makes across steps; the arithmetic of the 3B forward
+        // (a batch's BatchNorm statistics may be split into partial sums differently: summation order only)
+        // (1.632 -> 1.609 ms; JCK_REAL_SIDE=0: one 3B forward behind G's)
+        // (the split does not depend on the stream layout: a captured, one-stream step is the same arithmetic launch for launch)
+        const bool split = pre || e->real_side;
+        const bool beside = !pre && e->real_side && sA;
+        hipStream_t sr = beside ? sA : st;
+        if (beside) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(sA, e->ev0, 0)); }
+        if (!pre) JCK_TRY(prep_real(e, in, B, sr));                                               // :160
+        if (!pre && split) JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr));          // :162
+        if (beside) HIPCHK(hipEventRecord(e->evReal, sA));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
+        if (beside) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));                                             // :171, :111-113
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
-        if (pre) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                          // :173, 118 as one 2B forward
-        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, pre, part));        // :162-176, 178
+        if (split) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                        // :173, 118 as one 2B forward
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, split, part));      // :162-176, 178
         if (part == 0) e->gp_done = true;
         return JCK_OK;
       }

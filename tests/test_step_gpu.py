@@ -317,6 +317,74 @@ def test_launches_folded_into_their_neighbours_leave_the_step_bit_for_bit(family
         assert torch.equal(a0[k], a1[k]), k
 
 
+@pytest.mark.parametrize("B,prec", [(64, "bf16"), (16, "f32"), (256, "bf16")])
+def test_real_forward_beside_the_generator_is_the_3b_forward(B, prec, monkeypatch):
+    """The batched D pass runs D(real)'s input transform and conv stack on the weight-gradient stream beside G's forward and
+    [fake | penalty] as one 2B forward behind it (csrc/engine.hip, JCK_REAL_SIDE; the split PHASE_D_REAL_FWD makes across steps).
+    BatchNorm is per batch either way and every tile stays inside its batch; what may differ from the one 3B forward
+    (JCK_REAL_SIDE=0) is how a batch's statistics are split into partial sums (the launch geometry).  One step of each against
+    the fp32 oracle: exact-fp32 both inside the parity tolerances and 1e-4 from each other; bf16 tensor by tensor no further
+    from the oracle than the 3B form, and closer to it than either is to the oracle (a rounding-boundary flip of a stored
+    activation amplified through the layers below - G.conv1's gradient moves by 3.8 % at batch 256, 0.12 being the storage
+    format's own distance there, tests/test_bf16_envelope.py)."""
+    runs = []
+    for side in ("1", "0"):
+        monkeypatch.setenv("JCK_REAL_SIDE", side)
+        orc, eng, out = _run(B, 1, prec)
+        torch.cuda.synchronize()
+        runs.append((out[-1][1], {t: {k: v.detach().float().cpu().clone() for k, v in eng.named_views(t, "grads").items()} for t in "dg"}))
+    ref_s, ref = out[-1][0], {"d": out[-1][2], "g": out[-1][3]}
+    (s1, g1), (s0, g0) = runs
+    stol = 1e-5 if prec == "f32" else 2e-3
+    for k in ("loss_d", "loss_g", "gp", "loss_real", "loss_fake", "d_x", "d_gz1", "d_gz2"):
+        assert _rel(s1[k], s0[k]) < stol, (k, s1[k], s0[k])
+        if prec == "f32":
+            assert _rel(s1[k], ref_s[k]) < 1e-3, (k, s1[k], ref_s[k])
+    l2 = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()
+    for t in "dg":
+        for k, r in ref[t].items():
+            d1, d0, d10 = l2(g1[t][k].view(r.shape), r), l2(g0[t][k].view(r.shape), r), l2(g1[t][k], g0[t][k])
+            if prec == "f32":
+                assert d10 < 1e-4 and d1 < 2e-2, (t, k, d10, d1)
+            else:
+                assert d1 <= 1.25 * d0 + 1e-3, (t, k, d1, d0)
+                assert d10 <= max(2e-2, 0.75 * max(d0, d1)), (t, k, d10, d0, d1)
+
+
+@pytest.mark.parametrize("B,prec", [(32, "bf16"), (8, "f32")])
+def test_real_forward_beside_the_generator_cgan(B, prec, monkeypatch):
+    """The same schedule in CGAN's batched pass (its head runs once over the 3B rows of the concat buffer, which the two forwards
+    fill in two pieces), with the instance noise drawn inside the kernels: one step from the same state, scalars and gradients
+    to summation-order accuracy (exact-fp32 1e-5 / 1e-4; bf16 2e-3 / 6e-2, the double backward amplifies more)."""
+    import bf16_error as be
+    from hipgan.engine import CganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images
+    torch.manual_seed(12345)
+    g, d = build_params("cgan")
+    imgs = synth_images(B)
+    runs = []
+    for side in ("1", "0"):
+        monkeypatch.setenv("JCK_REAL_SIDE", side)
+        eng = CganEngine(batch=B, prec=prec)
+        eng.load_state(g, d)
+        eng.set_noise_seed(999)
+        eng.step_async(imgs.cuda(), None, 2e-4, labels=be.labels_for(B, 5).cuda())
+        sc = eng.scalars()
+        torch.cuda.synchronize()
+        runs.append((sc, {t: {k: v.detach().float().cpu().clone() for k, v in eng.named_views(t, "grads").items()} for t in "dg"},
+                     eng.tensor("fake").clone()))
+    (s1, g1, f1), (s0, g0, f0) = runs
+    assert torch.equal(f0, f1)                       # G's forward is untouched
+    stol, gtol = (1e-5, 1e-4) if prec == "f32" else (2e-3, 6e-2)
+    for k in s0:
+        assert _rel(s1[k], s0[k]) < stol, (k, s1[k], s0[k])
+    for t in "dg":
+        for k, r in g0[t].items():
+            l2 = ((g1[t][k] - r).norm() / (r.norm() + 1e-30)).item()
+            assert l2 < gtol, (t, k, l2)
+
+
 def test_per_pass_schedule_in_bf16_keeps_one_resident_launch_in_flight(monkeypatch):
     """bf16 at batch 106: the per-pass schedule runs the penalty pass on its own stream beside D(fake).  Two resident BatchNorm
     backward launches at once would share the engine's barrier words (and could starve each other of CUs), so that pass takes the
