@@ -321,23 +321,31 @@ def measure(a, model, world, rank, dev, dist):
     if rank == 0 and not a.no_roofline:
         import ctypes as C
         lib.jck_prof_enable(0)
-        cap = 40
+        cap = 64
         names, cnt, msv, flv = (C.c_char_p * cap)(), (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
         byv, stv = (C.c_double * cap)(), (C.c_void_p * cap)()
         n = lib.jck_prof_collect(cap, names, cnt, msv, flv, byv, stv)
         main_stream = torch.cuda.current_stream().cuda_stream
-        rows = []
-        for i in range(n):
-            r = {"kernel": names[i].decode(), "launches_per_step": cnt[i] / 3, "avg_ms": msv[i] / cnt[i], "ms_per_step": msv[i] / 3,
-                 # the HIP stream the launches were issued on, from the launch records themselves: the engine's
-                 # second stream carries the weight-gradient products beside the dgrad / BatchNorm chain
-                 "stream": "main" if (stv[i] or 0) == main_stream else ("main + side" if (stv[i] or 0) == 2 ** 64 - 1 else "side (beside the main stream)")}
-            if byv[i] > 0:
-                r["bound"], r["gbs"] = "hbm", byv[i] / (msv[i] * 1e-3) / 1e9
+        # one record per (kernel, HIP stream the launches were issued on) - from the launch records themselves: the
+        # engine's second stream carries the weight-gradient products beside the dgrad / BatchNorm chain and, since round 4, D(real)'s
+        # forward beside G's
+        def make_row(name, count, ms, fl, by, stream):
+            r = {"kernel": name, "launches_per_step": count / 3, "avg_ms": ms / count, "ms_per_step": ms / 3, "stream": stream}
+            if by > 0:
+                r["bound"], r["gbs"] = "hbm", by / (ms * 1e-3) / 1e9
             else:
-                r["bound"], r["tflops"] = "mfma", flv[i] / (msv[i] * 1e-3) / 1e12
-            rows.append(r)
+                r["bound"], r["tflops"] = "mfma", fl / (ms * 1e-3) / 1e12
+            return r
+        per_stream, total = [], {}
+        for i in range(n):
+            on_main = (stv[i] or 0) == main_stream
+            per_stream.append(make_row(names[i].decode(), cnt[i], msv[i], flv[i], byv[i], "main" if on_main else "side (beside the main stream)"))
+            t = total.setdefault(names[i].decode(), [0, 0.0, 0.0, 0.0, set()])
+            t[0] += cnt[i]; t[1] += msv[i]; t[2] += flv[i]; t[3] += byv[i]; t[4].add(on_main)
+        rows = [make_row(k, t[0], t[1], t[2], t[3], "main" if t[4] == {True} else ("side (beside the main stream)" if t[4] == {False} else "main + side"))
+                for k, t in total.items()]
         rows.sort(key=lambda r: -r["ms_per_step"])
+        per_stream.sort(key=lambda r: -r["ms_per_step"])
         method = "HIP events around every launch on the stream it is launched on, 3 extra (eagerly launched) steps after the timed region"
 
         def mfma_obj(d, selection):
@@ -354,8 +362,9 @@ def measure(a, model, world, rank, dev, dist):
             # step's critical (main) stream - the weight gradients overlap that chain on the second stream, so their launch
             # durations are those of a kernel sharing the chip; (3) the largest HBM-bound kernel (the BatchNorm side of the step)
             res["roofline"] = mfma_obj(mf[0], "largest total time per step among the MFMA kernels, any stream")
-            crit = [r for r in mf if r["stream"] == "main"] or mf
-            res["roofline_critical"] = mfma_obj(crit[0], "largest total time per step among the MFMA kernels launched on the step's main stream")
+            crit = [r for r in per_stream if r["bound"] == "mfma" and r["stream"] == "main"] or mf
+            res["roofline_critical"] = mfma_obj(crit[0], "largest total time per step among the MFMA kernels' launches on the step's main stream "
+                                                         "(launches of the same kernel on the second stream are not counted)")
         if hb:
             d = hb[0]
             tr = pmc_traffic(d["kernel"])

@@ -372,7 +372,8 @@ void jck_graph_destroy(void* graph_exec);
  * one process A/B two variants on one device and lets a test force a variant at a small shape.  Unknown key -> JCK_E_ARG. */
 int jck_tune(const char* key, int value);
 /* per-launch HIP-event timing of the MFMA kernels (bench.py roofline leg).  enable(1) ... run ... collect():
- * per kernel variant: launches, total milliseconds, total algorithmic FLOPs.  Returns the number of rows. */
+ * per (kernel variant, HIP stream the launches ran on): launches, total milliseconds, total algorithmic FLOPs, total algorithmic
+ * bytes (streaming kernels), the stream.  A variant launched on two streams comes back as two rows.  Returns the number of rows. */
 int jck_prof_enable(int on);
 int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out, double* bytes_out,
                      void** stream_out);

@@ -109,34 +109,35 @@ extern "C" int jck_prof_enable(int on) {
   g_prof_on = on != 0;
   return JCK_OK;
 }
-// Synchronises the recorded events, accumulates per kernel variant: count, total ms, total algorithmic FLOPs, total algorithmic
-// bytes (streaming kernels) and the HIP stream the launches ran on (all ones when a variant ran on several).  Returns the number of
-// variants written (<= cap).  name_out[i] points at a static string.
+// Synchronises the recorded events, accumulates per (kernel variant, HIP stream the launches ran on): count, total ms, total
+// algorithmic FLOPs, total algorithmic bytes (streaming kernels).  A variant launched on two streams comes back as two rows.
+// Returns the number of rows written (<= cap).  name_out[i] points at a static string.
 extern "C" int jck_prof_collect(int cap, const char** name_out, int* count_out, double* ms_out, double* flops_out, double* bytes_out,
                                 void** stream_out) {
   constexpr int NV = sizeof(PROF_NAMES) / sizeof(PROF_NAMES[0]);
-  int cnt[NV] = {0}; double ms[NV] = {0}, fl[NV] = {0}, by[NV] = {0};
-  hipStream_t sv[NV] = {nullptr}; bool mixed[NV] = {false};
+  struct Row { int variant; hipStream_t st; int cnt; double ms, fl, by; };
+  std::vector<Row> rows;
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.e1);
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.e0, r.e1);
     if (r.variant >= 0 && r.variant < NV) {
-      const int v = r.variant;
-      if (cnt[v] == 0) sv[v] = r.st; else if (sv[v] != r.st) mixed[v] = true;
-      cnt[v]++; ms[v] += t; fl[v] += r.flops; by[v] += r.bytes;
+      Row* q = nullptr;
+      for (auto& x : rows) if (x.variant == r.variant && x.st == r.st) { q = &x; break; }
+      if (!q) { rows.push_back(Row{r.variant, r.st, 0, 0.0, 0.0, 0.0}); q = &rows.back(); }
+      q->cnt++; q->ms += t; q->fl += r.flops; q->by += r.bytes;
     }
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
   int n = 0;
-  for (int v = 0; v < NV && n < cap; ++v)
-    if (cnt[v]) {
-      name_out[n] = PROF_NAMES[v]; count_out[n] = cnt[v]; ms_out[n] = ms[v]; flops_out[n] = fl[v];
-      if (bytes_out) bytes_out[n] = by[v];
-      if (stream_out) stream_out[n] = mixed[v] ? (void*)~(uintptr_t)0 : (void*)sv[v];      // all ones: several streams
-      ++n;
-    }
+  for (auto& x : rows) {
+    if (n >= cap) break;
+    name_out[n] = PROF_NAMES[x.variant]; count_out[n] = x.cnt; ms_out[n] = x.ms; flops_out[n] = x.fl;
+    if (bytes_out) bytes_out[n] = x.by;
+    if (stream_out) stream_out[n] = (void*)x.st;
+    ++n;
+  }
   return n;
 }
 
