@@ -130,3 +130,13 @@ def test_lazy_join_with_the_weight_gradient_stream_is_bitwise_the_plain_order(pr
     assert s0 == s1, (s0, s1)
     for k in a0:
         assert torch.equal(a0[k], a1[k]), k
+
+
+@pytest.mark.parametrize("env", [{"JCK_WGRAD_SIDE": "0"}, {"JCK_EXT_EVENTS": "0"}, {"JCK_OVERLAP": "0"}, {"JCK_HEAD_SIDE": "0"},
+                                 {"JCK_REAL_SIDE": "0"}, {"JCK_CBUF_DIRECT": "0"}, {"JCK_LAZY_JOIN": "0"}])
+def test_cgan_alternative_stream_layouts_give_the_same_step(env, monkeypatch):
+    """Every switch that moves CGAN work between the two streams (or keeps a copy / a join the default drops) is the same
+    arithmetic: one exact-fp32 step of each against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    test_cgan_step_parity("f32", 8, 1e-3, 2e-2)
