@@ -1004,7 +1004,19 @@ static int clear_acc(jck_engine* e, int step, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------------------
+static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream);
 extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream) {
+  const int rc = phase_impl(e, phase, in_, stream);
+  if (rc != JCK_OK && e) {
+    // a phase that failed half way leaves no promise behind: the next D phase clears its arenas itself and joins the
+    // weight-gradient stream before anything else (state armed before a failing call must not outlive it)
+    e->acc_clean_step = e->dg_clean_step = e->gg_clean_step = -1;
+    if (e->join_pending && e->sA && stream && !e->capturing) (void)hipStreamWaitEvent((hipStream_t)stream, e->evWdone, 0);
+    e->join_pending = e->mid_recorded = false;
+  }
+  return rc;
+}
+static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream) {
   if (!e || !e->bound || !in_) JCK_FAIL(JCK_E_ARG, "engine not bound / null inputs");
   // z, alpha and (CGAN) the Dropout keep masks left NULL: the engine's own draws for this step (jck_engine_set_step)
   jck_step_inputs loc = *in_;
