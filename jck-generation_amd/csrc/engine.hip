@@ -169,6 +169,7 @@ struct jck_engine {
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
   bool cbuf_direct = true;              // CGAN: D's last BatchNorm+LeakyReLU writes straight into the head's concat buffer (JCK_CBUF_DIRECT=0: a copy)
+  bool head_fuse = true;                // CGAN: Linear finish + Linear(256,1)/sigmoid/BCE + its input gradient + Dropout backward as one launch (JCK_HEAD_FUSE=0: four)
   bool real_side = true;                // batched D pass: D(real)'s forward beside G's forward on the weight-gradient stream (JCK_REAL_SIDE=0: one 3B forward)
   bool fold_zero = true;                // zero_grad() of both networks inside neighbouring launches (JCK_FOLD_ZERO=0: memsets)
   bool fuse_tanh = true;                // G's loss pass: tanh backward in the epilogue of D.conv1's input gradient (JCK_FUSE_TANH=0: a launch of its own)
@@ -353,6 +354,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
   e->cbuf_direct = family == 1 && !(getenv("JCK_CBUF_DIRECT") && atoi(getenv("JCK_CBUF_DIRECT")) == 0);
+  e->head_fuse = family == 1 && !(getenv("JCK_HEAD_FUSE") && atoi(getenv("JCK_HEAD_FUSE")) == 0);
   e->real_side = !(getenv("JCK_REAL_SIDE") && atoi(getenv("JCK_REAL_SIDE")) == 0);
   e->fold_zero = !(getenv("JCK_FOLD_ZERO") && atoi(getenv("JCK_FOLD_ZERO")) == 0);
   e->fuse_tanh = !(getenv("JCK_FUSE_TANH") && atoi(getenv("JCK_FUSE_TANH")) == 0);
@@ -528,21 +530,31 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
 // label embedding, Linear(8392,256), Dropout.  Leaves cbuf, pre_e, h_pre, h_drop for the matching d_head_backward.
 // rows: B, or 3B for the batched head (label_period = B: the three groups share the batch's labels; drop_mask = their three
 // [B][256] masks back to back)
-static int cg_head_forward(jck_engine* e, const void* a4, int rows, const float* drop_mask, hipStream_t st, int label_period = 0) {
+// finish = false: stops at the split-K slabs of Linear(8392,256); cg_head_mid (one launch) takes it from there
+static int cg_head_forward(jck_engine* e, const void* a4, int rows, const float* drop_mask, hipStream_t st, int label_period = 0, bool finish = true) {
   if (!e->cur_labels || !drop_mask) JCK_FAIL(JCK_E_ARG, "CGAN pass needs labels and a dropout mask");
   if (a4) JCK_TRY(jck_concat_rows(e->prec, a4, TT.FEAT, e->cbuf, L1_KPAD, rows, st));      // null: the conv stack wrote the rows itself
   JCK_TRY(jck_label_embed_fwd_tiled(e->prec, e->cur_labels, e->P(e->LD, e->dp, "label_embedding.weight"),
                                     e->P(e->LD, e->dp, "label_embedding.bias"), LRELU, rows, N_CLASS, EMB, e->cbuf, L1_KPAD, TT.FEAT,
                                     e->pre_e, label_period, st));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf, e->l1_w, nullptr, e->l1_slab, rows, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
+  if (!finish) return JCK_OK;
   return jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre,
                            e->h_drop, rows, L1_OUT, st);
 }
+// The head from the split-K slabs to the gradient at the Linear(8392,256) output, rows [0, G * B) of the head buffers: h_pre, h_drop,
+// prob / ds / scalar slots per group, g_hd, g_h (ops.hip: cg_head_mid)
+static int cg_head_middle(jck_engine* e, int B, int G, const float* targets, const int* modes, const int* slot_loss, const int* slot_p,
+                          float* prob, float* ds, const float* drop_mask, hipStream_t st) {
+  return cg_head_mid(e->prec, e->l1_slab, L1_KSPLIT, e->P(e->LD, e->dp, "linear1.bias"), drop_mask, 1.0f / 0.75f, e->h_pre, e->h_drop,
+                     e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, G, targets, modes, prob, ds, e->acc, slot_loss,
+                     slot_p, e->acc_ld, e->g_hd, e->g_h, st);
+}
 
-static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st) {
+static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, const float* drop_mask, hipStream_t st, bool head_finish = true) {
   const bool direct = e->family == 1 && e->cbuf_direct;
   JCK_TRY(d_convs_forward(e, D, x_in, B, pass, st, direct));
-  if (e->family == 1) return cg_head_forward(e, direct ? nullptr : e->d_a[TT.NS - 1], B, drop_mask, st);
+  if (e->family == 1) return cg_head_forward(e, direct ? nullptr : e->d_a[TT.NS - 1], B, drop_mask, st, 0, head_finish);
   return JCK_OK;
 }
 
@@ -556,8 +568,9 @@ static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slo
 
 // head backward from ds (device float[B]) down to the gradient w.r.t. a4 in e->d_g[3] (or `ga4_out`).
 // side (family 1, optional): the parameter gradients run there (see cg_head_backward_batched)
+// mid_done: g_hd and g_h are in place (cg_head_middle)
 static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st,
-                           hipStream_t side = nullptr) {
+                           hipStream_t side = nullptr, bool mid_done = false) {
   if (e->family == 0)
     return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, ga4_out, want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr,
                              e->head_ws, st);
@@ -577,13 +590,13 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
     return JCK_OK;
   };
   const float* w2 = e->P(e->LD, e->dp, "linear2.weight");
-  JCK_TRY(jck_head_bwd(e->prec, ds, w2, h_drop, B, L1_OUT, g_hd, nullptr, 1, e->head_ws, st));
+  if (!mid_done) JCK_TRY(jck_head_bwd(e->prec, ds, w2, h_drop, B, L1_OUT, g_hd, nullptr, 1, e->head_ws, st));
   if (want_wgrad) {
     JCK_TRY(fork(0));
     JCK_TRY(jck_head_bwd(e->prec, ds, w2, h_drop, B, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
     JCK_TRY(jck_sum_vec(ds, B, e->P(e->LD, e->dg, "linear2.bias"), ws));
   }
-  JCK_TRY(jck_dropout(e->prec, g_hd, drop_mask, 1.0f / 0.75f, g_h, (long long)B * L1_OUT, st));
+  if (!mid_done) JCK_TRY(jck_dropout(e->prec, g_hd, drop_mask, 1.0f / 0.75f, g_h, (long long)B * L1_OUT, st));
   if (want_wgrad) {
     JCK_TRY(fork(1));
     JCK_TRY(jck_linear_wgrad(e->prec, g_h, L1_OUT, cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, ws));
@@ -606,7 +619,7 @@ static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool 
 // gradient down to the conv stack; evHead marks their end on that stream (PHASE_D_GP's main-stream writers of the same gradients
 // wait for it).
 static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const float* drop_mask, void* ga4_out, hipStream_t st,
-                                    hipStream_t side = nullptr) {
+                                    hipStream_t side = nullptr, bool mid_done = false) {
   const int R3 = 3 * B, R2 = 2 * B;
   const float* w2 = e->P(e->LD, e->dp, "linear2.weight");
   hipStream_t ws = st;
@@ -617,12 +630,18 @@ static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const
     ws = side;
     return JCK_OK;
   };
-  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R3, L1_OUT, e->g_hd, nullptr, 1, e->head_ws, st));
-  JCK_TRY(fork(0));
-  JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
-  JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), ws));
-  JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)R3 * L1_OUT, st));
+  if (!mid_done) JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R3, L1_OUT, e->g_hd, nullptr, 1, e->head_ws, st));
+  if (!mid_done) {        // (with the middle in one launch both forks start at the same point: one hand-over)
+    JCK_TRY(fork(0));
+    JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
+    JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), ws));
+    JCK_TRY(jck_dropout(e->prec, e->g_hd, drop_mask, 1.0f / 0.75f, e->g_h, (long long)R3 * L1_OUT, st));
+  }
   JCK_TRY(fork(1));
+  if (mid_done) {
+    JCK_TRY(jck_head_bwd(e->prec, ds, w2, e->h_drop, R2, L1_OUT, nullptr, e->P(e->LD, e->dg, "linear2.weight"), 1, e->head_ws, ws));
+    JCK_TRY(jck_sum_vec(ds, R2, e->P(e->LD, e->dg, "linear2.bias"), ws));
+  }
   JCK_TRY(jck_linear_wgrad(e->prec, e->g_h, L1_OUT, e->cbuf, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, R2, L1_OUT, ws));
   JCK_TRY(jck_colsum(e->prec, e->g_h, R2, L1_OUT, L1_OUT, e->P(e->LD, e->dg, "linear1.bias"), ws));
   JCK_TRY(jck_linear_fwd(e->prec, e->g_h, e->l1_wT, nullptr, e->gc, R3, L1_OUT, L1_KPAD, L1_KPAD, 1, st));
@@ -642,8 +661,8 @@ static int cg_head_backward_batched(jck_engine* e, const float* ds, int B, const
 // product rides in the epilogue of the launch that computes it (conv_up_tanh_bwd_ev) when the layer runs on the image-side kernel
 struct XgradEpi { const void* tanh_y; float scale; void* out; hipEvent_t done; bool fused; };
 static int d_backward(jck_engine* e, DSet& D, const void* x_in, int B, bool want_wgrad, bool want_xgrad, const float* drop_mask,
-                      hipStream_t st, hipStream_t side, bool join = true, bool resident = true, XgradEpi* xe = nullptr) {
-  JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[TT.NS - 1], st));
+                      hipStream_t st, hipStream_t side, bool join = true, bool resident = true, XgradEpi* xe = nullptr, bool head_mid_done = false) {
+  JCK_TRY(d_head_backward(e, D, D.ds, B, want_wgrad, drop_mask, D.g[TT.NS - 1], st, nullptr, head_mid_done));
   const bool par = want_wgrad && side != nullptr;
   for (int i = TT.NS - 1; i >= 0; --i) {
     const int hb = TT.D_HB[i], cs = TT.D_CS[i], cb = TT.D_CB[i];
@@ -1114,12 +1133,15 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         auto& S = e->bset;
         const float tg[2] = {0.9f, 0.1f};
         e->head_row0 = 0;
-        if (head3) JCK_TRY(cg_head_forward(e, direct ? nullptr : S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B));
+        const bool fuse = head3 && e->head_fuse;
+        if (head3) JCK_TRY(cg_head_forward(e, direct ? nullptr : S.a[TT.NS - 1], 3 * B, in->drop_mask[0], st, B, !fuse));
         if (head3) {
           const float tg3[3] = {tg[0], tg[1], 0.f};
           const int md3[3] = {0, 0, 1}, sl3[3] = {0, 1, -1}, sp3[3] = {3, 4, -1};
-          JCK_TRY(jck_head_fwd_grouped(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
-                                       3, tg3, md3, S.prob, S.ds, e->acc, sl3, sp3, e->acc_ld, st));
+          if (fuse) JCK_TRY(cg_head_middle(e, B, 3, tg3, md3, sl3, sp3, S.prob, S.ds, in->drop_mask[0], st));
+          else
+            JCK_TRY(jck_head_fwd_grouped(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT,
+                                         3, tg3, md3, S.prob, S.ds, e->acc, sl3, sp3, e->acc_ld, st));
         }
         for (int g = 0; g < 3 && !head3; ++g) {
           const bool pen = g == 2;
@@ -1133,7 +1155,7 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         }
         if (head3) {
           static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
-          JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st, head_side ? sA : nullptr));
+          JCK_TRY(cg_head_backward_batched(e, S.ds, B, in->drop_mask[0], S.g[TT.NS - 1], st, head_side ? sA : nullptr, fuse));
           e->head_row0 = 2 * B;                        // where PHASE_D_GP finds the penalty group's head state
           e->head_wrow0 = 0;
         }
@@ -1282,11 +1304,16 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       if (!(e->gg_clean_step == in->step && !e->capturing)) HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
       e->gg_clean_step = -1;
-      JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st));
-      JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
+      const bool fuse = cg && e->head_fuse;           // CGAN: the middle of the head as one launch (cg_head_middle)
+      JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st, !fuse));
+      if (fuse) {
+        const float tg1 = 0.9f;
+        const int md1 = 0, sl1 = 2, sp1 = 5;
+        JCK_TRY(cg_head_middle(e, B, 1, &tg1, &md1, &sl1, &sp1, D0.prob, D0.ds, in->drop_mask[3], st));
+      } else JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st));
       // D's own weight gradients from this pass are dead (zeroed at :155 before they are read): skipped
       XgradEpi xe = {e->fake_raw, 0.9f, e->g_raw, (sA && e->ext_events) ? e->evW[TT.NS - 1] : nullptr, false};
-      JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr, true, true, e->fuse_tanh ? &xe : nullptr));
+      JCK_TRY(d_backward(e, D0, e->fake, B, false, true, in->drop_mask[3], st, nullptr, true, true, e->fuse_tanh ? &xe : nullptr, fuse));
       JCK_TRY(g_backward(e, D0.gx, B, st, sA, xe.fused));
       return JCK_OK;
     }

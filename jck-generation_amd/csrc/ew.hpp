@@ -1358,6 +1358,67 @@ __global__ void linear_finish_kernel(const float* __restrict__ slab, int Z, long
   if (hd) stf(hd + i, mask ? s * mask[i] * scale : s);
 }
 
+// The middle of CGAN's head as ONE launch, one workgroup per row of N = 256 columns (thread = column): linear_finish_kernel
+// (split-K sum + bias, Dropout), head_fwd_kernel (Linear(256,1) + sigmoid + BCE, ds), head_dgrad_kernel (g_hd = ds * w2) and the
+// Dropout backward (g_h = g_hd * mask * scale) - four launches at the launch floor on a serial chain.  Same arithmetic in the same
+// order as the four (the dot product is formed by threads 0..31 over 8 columns each, then block_sum256, as head_fwd_kernel
+// does it; every value is rounded to T where the separate launches stored it).
+template <typename T>
+__global__ __launch_bounds__(256) void cg_head_mid_kernel(const float* __restrict__ slab, int Z, long long zstride, const float* __restrict__ bias1,
+                                                          const float* __restrict__ mask, float scale, T* __restrict__ h, T* __restrict__ hd,
+                                                          const float* __restrict__ w2, const float* __restrict__ bias2, const HeadGroups hg,
+                                                          float invB, float* __restrict__ prob, float* __restrict__ ds, float* __restrict__ scal,
+                                                          int scal_ld, T* __restrict__ g_hd, T* __restrict__ g_h) {
+  __shared__ float sm[4];
+  __shared__ __attribute__((aligned(16))) float shd[256];
+  __shared__ float sds;
+  const int j = threadIdx.x;
+  const long long i = (long long)blockIdx.x * 256 + j;
+  float s = bias1 ? bias1[j] : 0.f;
+  for (int z = 0; z < Z; ++z) s += slab[(long long)z * zstride + i];
+  stf(h + i, s);
+  T t;
+  stf(&t, s * mask[i] * scale);
+  hd[i] = t;
+  shd[j] = ldf(&t);
+  __syncthreads();
+  float d = 0.f;
+  if (j < 32) {
+    const float* v = shd + j * 8;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2 + j * 8), w1 = *reinterpret_cast<const f32x4*>(w2 + j * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d += v[k] * w0[k] + v[4 + k] * w1[k];
+  }
+  d = block_sum256(d, sm);
+  if (j == 0) {
+    const int grp = blockIdx.x / hg.rows_per_group, nrow = blockIdx.x - grp * hg.rows_per_group;
+    const float target = hg.target[grp];
+    const int mode = hg.mode[grp], slot_loss = hg.slot_loss[grp], slot_p = hg.slot_p[grp];
+    if (bias2) d += bias2[0];
+    const float p = 1.f / (1.f + expf(-d));
+    prob[blockIdx.x] = p;
+    const float pq = p * (1.f - p);
+    float dsv;
+    if (mode == 0) {
+      const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+      const float loss = -(target * lp + (1.f - target) * lq);
+      const float dp = (p - target) / fmaxf(pq, 1e-12f) * invB;
+      dsv = dp * pq;
+      if (slot_loss >= 0) scal[(long long)slot_loss * scal_ld + nrow] = loss;
+    } else {
+      dsv = pq;
+    }
+    ds[blockIdx.x] = dsv;
+    sds = dsv;
+    if (slot_p >= 0) scal[(long long)slot_p * scal_ld + nrow] = p;
+  }
+  __syncthreads();
+  T tg;
+  stf(&tg, sds * w2[j]);
+  g_hd[i] = tg;
+  stf(g_h + i, ldf(&tg) * mask[i] * scale);
+}
+
 // out[0] += sum_i x[i]   (bias gradient of a 1-output Linear)
 static __global__ __launch_bounds__(256) void sum_vec_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
   __shared__ float sm[4];

@@ -972,6 +972,24 @@ extern "C" int jck_head_fwd(int prec, const void* a4, const float* wp, const flo
                             float* prob, float* ds, float* scal, int slot_loss, int slot_p, int scal_ld, void* stream) {
   return jck_head_fwd_grouped(prec, a4, wp, bias, B, K, 1, &target, &mode, prob, ds, scal, &slot_loss, &slot_p, scal_ld, stream);
 }
+// jck_linear_finish + jck_head_fwd_grouped + the input-gradient half of jck_head_bwd + jck_dropout of CGAN's head in one launch
+// (ew.hpp: cg_head_mid_kernel); N = 256 columns; rows = G * B; mask required
+int cg_head_mid(int prec, const float* slab, int ksplit, const float* bias1, const float* mask, float scale, void* h, void* hd, const float* w2,
+                const float* bias2, int B, int G, const float* targets, const int* modes, float* prob, float* ds, float* scal,
+                const int* slot_loss, const int* slot_p, int scal_ld, void* g_hd, void* g_h, hipStream_t stream) {
+  if (G < 1 || G > 4 || B < 1 || !mask || !slab || ksplit < 1) JCK_FAIL(JCK_E_ARG, "cg_head_mid: 1..4 groups of >= 1 rows, a dropout mask, split-K slabs");
+  HeadGroups hg = {};
+  hg.rows_per_group = B;
+  for (int g = 0; g < G; ++g) {
+    hg.target[g] = targets[g]; hg.mode[g] = modes[g]; hg.slot_loss[g] = slot_loss[g]; hg.slot_p[g] = slot_p[g];
+    if ((slot_loss[g] >= 0 || slot_p[g] >= 0) && (!scal || scal_ld < B)) JCK_FAIL(JCK_E_ARG, "cg_head_mid: scalar slots need scal with scal_ld >= B");
+  }
+  const long long rows = (long long)G * B;
+  DISPATCH_T(prec, hipLaunchKernelGGL(cg_head_mid_kernel<T>, dim3((unsigned)rows), dim3(256), 0, stream, slab, ksplit, rows * 256, bias1, mask, scale,
+                                      (T*)h, (T*)hd, w2, bias2, hg, 1.0f / (float)B, prob, ds, scal, scal_ld, (T*)g_hd, (T*)g_h));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
 #define HEAD_NS 8          /* partial rows of jck_head_bwd */
 #define HEAD_CONV_NS 16    /* partial rows of jck_head_bwd_conv */
 extern "C" size_t jck_head_bwd_ws_floats(int K) { return (size_t)HEAD_CONV_NS * K; }

@@ -59,4 +59,7 @@ int pack_linear_pair(int prec, const float* w, int N, int K, int rows0, int cols
                      int permHW, hipStream_t stream);
 int bn_act_fwd_pitched(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group, int C, int groups,
                        long long out_row, long long out_pitch, hipStream_t stream);
+int cg_head_mid(int prec, const float* slab, int ksplit, const float* bias1, const float* mask, float scale, void* h, void* hd, const float* w2,
+                const float* bias2, int B, int G, const float* targets, const int* modes, float* prob, float* ds, float* scal,
+                const int* slot_loss, const int* slot_p, int scal_ld, void* g_hd, void* g_h, hipStream_t stream);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);

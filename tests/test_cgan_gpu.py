@@ -133,10 +133,40 @@ def test_lazy_join_with_the_weight_gradient_stream_is_bitwise_the_plain_order(pr
 
 
 @pytest.mark.parametrize("env", [{"JCK_WGRAD_SIDE": "0"}, {"JCK_EXT_EVENTS": "0"}, {"JCK_OVERLAP": "0"}, {"JCK_HEAD_SIDE": "0"},
-                                 {"JCK_REAL_SIDE": "0"}, {"JCK_CBUF_DIRECT": "0"}, {"JCK_LAZY_JOIN": "0"}])
+                                 {"JCK_REAL_SIDE": "0"}, {"JCK_CBUF_DIRECT": "0"}, {"JCK_LAZY_JOIN": "0"}, {"JCK_HEAD_FUSE": "0"}])
 def test_cgan_alternative_stream_layouts_give_the_same_step(env, monkeypatch):
     """Every switch that moves CGAN work between the two streams (or keeps a copy / a join the default drops) is the same
     arithmetic: one exact-fp32 step of each against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_cgan_step_parity("f32", 8, 1e-3, 2e-2)
+
+
+@pytest.mark.parametrize("prec,B", [("bf16", 64), ("f32", 16)])
+def test_head_middle_in_one_launch_is_bitwise_the_four(prec, B, monkeypatch):
+    """csrc/ew.hpp: cg_head_mid_kernel = linear_finish + head_fwd + head_dgrad + dropout backward of CGAN's head (JCK_HEAD_FUSE=0
+    keeps the four launches), used by the batched D pass (3 groups) and by G's loss pass.  Same arithmetic in the same order, every
+    intermediate rounded where the separate launches stored it: two steps leave bit-identical weights, moments, gradients, scalars."""
+    from hipgan.engine import CganEngine
+    from oracle.gan_oracle import build_params
+    from util import synth_images, synth_onehot
+    torch.manual_seed(12345)
+    g, d = build_params("cgan")
+    imgs = synth_images(B * 2)
+    onehot, _ = synth_onehot(B * 2)
+    runs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("JCK_HEAD_FUSE", fuse)
+        eng = CganEngine(batch=B, prec=prec)
+        eng.load_state(g, d)
+        sc = []
+        for s in range(2):
+            lab = onehot[s * B:(s + 1) * B]
+            nz = _noise(B, 900 + s, lab)
+            sc.append(eng.step(imgs[s * B:(s + 1) * B].cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4))
+        torch.cuda.synchronize()
+        runs.append((sc, {k: v.clone() for k, v in eng.arenas.items()}))
+    (s0, a0), (s1, a1) = runs
+    assert s0 == s1, (s0, s1)
+    for k in a0:
+        assert torch.equal(a0[k], a1[k]), k
