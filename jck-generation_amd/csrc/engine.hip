@@ -887,16 +887,24 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   JCK_TRY(jck_concat_rows(e->prec, e->d_v[TT.NS - 1], TT.FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
   JCK_TRY(jck_linear_wgrad(e->prec, gh1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
-  JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
+  const bool fuse = e->head_fuse && L1_OUT == 256;    // the next four launches as one (ops.hip: gp_head_mid_ev)
+  if (!fuse) JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
   // (the head's parameter gradients - the dw2 sum here, linear2 / linear1 / the label embedding in d_head_backward below: ~75 us of
   // launches that only the optimiser waits for - go to the weight-gradient stream; JCK_HEAD_SIDE=0 keeps them on the main one)
   static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
   hipStream_t hs = head_side && e->ext_events ? side : nullptr;
-  JCK_TRY(gp_head2_ev(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
-                      e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st, hs, hs ? e->evHead : nullptr));
+  if (fuse) {
+    // g_hd / g_h rows [head_wrow0, + B): not the rows the v-chain's Linear weight gradient reads (the penalty group's, or the copy)
+    const size_t w0 = (size_t)e->head_wrow0 * L1_OUT * esz;
+    JCK_TRY(gp_head_mid_ev(e->prec, e->l1_slab, L1_KSPLIT, drop_mask, 1.0f / 0.75f, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, e->rs,
+                           e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, (unsigned char*)e->g_hd + w0, (unsigned char*)e->g_h + w0, st, hs,
+                           hs ? e->evHead : nullptr));
+  } else
+    JCK_TRY(gp_head2_ev(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
+                        e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st, hs, hs ? e->evHead : nullptr));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
   join();
-  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st, hs));
+  JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st, hs, fuse));
   // the last sum into the permuted Linear gradient is enqueued: back to the reference's layout, on the stream that holds it
   JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, hs ? hs : st));
   for (int i = TT.NS - 1; i >= 0; --i) {

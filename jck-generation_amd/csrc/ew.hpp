@@ -1196,6 +1196,40 @@ __global__ __launch_bounds__(256) void gp_head2_kernel(const T* __restrict__ ugh
   }
 }
 
+// The same stretch of the penalty's double backward as ONE launch, one workgroup per row of 256 columns (thread = column):
+// linear_finish_kernel (split-K sum of the v-chain's Linear product, Dropout) -> ughd, gp_head2_kernel (rs, pq), head_dgrad_kernel
+// (g_hd = rs * w2) and the Dropout backward (g_h) - the arithmetic and the rounding points of the four launches.
+template <typename T>
+__global__ __launch_bounds__(256) void cg_gp_head_mid_kernel(const float* __restrict__ slab, int Z, long long zstride, const float* __restrict__ mask,
+                                                             float scale, T* __restrict__ ughd, const float* __restrict__ w2,
+                                                             const float* __restrict__ prob, float* __restrict__ rs, float* __restrict__ pq_out,
+                                                             T* __restrict__ g_hd, T* __restrict__ g_h) {
+  __shared__ float sm[4];
+  __shared__ float srs;
+  const int j = threadIdx.x, n = blockIdx.x;
+  const long long i = (long long)n * 256 + j;
+  float s = 0.f;
+  for (int z = 0; z < Z; ++z) s += slab[(long long)z * zstride + i];
+  T t;
+  stf(&t, s * mask[i] * scale);
+  ughd[i] = t;
+  float d = 0.f;
+  d += ldf(&t) * w2[j];
+  d = block_sum256(d, sm);
+  if (j == 0) {
+    const float p = prob[n], pq = p * (1.f - p);
+    const float r = d * (1.f - 2.f * p) * pq;
+    rs[n] = r;
+    pq_out[n] = pq;
+    srs = r;
+  }
+  __syncthreads();
+  T tg;
+  stf(&tg, srs * w2[j]);
+  g_hd[i] = tg;
+  stf(g_h + i, ldf(&tg) * mask[i] * scale);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Second-order BatchNorm terms of the back-propagated gradient penalty (CGAN, train/cgan_trainer.py:200-203).
 // Notation (tests/test_gp_double_backward_math.py): first backward gy = (gamma/sigma) (gz - m1 - xhat*m2),

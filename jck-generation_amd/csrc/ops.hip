@@ -1276,6 +1276,26 @@ int gp_head2_ev(int prec, const void* ughd, const float* w2, const float* prob, 
   return JCK_OK;
 }
 
+// jck_linear_finish(bias = NULL, h = NULL) + gp_head2_ev + the input-gradient half of jck_head_bwd(ds = rs) + jck_dropout in one launch
+// (ew.hpp: cg_gp_head_mid_kernel; 256 columns), then the dw2 sum as in gp_head2_ev (on `side` behind `handover` when given)
+int gp_head_mid_ev(int prec, const float* slab, int ksplit, const float* mask, float scale, void* ughd, const float* w2, const float* prob, int B,
+                   float* rs, float* dw2, float* ws, void* g_hd, void* g_h, hipStream_t stream, hipStream_t side, hipEvent_t handover) {
+  if (!ws || !mask || !slab || ksplit < 1) JCK_FAIL(JCK_E_ARG, "gp_head_mid: workspace, dropout mask and split-K slabs are required");
+  if ((side != nullptr) != (handover != nullptr)) JCK_FAIL(JCK_E_ARG, "gp_head_mid: side stream and hand-over event go together");
+  const int K = 256;
+  DISPATCH_T(prec, LAUNCH_EV(cg_gp_head_mid_kernel<T>, dim3(B), dim3(256), 0, stream, handover, slab, ksplit, (long long)B * K, mask, scale,
+                             (T*)ughd, w2, prob, rs, ws, (T*)g_hd, (T*)g_h));
+  HIPCHK(hipGetLastError());
+  hipStream_t gs = stream;
+  if (side) { HIPCHK(hipStreamWaitEvent(side, handover, 0)); gs = side; }
+  float* part = ws + (B + 63) / 64 * 64;
+  DISPATCH_T(prec, hipLaunchKernelGGL(head_wgrad_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_NS), dim3(256), 0, gs, ws, (const T*)ughd, B, K, part));
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, gs, part, HEAD_NS, K, 0, dw2, 1);
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+
 // v-chain step of the penalty's double backward at one BatchNorm layer.  ws: jck_bn2_ws_floats(C) floats; on return
 // ws[0..3C) = {sum v, sum v*xhat, sum v*gy} (keep it for jck_bn2_reverse).  u may alias v.
 extern "C" size_t jck_bn2_ws_floats(int C) { return (size_t)(4 + 4 * BN_BWD_MAX_BLOCKS) * C; }

@@ -62,4 +62,6 @@ int bn_act_fwd_pitched(int prec, const void* y, const float* aux, float slope, v
 int cg_head_mid(int prec, const float* slab, int ksplit, const float* bias1, const float* mask, float scale, void* h, void* hd, const float* w2,
                 const float* bias2, int B, int G, const float* targets, const int* modes, float* prob, float* ds, float* scal,
                 const int* slot_loss, const int* slot_p, int scal_ld, void* g_hd, void* g_h, hipStream_t stream);
+int gp_head_mid_ev(int prec, const float* slab, int ksplit, const float* mask, float scale, void* ughd, const float* w2, const float* prob, int B,
+                   float* rs, float* dw2, float* ws, void* g_hd, void* g_h, hipStream_t stream, hipStream_t side, hipEvent_t handover);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);
