@@ -315,6 +315,10 @@ int jck_engine_phase(jck_engine*, int phase, const jck_step_inputs* in, void* st
 /* device pointer to float[8]: loss_d, loss_g, D(x), D(G(z))_1, D(G(z))_2, gp, loss_real, loss_fake (valid after PHASE_G_STEP) */
 /* first element of the gradient-arena tail that PHASE_D_LOSS_A finalises (net 1 = D); -1 when the schedule has no such split */
 long long jck_engine_grad_tail(const jck_engine*, int net);
+/* PHASE_D_LOSS_A | JCK_PHASE_LAZY_JOIN (DCGAN, data parallel): the phase returns without making its stream wait for the weight-
+ * gradient stream (the stall cost more than the early all-reduce hid); the caller starts the tail's all-reduce from ANOTHER stream
+ * that it first passes here - it then waits for the tail's last writers on both engine streams. */
+int jck_engine_order_after_tail(jck_engine*, void* stream);
 /* after a device synchronisation: JCK_E_HIP if a grid barrier of a resident launch (jck_bn_act_bwd_res) timed out since the last
  * call - the step's results are then invalid; the barrier state is re-armed */
 int jck_engine_check(jck_engine*);

@@ -159,8 +159,9 @@ struct jck_engine {
   int parity = 0;                       // step & 1: selects the scalar accumulators and the BN records of the step in flight
   // side streams: A = weight gradients beside the dgrad chain, B = G forward beside D(real), C = penalty pass beside D(fake)
   hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;
-  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, evWmid = nullptr, evHead = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
+  hipEvent_t evW[JCK_MAX_STAGES] = {}, evWdone = nullptr, evWmid = nullptr, evHead = nullptr, evTail = nullptr, ev0 = nullptr, evF = nullptr, evReal = nullptr, evGP = nullptr;
   bool overlap = true, gp_inflight = false, defer_join = true;
+  bool tail_on_side = false, pre_on_side = false;       // PHASE_D_LOSS_A's tail marker sits on sA; PHASE_D_REAL_FWD ran on sA (evReal)
   bool join_pending = false, mid_recorded = false;    // PHASE_LAZY_JOIN: evWdone (and evWmid) recorded on sA, not yet waited for
   // cross-stream hand-overs of the backward: the producing launch completes the event itself (the `done` argument of
   // bn_act_bwd_res_ev / tanh_bwd_ev: hipExtLaunchKernel's stop event) instead of a
@@ -361,8 +362,8 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   if (e->overlap) {
     hipStream_t* ss[3] = {&e->sA, &e->sB, &e->sC};
     for (auto pp : ss) HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));      // queue priorities measured neutral (r1-r4)
-    hipEvent_t* ev[7 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = &e->evW[i];
+    hipEvent_t* ev[8 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->evTail, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[8 + i] = &e->evW[i];
     for (auto p : ev) HIPCHK(hipEventCreateWithFlags(p, jck_event_flags()));
   }
   *out = e;
@@ -373,8 +374,8 @@ extern "C" void jck_engine_destroy(jck_engine* e) {
   if (e->overlap) {
     hipStream_t ss[3] = {e->sA, e->sB, e->sC};
     for (auto p : ss) if (p) { (void)hipStreamSynchronize(p); (void)hipStreamDestroy(p); }
-    hipEvent_t ev[7 + JCK_MAX_STAGES] = {e->evWdone, e->evWmid, e->evHead, e->ev0, e->evF, e->evReal, e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = e->evW[i];
+    hipEvent_t ev[8 + JCK_MAX_STAGES] = {e->evWdone, e->evWmid, e->evHead, e->evTail, e->ev0, e->evF, e->evReal, e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[8 + i] = e->evW[i];
     for (auto p : ev) if (p) (void)hipEventDestroy(p);
   }
   delete e;
@@ -762,7 +763,10 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
                                 S.sums[i] + (size_t)gw * jck_bn_bwd_ws_floats(cs), at(S.g[i], (size_t)gw * rows * cs), nullptr, nullptr, rows, cs,
                                 G - gw, 0, e->gsync, st, nullptr));
     if (part == 1) {
-      if (side) { HIPCHK(hipEventRecord(e->evWdone, side)); HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0)); }
+      // evTail: the tail of D's gradient arena is final behind it (jck_engine_order_after_tail); lazy_join: st does not wait
+      HIPCHK(hipEventRecord(e->evTail, side ? side : st));
+      e->tail_on_side = side != nullptr;
+      if (side && !lazy_join) HIPCHK(hipStreamWaitEvent(st, e->evTail, 0));
       return JCK_OK;
     }
     if (i > 0)
@@ -786,7 +790,7 @@ static int d_batched_backward(jck_engine* e, const void* x_in, int B, int G, int
 // (targets / accumulator slots given per group) and contribute weight gradients; the LAST group is the penalty pass (head
 // mode 1, gradient w.r.t. its input image -> dset[0].gx, norms -> dset[0].norms).  Weight gradients run on `side`.
 static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pass0, const float* targets, const int* slot_loss,
-                          const int* slot_p, hipStream_t st, hipStream_t side, bool forward_done = false, int part = 0) {
+                          const int* slot_p, hipStream_t st, hipStream_t side, bool forward_done = false, int part = 0, bool lazy_tail = false) {
   auto& S = e->bset;
   const size_t esz = e->esz;
   const int gw = G - 1;
@@ -808,7 +812,7 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
   const bool hs = side && e->ext_events && head_side;
   JCK_TRY(head_bwd_conv2_ev(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
                             e->head_ws, st, hs ? side : nullptr, hs ? e->evHead : nullptr));
-  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part));
+  JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part, part == 1 && lazy_tail));
   return JCK_OK;
 }
 
@@ -1059,6 +1063,7 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
   const int B = e->B, HW = TT.HW;
   const bool cg = e->family == 1;
   const bool lazy = (phase & JCK_PHASE_LAZY_JOIN) && cg && !e->capturing;
+  const bool lazy_tail = (phase & JCK_PHASE_LAZY_JOIN) && !cg && (phase & 0xff) == JCK_PHASE_D_LOSS_A;
   phase &= ~JCK_PHASE_LAZY_JOIN;
   // a join left open by the phase before (JCK_PHASE_LAZY_JOIN): the penalty's double backward keeps using the weight-gradient
   // stream in order and the optimiser phase closes it tensor by tensor; anything else waits here
@@ -1194,18 +1199,20 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         // (the split does not depend on the stream layout: a captured, one-stream step is the same arithmetic launch for launch)
         const bool split = pre || e->real_side;
         const bool beside = !pre && e->real_side && sA;
+        const bool pre_side = pre && e->pre_on_side;    // PHASE_D_REAL_FWD ran on the weight-gradient stream: joined behind G's forward
+        e->pre_on_side = false;
         hipStream_t sr = beside ? sA : st;
         if (beside) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(sA, e->ev0, 0)); }
         if (!pre) JCK_TRY(prep_real(e, in, B, sr));                                               // :160
         if (!pre && split) JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr));          // :162
         if (beside) HIPCHK(hipEventRecord(e->evReal, sA));
         JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
-        if (beside) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
+        if (beside || pre_side) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));                                             // :171, :111-113
         const float tg[2] = {0.9f, 0.1f};
         const int sl[2] = {0, 1}, sp[2] = {3, 4};
         if (split) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st));                        // :173, 118 as one 2B forward
-        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, split, part));      // :162-176, 178
+        JCK_TRY(d_batched_pass(e, e->real_noisy, B, 3, 0, tg, sl, sp, st, sA, split, part, lazy_tail));      // :162-176, 178
         if (part == 0) e->gp_done = true;
         return JCK_OK;
       }
@@ -1259,8 +1266,14 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
       // the G phase of the step before it reads or writes
       if (cg || e->batched != 3 || e->capturing) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL_FWD: only with the batched DCGAN schedule, outside a capture");
       if (!in->real_nchw && !in->real_u8) JCK_FAIL(JCK_E_ARG, "PHASE_D_REAL_FWD needs real_nchw (or real_u8)");
-      JCK_TRY(prep_real(e, in, B, st));                                                           // :160
-      JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, st));                               // :162
+      // on the weight-gradient stream when there is one (idle here: G's backward has joined it): the caller's stream then only
+      // carries the wait for G's all-reduce and Adam(G), and the rest of this forward runs beside the next step's G forward
+      hipStream_t sr = (e->real_side && sA) ? sA : st;
+      if (sr != st) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(sr, e->ev0, 0)); }
+      JCK_TRY(prep_real(e, in, B, sr));                                                           // :160
+      JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr));                               // :162
+      if (sr != st) HIPCHK(hipEventRecord(e->evReal, sr));
+      e->pre_on_side = sr != st;
       e->real_fwd_step = in->step;
       return JCK_OK;
     }
@@ -1446,8 +1459,8 @@ extern "C" int jck_engine_capture_abort(jck_engine* e, void* stream) {
       HIPCHK(hipStreamCreateWithFlags(pp, hipStreamNonBlocking));
     }
     // ... and so may the events recorded inside it
-    hipEvent_t* ev[7 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->ev0, &e->evF, &e->evReal, &e->evGP};
-    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[7 + i] = &e->evW[i];
+    hipEvent_t* ev[8 + JCK_MAX_STAGES] = {&e->evWdone, &e->evWmid, &e->evHead, &e->evTail, &e->ev0, &e->evF, &e->evReal, &e->evGP};
+    for (int i = 0; i < JCK_MAX_STAGES; ++i) ev[8 + i] = &e->evW[i];
     for (auto p : ev) {
       if (*p) (void)hipEventDestroy(*p);
       *p = nullptr;
@@ -1468,6 +1481,16 @@ extern "C" void jck_graph_destroy(void* graph_exec) {
   if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
 }
 
+// Makes `stream` wait until the tail of D's gradient arena that PHASE_D_LOSS_A finalises is complete (its last writers: the
+// BatchNorm backward of the top layer on the phase's stream, the top layer's weight gradient and conv5's on the weight-gradient
+// stream).  For a caller that passed JCK_PHASE_LAZY_JOIN with PHASE_D_LOSS_A and starts the tail's all-reduce from `stream`.
+extern "C" int jck_engine_order_after_tail(jck_engine* e, void* stream) {
+  if (!e || !e->bound || !stream) JCK_FAIL(JCK_E_ARG, "engine not bound / null stream");
+  if (!e->evTail) return JCK_OK;                    // no second stream: the tail is final in the phase's stream order
+  if (e->tail_on_side) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evW[e->T.NS - 1], 0));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evTail, 0));
+  return JCK_OK;
+}
 extern "C" long long jck_engine_grad_tail(const jck_engine* e, int net) {
   if (!e || !e->bound || net != 1 || e->family != 0 || e->batched != 3) return -1;
   return (long long)find(e->LD, CWN[e->T.NS - 1])->offset;

@@ -119,6 +119,8 @@ class DcganEngine:
         # data parallel: D's all-reduce in two pieces under D's own backward + G's under the next batch's D(real) forward;
         # False = one all-reduce per network, waited for before its Adam (hipgan.dist.ReplicaGuard falls back to it)
         self.lazy_join = os.environ.get("JCK_LAZY_JOIN", "1") != "0"
+        self.ddp_lazy_tail = os.environ.get("JCK_DDP_LAZY_TAIL", "1") != "0"
+        self._ar_stream = None
         self.ddp_overlap = os.environ.get("JCK_DDP_SPLIT", "1") == "1"
         # steps without a noise dict draw z / alpha with torch and the two instance-noise tensors INSIDE the image kernels
         # (Philox, jck_engine_set_noise_seed); JCKGAN_FAST_NOISE=0 draws them with torch.randn as round 1 did
@@ -550,8 +552,18 @@ class DcganEngine:
             # bytes) is final after the first weight-gradient product of the backward pass - its all-reduce is started
             # there, in plain stream order, and runs under the remaining ~0.5 ms of the pass; the head follows at the end
             flat = self.arenas["d_grads"]
-            lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
-            w_tail = reduce_d(flat[tail:])
+            if self.ddp_lazy_tail:
+                # the phase does not make this stream wait for the weight-gradient stream (that stall cost more than the early
+                # collective hid): the tail's all-reduce is issued from a stream of its own that waits for the tail's last writers
+                lib.jck_engine_phase(h, PHASE_D_LOSS_A | PHASE_LAZY_JOIN, C.byref(si), st)
+                if self._ar_stream is None:
+                    self._ar_stream = torch.cuda.Stream()
+                lib.jck_engine_order_after_tail(h, self._ar_stream.cuda_stream)
+                with torch.cuda.stream(self._ar_stream):
+                    w_tail = reduce_d(flat[tail:])
+            else:
+                lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
+                w_tail = reduce_d(flat[tail:])
             lib.jck_engine_phase(h, PHASE_D_LOSS_B, C.byref(si), st)
             w_head = reduce_d(flat[:tail])
             lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
