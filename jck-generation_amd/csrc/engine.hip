@@ -170,7 +170,8 @@ struct jck_engine {
   // resident one-launch BatchNorm backward (bnres.hpp): grid-barrier state (zeroed at bind); JCK_BN_RES=0 switches it off
   unsigned* gsync = nullptr; bool bn_res = true;
   bool cbuf_direct = true;              // CGAN: D's last BatchNorm+LeakyReLU writes straight into the head's concat buffer (JCK_CBUF_DIRECT=0: a copy)
-  bool head_fuse = true;                // CGAN: Linear finish + Linear(256,1)/sigmoid/BCE + its input gradient + Dropout backward as one launch (JCK_HEAD_FUSE=0: four)
+  bool head_fuse = true;                // CGAN: Linear finish + Linear(256,1)/sigmoid/BCE + its input gradient + Dropout backward as one launch; DCGAN: conv5's
+                                        // forward writes its input gradient too (JCK_HEAD_FUSE=0: separate launches)
   bool real_side = true;                // batched D pass: D(real)'s forward beside G's forward on the weight-gradient stream (JCK_REAL_SIDE=0: one 3B forward)
   bool fold_zero = true;                // zero_grad() of both networks inside neighbouring launches (JCK_FOLD_ZERO=0: memsets)
   bool fuse_tanh = true;                // G's loss pass: tanh backward in the epilogue of D.conv1's input gradient (JCK_FUSE_TANH=0: a launch of its own)
@@ -355,7 +356,7 @@ extern "C" int jck_engine_create_sized(jck_engine** out, int family, int prec, i
   e->ext_events = !(getenv("JCK_EXT_EVENTS") && atoi(getenv("JCK_EXT_EVENTS")) == 0);
   e->bn_res = !(getenv("JCK_BN_RES") && atoi(getenv("JCK_BN_RES")) == 0);
   e->cbuf_direct = family == 1 && !(getenv("JCK_CBUF_DIRECT") && atoi(getenv("JCK_CBUF_DIRECT")) == 0);
-  e->head_fuse = family == 1 && !(getenv("JCK_HEAD_FUSE") && atoi(getenv("JCK_HEAD_FUSE")) == 0);
+  e->head_fuse = !(getenv("JCK_HEAD_FUSE") && atoi(getenv("JCK_HEAD_FUSE")) == 0);
   e->real_side = !(getenv("JCK_REAL_SIDE") && atoi(getenv("JCK_REAL_SIDE")) == 0);
   e->fold_zero = !(getenv("JCK_FOLD_ZERO") && atoi(getenv("JCK_FOLD_ZERO")) == 0);
   e->fuse_tanh = !(getenv("JCK_FUSE_TANH") && atoi(getenv("JCK_FUSE_TANH")) == 0);
@@ -560,9 +561,11 @@ static int d_forward(jck_engine* e, DSet& D, const void* x_in, int B, int pass, 
 }
 
 // sigmoid head + loss (mode 0) or + d(sum p)/dlogit (mode 1); fills e->prob / e->ds
-static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st) {
+// g_out (family 0, optional): conv5's input gradient ds[n] * w from the same launch
+static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slot_loss, int slot_p, hipStream_t st, void* g_out = nullptr) {
   if (e->family == 0)
-    return jck_head_fwd(e->prec, D.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, target, mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
+    return head_fwd_grouped_ev(e->prec, D.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, 1, &target, &mode, D.prob, D.ds, e->acc, &slot_loss,
+                               &slot_p, e->acc_ld, g_out, st, nullptr);
   return jck_head_fwd(e->prec, e->h_drop, e->P(e->LD, e->dp, "linear2.weight"), e->P(e->LD, e->dp, "linear2.bias"), B, L1_OUT, target,
                       mode, D.prob, D.ds, e->acc, slot_loss, slot_p, e->acc_ld, st);
 }
@@ -572,9 +575,9 @@ static int d_head(jck_engine* e, DSet& D, int B, float target, int mode, int slo
 // mid_done: g_hd and g_h are in place (cg_head_middle)
 static int d_head_backward(jck_engine* e, DSet& D, const float* ds, int B, bool want_wgrad, const float* drop_mask, void* ga4_out, hipStream_t st,
                            hipStream_t side = nullptr, bool mid_done = false) {
-  if (e->family == 0)
-    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, ga4_out, want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr,
-                             e->head_ws, st);
+  if (e->family == 0)       // mid_done: the input gradient is in place (d_head with g_out)
+    return jck_head_bwd_conv(e->prec, ds, e->d_head_wp, D.a[TT.NS - 1], B, TT.G_C1, mid_done ? nullptr : ga4_out,
+                             want_wgrad ? e->P(e->LD, e->dg, CWN[TT.NS]) : nullptr, e->head_ws, st);
   // linear2 + sigmoid: g_hd = ds * w2, dW2 += sum ds * h_drop, db2 += sum ds.  Head buffers from row e->head_row0 on (the
   // penalty group of a batched head sits at rows [2B, 3B))
   const size_t r0 = (size_t)e->head_row0, w0 = (size_t)e->head_wrow0;
@@ -804,14 +807,22 @@ static int d_batched_pass(jck_engine* e, const void* x_in, int B, int G, int pas
       const bool pen = g == G - 1;
       tg[g] = pen ? 0.f : targets[g]; md[g] = pen ? 1 : 0; sl[g] = pen ? -1 : slot_loss[g]; sp[g] = pen ? -1 : slot_p[g];
     }
-    JCK_TRY(jck_head_fwd_grouped(e->prec, S.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, G, tg, md, S.prob, S.ds, e->acc, sl, sp, e->acc_ld, st));
+    // conv5's forward also writes the rows' input gradient and completes the hand-over event itself: the weight gradient (partial
+    // rows + their ordered sum) is then all the weight-gradient stream's (JCK_HEAD_FUSE=0: head_bwd_fused_kernel does both on st)
+    JCK_TRY(head_fwd_grouped_ev(e->prec, S.a[TT.NS - 1], e->d_head_wp, nullptr, B, TT.FEAT, G, tg, md, S.prob, S.ds, e->acc, sl, sp, e->acc_ld,
+                                e->head_fuse ? S.g[TT.NS - 1] : nullptr, st, e->head_fuse && side && e->ext_events ? e->evHead : nullptr));
   }
   // loss groups (input + weight gradient) and the penalty group (input gradient only), one launch
   // (the ordered sum of conv5's weight-gradient rows is wanted by the optimiser only: weight-gradient stream, 10 us off the main one)
   static const bool head_side = !(getenv("JCK_HEAD_SIDE") && atoi(getenv("JCK_HEAD_SIDE")) == 0);
   const bool hs = side && e->ext_events && head_side;
-  JCK_TRY(head_bwd_conv2_ev(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
-                            e->head_ws, st, hs ? side : nullptr, hs ? e->evHead : nullptr));
+  if (e->head_fuse) {
+    const bool hf = side && e->ext_events;
+    JCK_TRY(head_bwd_conv2_ev(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, 0, TT.G_C1, nullptr, e->P(e->LD, e->dg, CWN[TT.NS]),
+                              e->head_ws, st, hf ? side : nullptr, hf ? e->evHead : nullptr));
+  } else
+    JCK_TRY(head_bwd_conv2_ev(e->prec, S.ds, e->d_head_wp, S.a[TT.NS - 1], gw * B, B, TT.G_C1, S.g[TT.NS - 1], e->P(e->LD, e->dg, CWN[TT.NS]),
+                              e->head_ws, st, hs ? side : nullptr, hs ? e->evHead : nullptr));
   JCK_TRY(d_batched_backward(e, x_in, B, G, gw, true, st, side, true, part, part == 1 && lazy_tail));
   return JCK_OK;
 }
@@ -1325,9 +1336,11 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
       if (!(e->gg_clean_step == in->step && !e->capturing)) HIPCHK(hipMemsetAsync(e->gg, 0, e->LG.n_params * sizeof(float), st));
       e->gg_clean_step = -1;
-      const bool fuse = cg && e->head_fuse;           // CGAN: the middle of the head as one launch (cg_head_middle)
+      const bool fuse = e->head_fuse;                 // CGAN: the middle of the head as one launch (cg_head_middle); DCGAN: conv5's forward
+                                                      // writes its input gradient too
       JCK_TRY(d_forward(e, D0, e->fake, B, 3, in->drop_mask[3], st, !fuse));
-      if (fuse) {
+      if (fuse && !cg) JCK_TRY(d_head(e, D0, B, 0.9f, 0, 2, 5, st, D0.g[TT.NS - 1]));
+      else if (fuse) {
         const float tg1 = 0.9f;
         const int md1 = 0, sl1 = 2, sp1 = 5;
         JCK_TRY(cg_head_middle(e, B, 1, &tg1, &md1, &sl1, &sp1, D0.prob, D0.ds, in->drop_mask[3], st));

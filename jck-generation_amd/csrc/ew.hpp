@@ -496,8 +496,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4, const float* __restrict__ w, int K,
                                                        const float* __restrict__ bias, const HeadGroups hg, float invB,
                                                        float* __restrict__ prob, float* __restrict__ ds,
-                                                       float* __restrict__ scal, int scal_ld) {
+                                                       float* __restrict__ scal, int scal_ld, T* __restrict__ g_out = nullptr) {
+  // g_out (optional): the input gradient of the row, g_out[n][k] = ds[n] * w[k] (head_bwd_fused_kernel's / head_dgrad_kernel's
+  // product), written by the workgroup that has just formed ds[n] - one launch less on the step's serial chain
   __shared__ float sm[4];
+  __shared__ float sds;
   const int grp = blockIdx.x / hg.rows_per_group, nrow = blockIdx.x - grp * hg.rows_per_group;
   const float target = hg.target[grp];
   const int mode = hg.mode[grp], slot_loss = hg.slot_loss[grp], slot_p = hg.slot_p[grp];
@@ -520,12 +523,24 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a4,
       const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
       const float loss = -(target * lp + (1.f - target) * lq);
       const float dp = (p - target) / fmaxf(pq, 1e-12f) * invB;
-      ds[blockIdx.x] = dp * pq;
+      sds = dp * pq;
       if (slot_loss >= 0) scal[(long long)slot_loss * scal_ld + nrow] = loss;
     } else {
-      ds[blockIdx.x] = pq;
+      sds = pq;
     }
+    ds[blockIdx.x] = sds;
     if (slot_p >= 0) scal[(long long)slot_p * scal_ld + nrow] = p;
+  }
+  if (!g_out) return;
+  __syncthreads();
+  const float d = sds;
+  T* gr = g_out + (long long)blockIdx.x * K;
+  for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + i), w1 = *reinterpret_cast<const f32x4*>(w + i + 4);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = d * w0[k]; o[4 + k] = d * w1[k]; }
+    st8(gr + i, o);
   }
 }
 

@@ -955,6 +955,13 @@ int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, 
 extern "C" int jck_head_fwd_grouped(int prec, const void* a4, const float* wp, const float* bias, int B, int K, int G,
                                     const float* targets, const int* modes, float* prob, float* ds, float* scal,
                                     const int* slot_loss, const int* slot_p, int scal_ld, void* stream) {
+  return head_fwd_grouped_ev(prec, a4, wp, bias, B, K, G, targets, modes, prob, ds, scal, slot_loss, slot_p, scal_ld, nullptr,
+                             (hipStream_t)stream, nullptr);
+}
+// g_out (optional): the rows' input gradient ds[n] * wp[k] from the same launch; done (optional): completed by the launch
+int head_fwd_grouped_ev(int prec, const void* a4, const float* wp, const float* bias, int B, int K, int G, const float* targets,
+                        const int* modes, float* prob, float* ds, float* scal, const int* slot_loss, const int* slot_p, int scal_ld,
+                        void* g_out, hipStream_t stream, hipEvent_t done) {
   if (K % 8) JCK_FAIL(JCK_E_ARG, "head_fwd: K % 8 != 0");
   if (G < 1 || G > 4 || B < 1) JCK_FAIL(JCK_E_ARG, "head_fwd: 1..4 groups of >= 1 rows");
   HeadGroups hg = {};
@@ -963,8 +970,8 @@ extern "C" int jck_head_fwd_grouped(int prec, const void* a4, const float* wp, c
     hg.target[g] = targets[g]; hg.mode[g] = modes[g]; hg.slot_loss[g] = slot_loss[g]; hg.slot_p[g] = slot_p[g];
     if ((slot_loss[g] >= 0 || slot_p[g] >= 0) && (!scal || scal_ld < B)) JCK_FAIL(JCK_E_ARG, "head_fwd: scalar slots need scal with scal_ld >= B");
   }
-  DISPATCH_T(prec, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(G * B), dim3(256), 0, (hipStream_t)stream, (const T*)a4, wp, K, bias,
-                                      hg, 1.0f / (float)B, prob, ds, scal, scal_ld));
+  DISPATCH_T(prec, LAUNCH_EV(head_fwd_kernel<T>, dim3(G * B), dim3(256), 0, stream, done, (const T*)a4, wp, K, bias,
+                             hg, 1.0f / (float)B, prob, ds, scal, scal_ld, (T*)g_out));
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -1032,6 +1039,17 @@ int head_bwd_conv2_ev(int prec, const float* ds, const float* wp, const void* a4
   if (!g_a4 && !grad) return JCK_OK;
   if (grad && !ws) JCK_FAIL(JCK_E_ARG, "head_bwd_conv: the weight gradient needs a workspace of jck_head_bwd_ws_floats(16*C) floats");
   const int K = 16 * C;
+  if (!g_a4 && grad && side) {
+    // only the weight gradient is wanted (the rows' input gradient came out of head_fwd_grouped_ev, which completed `handover`):
+    // the partial rows and their sum both run on `side`
+    HIPCHK(hipStreamWaitEvent(side, handover, 0));
+    DISPATCH_T(prec, hipLaunchKernelGGL(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, side, ds, wp,
+                                        (const T*)a4, B, K, C, (T*)nullptr, ws, 0));
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(head_part_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, side, ws, HEAD_CONV_NS, K, C, grad, 1);
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   hipEvent_t ev = grad ? handover : nullptr;
   DISPATCH_T(prec, LAUNCH_EV(head_bwd_fused_kernel<T>, dim3(cdiv(K / 8, 64), HEAD_CONV_NS), dim3(256), 0, stream, ev, ds, wp,
                              (const T*)a4, B, K, C, (T*)g_a4, grad ? ws : nullptr, B_more));

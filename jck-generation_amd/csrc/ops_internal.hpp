@@ -64,4 +64,7 @@ int cg_head_mid(int prec, const float* slab, int ksplit, const float* bias1, con
                 const int* slot_loss, const int* slot_p, int scal_ld, void* g_hd, void* g_h, hipStream_t stream);
 int gp_head_mid_ev(int prec, const float* slab, int ksplit, const float* mask, float scale, void* ughd, const float* w2, const float* prob, int B,
                    float* rs, float* dw2, float* ws, void* g_hd, void* g_h, hipStream_t stream, hipStream_t side, hipEvent_t handover);
+int head_fwd_grouped_ev(int prec, const void* a4, const float* wp, const float* bias, int B, int K, int G, const float* targets,
+                        const int* modes, float* prob, float* ds, float* scal, const int* slot_loss, const int* slot_p, int scal_ld,
+                        void* g_out, hipStream_t stream, hipEvent_t done);
 int tanh_bwd_ev(int prec, const void* g, const void* y, float scale, void* out, long long numel, hipStream_t stream, hipEvent_t done);

@@ -279,7 +279,8 @@ def test_per_pass_schedule_at_the_8gpu_tail_batch():
 def test_launches_folded_into_their_neighbours_leave_the_step_bit_for_bit(family, B, inkernel, env, monkeypatch):
     """Round 4 folds small launches into their neighbours: D.zero_grad() into the step's set-step launch, G.zero_grad() into D's
     Adam launch, the tanh + noise-mix backward of G's output into the epilogue of D.conv1's input gradient (on the value as the
-    separate launch read it: rounded to bf16 first).  JCK_FOLD_ZERO=0 / JCK_FUSE_TANH=0 keep the launches.  Three bf16 steps each
+    separate launch read it: rounded to bf16 first), conv5's input gradient into the launch that forms the logits (CGAN: the middle
+    of its head as one launch).  JCK_FOLD_ZERO=0 / JCK_FUSE_TANH=0 / JCK_HEAD_FUSE=0 keep the launches.  Three bf16 steps each
     way, with explicit noise tensors and with the instance noise drawn inside the kernels (as the trainers and bench.py run):
     bit-identical weights, moments, gradients and scalars (batched schedule, CGAN, per-pass schedule)."""
     import bf16_error as be
@@ -293,7 +294,7 @@ def test_launches_folded_into_their_neighbours_leave_the_step_bit_for_bit(family
     imgs = synth_images(B * 3)
     runs = []
     for plain in (False, True):
-        for k in ("JCK_FUSE_TANH", "JCK_FOLD_ZERO"):
+        for k in ("JCK_FUSE_TANH", "JCK_FOLD_ZERO", "JCK_HEAD_FUSE"):
             monkeypatch.setenv(k, "0" if plain else "1")
         eng = (CganEngine if family == "cgan" else DcganEngine)(batch=B, prec="bf16")
         eng.load_state(g, d)
