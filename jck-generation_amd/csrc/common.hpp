@@ -91,10 +91,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// sum over the 16 lanes that share (lane>>4)
+// sum over the 16 lanes that share (lane>>4), valid in every lane.  DPP row rotations (v_add_f32 ... row_ror:n) instead of
+// __shfl_xor, which hipcc lowers to ds_bpermute_b32 - an LDS-crossbar round trip of ~100 cycles per step, 4 dependent steps per
+// value, hundreds of them in a GEMM tile epilogue (round 5: the per-tile statistics cost 8-23 us of a 65-100 us launch).  Lane i
+// adds, step by step, partial sums over the same lane sets as the xor butterfly does, and float addition is commutative: the
+// same bits.
+template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_row<0x128>(v);      // row_ror:8
+  v += dpp_row<0x124>(v);      // row_ror:4
+  v += dpp_row<0x122>(v);      // row_ror:2
+  v += dpp_row<0x121>(v);      // row_ror:1
   return v;
 }
 // block sum for blockDim.x == 256 (4 waves); result valid in every thread
@@ -104,6 +113,23 @@ __device__ __forceinline__ float block_sum256(float v, float* sm /* >= 4 floats 
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
   return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Transposing row reduction: lane r = lane & 15 returns the sum, over the 16 lanes of its row, of v[r].  A halving butterfly (xor
+// 8, 4, 2, 1; the half a lane keeps is chosen by that bit of r): 15 DPP adds instead of the 64 that sixteen row16_sum calls take,
+// and ONE live result per lane instead of sixteen - which is what lets the persistent gather-GEMM carry its BatchNorm sums across
+// tiles in 2 registers instead of 32.  Fixed order: deterministic.
+__device__ __forceinline__ float row16_transpose_sum(const float (&v)[16], int r) {
+  float w8[8], w4[4], w2[2];
+  const bool b3 = r & 8, b2 = r & 4, b1 = r & 2, b0 = r & 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w8[i] = (b3 ? v[i + 8] : v[i]) + dpp_row<0x128>(b3 ? v[i] : v[i + 8]);            // xor 8 = row_ror:8
+#pragma unroll
+  for (int i = 0; i < 4; ++i)                                                                                     // xor 4 = quad reverse, then half mirror
+    w4[i] = (b2 ? w8[i + 4] : w8[i]) + dpp_row<0x141>(dpp_row<0x1B>(b2 ? w8[i] : w8[i + 4]));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w2[i] = (b1 ? w4[i + 2] : w4[i]) + dpp_row<0x4E>(b1 ? w4[i] : w4[i + 2]);          // xor 2 = quad_perm [2,3,0,1]
+  return (b0 ? w2[1] : w2[0]) + dpp_row<0xB1>(b0 ? w2[0] : w2[1]);                                                // xor 1 = quad_perm [1,0,3,2]
 }
 
 // ---- MFMA --------------------------------------------------------------------------------------------

@@ -505,7 +505,18 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
 // the stores ran the 3B products 11-28 % faster: the store path, not the MFMA, was the tail of every tile).  bf16, no bias / tanh /
 // fp32 output / BatchNorm-backward statistics - the launcher sends those launches to igemm_dma_kernel.
 __device__ __forceinline__ int igemm_perm_row(int r) { return 8 * ((r & 15) >> 2) + 4 * (r >> 4) + (r & 3); }
-template <int BCH, int BPIX, int FM, int FN, int WPIXN>
+// per-lane partial BatchNorm sums of fragment pair k over the lane's FN pixels: v[c] = sum y, v[8 + c] = sum y^2 of channel 8g + c
+template <int FM, int FN>
+__device__ __forceinline__ void igemm_pair_sums(const f32x4 (&acc)[FM][FN], int k, float (&v)[16]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { const float y = acc[2 * k + (c >> 2)][j][c & 3]; s += y; q += y * y; }
+    v[c] = s; v[8 + c] = q;
+  }
+}
+template <int BCH, int BPIX, int FM, int FN, int WPIXN, bool NOSTORE = false>
 __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z,
                                                     int bidx, int bidy, int m0, int ch0, bool tile_stats = true) {
   static_assert(FM % 2 == 0, "fragment pairs");
@@ -516,22 +527,14 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
     const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
     float* sp = p.stats + slot * 2 * p.cstat;
+    const int r = lane & 15;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int ch = ch0 + wch * FM * 16 + (i >> 1) * 32 + 8 * g + 4 * (i & 1);
-      const bool chok = ch < p.NchStore;
-      const int cc = ch & (p.cstat - 1);
-      float sm[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; sm[r] += v; q[r] += v * v; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); q[r] = row16_sum(q[r]); }
-      if ((lane & 15) == 0 && chok) {
-        *reinterpret_cast<f32x4*>(sp + cc) = f32x4{sm[0], sm[1], sm[2], sm[3]};
-        *reinterpret_cast<f32x4*>(sp + p.cstat + cc) = f32x4{q[0], q[1], q[2], q[3]};
-      }
+    for (int k = 0; k < FM / 2; ++k) {
+      float v[16];
+      igemm_pair_sums<FM, FN>(acc, k, v);
+      const float t = row16_transpose_sum(v, r);                     // lane r: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7)
+      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+      if (ch < p.NchStore) sp[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = t;
     }
   }
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
@@ -545,6 +548,7 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
       if (ch >= p.NchStore) continue;
       const float v[8] = {acc[2 * k][j][0], acc[2 * k][j][1], acc[2 * k][j][2], acc[2 * k][j][3],
                           acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
+      if constexpr (NOSTORE) asm volatile("" :: "v"(v[0]), "v"(v[7])); else
       st8(outp + off + ch, v);
     }
   }
@@ -560,13 +564,17 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
 // the same results.  Forward statistics (p.stat_accum) are accumulated per workgroup and BatchNorm group.
 // Both roles execute exactly (tiles of this workgroup) x (K / 64) barriers.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BCH, int BPIX, int NCW>
+template <int BCH, int BPIX, int NCW, int ADIV = 1, bool PIPE = false>
 __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const IgemmParams p) {
   typedef PrecBf16 P;
   typedef IgemmCfg<P, BCH, BPIX, NCW> C;
   constexpr int FM = C::FM, FN = C::FN, LD = IG_BK;
   constexpr int STG_BYTES = (BCH + BPIX) * LD * 2;
-  constexpr int NLD = (BCH + BPIX) / 32;
+  // ADIV != 1: TIMING EXPERIMENTS ONLY (wrong results): 2 / 4 = part of the gather skipped; 101 no loads, 102 no MFMAs, 103 no epilogue, 104 barriers only
+  constexpr bool NOLOAD = ADIV == 101 || ADIV == 104 || ADIV == 108, NOMFMA = ADIV == 102 || ADIV == 104, NOEPI = ADIV == 103 || ADIV == 104 || ADIV == 108;
+  constexpr bool NOSTORE = ADIV == 105, NOSTAT = ADIV == 106, NOREAD = ADIV == 107 || ADIV == 108;
+  constexpr int AD = ADIV > 100 ? 1 : ADIV;
+  constexpr int NLD = NOLOAD ? 0 : (BCH + BPIX / AD) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* lds = smem_raw;
 
@@ -625,6 +633,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     const auto rs_a = make_rsrc(p.act, p.act_bytes);
     const auto rs_wt = make_rsrc(p.w, p.w_bytes);
     auto issue = [&](int kc, int stage) {
+      if constexpr (NOLOAD) return;
       const int kbase = kc * IG_BK;
       unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);
 #pragma unroll
@@ -636,7 +645,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       const int dyv = tp >> 16, dxv = (int)(short)(tp & 0xffff);
       const unsigned toffb = (unsigned)((((dyv * p.W + dxv) << p.logC) + (kbase & (Cc - 1))) * 2);
 #pragma unroll
-      for (int ps = 0; ps < C::APASS; ++ps) {
+      for (int ps = 0; ps < C::APASS / AD; ++ps) {
         const bool ok = (unsigned)(riy[ps] + dyv) < (unsigned)p.H && (unsigned)(rix[ps] + dxv) < (unsigned)p.W;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sb + (BCH + ps * 32) * (LD * 2)), 16,
                                                  (int)(ok ? rowoff[ps] + toffb + src_chunk : JCK_OOB), 0, 0, 0);
@@ -657,6 +666,10 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       if constexpr (NLD == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if constexpr (NLD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if constexpr (NLD == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if constexpr (NLD == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (NLD == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if constexpr (NLD == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else static_assert(NLD == 8 || NLD == 6 || NLD == 12, "add the vmcnt literal");
     };
     for (int s = 0; s < steps; ++s) {
@@ -677,7 +690,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   // in increasing pixel order): rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with
   // its channel tile; needs the launcher's divisibility conditions.  Rows of groups a workgroup has no tile in are zeros.
   constexpr int NPAIR = FM / 2;
-  float S1[NPAIR][8], S2[NPAIR][8];
+  float S[NPAIR];                // lane r = lane & 15: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7) of pair k (row16_transpose_sum)
   int cur_group = -1, next_row_group = 0;
   const bool acc_stats = p.stats && p.stat_accum;
   const int ngroups = acc_stats ? (p.bn_group_rows > 0 ? (p.M + p.bn_group_rows - 1) / p.bn_group_rows : 1) : 0;
@@ -689,25 +702,15 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     rank = xcd * per_xcd + idx / p.gy;
     rows_per_group = (int)(gridDim.x / p.gy) * C::WPIX;
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { S1[k][c] = 0.f; S2[k][c] = 0.f; }
+    for (int k = 0; k < NPAIR; ++k) S[k] = 0.f;
   }
   auto rows_write = [&](int grp, bool zero) __attribute__((always_inline)) {
     float* row = p.stats + ((long long)grp * rows_per_group + rank * C::WPIX + wpix) * 2 * p.cstat;
+    const int r = lane & 15;
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) {
       const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * (lane >> 4);
-      float a[8], b[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { a[c] = zero ? 0.f : row16_sum(S1[k][c]); b[c] = zero ? 0.f : row16_sum(S2[k][c]); }
-      if ((lane & 15) == 0 && ch < p.NchStore) {
-        const int cc = ch & (p.cstat - 1);
-        *reinterpret_cast<f32x4*>(row + cc) = f32x4{a[0], a[1], a[2], a[3]};
-        *reinterpret_cast<f32x4*>(row + cc + 4) = f32x4{a[4], a[5], a[6], a[7]};
-        *reinterpret_cast<f32x4*>(row + p.cstat + cc) = f32x4{b[0], b[1], b[2], b[3]};
-        *reinterpret_cast<f32x4*>(row + p.cstat + cc + 4) = f32x4{b[4], b[5], b[6], b[7]};
-      }
+      if (ch < p.NchStore) row[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = zero ? 0.f : S[k];
     }
   };
   auto stat_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
@@ -716,9 +719,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     if (grp > next_row_group) next_row_group = grp;
     cur_group = grp;
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { S1[k][c] = 0.f; S2[k][c] = 0.f; }
+    for (int k = 0; k < NPAIR; ++k) S[k] = 0.f;
   };
   for (int L = blockIdx.x; L < ntiles; L += gridDim.x) {
     locate(L);
@@ -727,6 +728,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!PIPE) {
     for (int k = 0; k < nk; ++k) {
       __builtin_amdgcn_s_barrier();
       const bf16_t* wt0 = reinterpret_cast<const bf16_t*>(lds + slot * STG_BYTES);
@@ -747,20 +749,88 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
       }
       slot = slot == 2 ? 0 : slot + 1;
     }
+    } else {
+      // Software-pipelined consumer (round 5).  The fragments of a 32-deep half-step are read into registers while the MFMAs of
+      // the half-step before run, across the k-step border too: the plain loop above exposes the LDS latency of every read group
+      // (6 reads, 8 MFMAs, 2 reads, 4 MFMAs, ... - the disassembly), and both consumer waves of a SIMD do so at the same moment.
+      //   half-step (k,0): reads of (k,1) are issued, then 16 MFMAs on the registers of (k,0)
+      //   half-step (k,1): half of its MFMAs, then lgkmcnt(0) (every read of stage k has completed: the loaders may refill it
+      //                    behind the barrier), the barrier that certifies stage k+1, the reads of (k+1,0), the other half.
+      // Same products in the same order per accumulator as the plain loop: bitwise the same results.
+      const int offA = (wch * FM * 16 + (lane & 15)) * LD * 2, offB = (BCH + wpix * FN * 16 + (lane & 15)) * LD * 2;
+      const int c0 = ((lane >> 4) ^ sw) * 16, c1 = (((lane >> 4) + 4) ^ sw) * 16;
+      bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+      auto rd = [&](bf16x8 (&a)[FM], bf16x8 (&b)[FN], int sl, int col) __attribute__((always_inline)) {
+        const unsigned char* base = lds + sl * STG_BYTES + col;
+        if constexpr (NOREAD) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(b[j]));
+#pragma unroll
+          for (int i = 0; i < FM; ++i) asm volatile("" : "=v"(a[i]));
+          return;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = lds_frag(reinterpret_cast<const bf16_t*>(base + offB + j * 16 * LD * 2));
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = lds_frag(reinterpret_cast<const bf16_t*>(base + offA + i * 16 * LD * 2));
+      };
+      auto mm = [&](bf16x8 (&a)[FM], bf16x8 (&b)[FN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            if constexpr (NOMFMA) asm volatile("" :: "v"(a[i]), "v"(b[j]));
+            else acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+          }
+      };
+      // one read, then MFMAs, ... : a burst of 8 reads per wave, issued by all 8 waves at the same moment behind the barrier, fills the
+      // LDS queue and the wave sits at its next ds_read instead of issuing the MFMAs behind it
+      auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < FM + FN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (FM * FN) / (FM + FN), 0);
+        }
+      };
+      __builtin_amdgcn_s_barrier();
+      rd(a0, b0, slot, c0);
+      for (int k = 0; k < nk - 1; ++k) {
+        rd(a1, b1, slot, c1);
+        mm(a0, b0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        rd(a0, b0, slot, c0);
+        mm(a1, b1);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      rd(a1, b1, slot, c1);
+      mm(a0, b0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot == 2 ? 0 : slot + 1;
+      mm(a1, b1);
+    }
     const int grp = (acc_stats && p.bn_group_rows > 0) ? m0 / p.bn_group_rows : 0;
     if (acc_stats && grp != cur_group) stat_switch(grp);
-    igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats);
-    if (acc_stats) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
+    if constexpr (NOEPI) {
 #pragma unroll
-      for (int k = 0; k < NPAIR; ++k)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else
+    igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX, NOSTORE>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats && !NOSTAT);
+    if (acc_stats && !NOEPI && !NOSTAT) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float v = acc[2 * k + (c >> 2)][j][c & 3];
-            S1[k][c] += v;
-            S2[k][c] += v * v;
-          }
+      for (int k = 0; k < NPAIR; ++k) {
+        float v[16];
+        igemm_pair_sums<FM, FN>(acc, k, v);
+        S[k] += row16_transpose_sum(v, lane & 15);
+      }
     }
   }
   if (acc_stats) stat_switch(ngroups);
