@@ -205,10 +205,14 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
               : g_igemm_dbg == 105 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 105, true> : g_igemm_dbg == 106 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 106, true>
               : g_igemm_dbg == 107 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 107, true> : g_igemm_dbg == 108 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 108, true>
               : g_igemm_pipe ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 1, true> : igemm_dma_persist_kernel<BCH, BPIX, NCW>;
-  static bool attr_done = false;
-  if (!attr_done || g_igemm_dbg || true) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+  static const void* attr_done[16] = {};                             // the variants of this tile that have their LDS attribute set
+  {
+    int i = 0;
+    while (i < 16 && attr_done[i] && attr_done[i] != reinterpret_cast<const void*>(kern)) ++i;
+    if (i < 16 && !attr_done[i]) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done[i] = reinterpret_cast<const void*>(kern);
+    }
   }
   dim3 grid(cdiv(p.M, BPIX), nch_pad / BCH, phases);
   IgemmParams q = p;
