@@ -231,6 +231,10 @@ def measure(a, model, world, rank, dev, dist):
     if red:
         ddp["mode"] = ("D all-reduce in two pieces under D's own backward + G all-reduce under the next batch's D(real) forward"
                        if overlap["on"] and not cgan else "one all-reduce per network, waited for before its Adam")
+        # phases issued while an all-reduce is in flight never launch a grid-barrier kernel when the collective has peers to wait
+        # for: RCCL's kernel holds CUs (include/jckgan.h JCK_PHASE_NO_RESIDENT)
+        ddp["bn_backward_under_collectives"] = ("three-launch form (no grid barrier while RCCL holds CUs)"
+                                                if eng.collective_world() > 1 else "resident form (one rank: the collective waits for nobody)")
         torch.cuda.synchronize()
         ddp["replicas_in_sync_after_warmup"] = guard.check()
         if not ddp["replicas_in_sync_after_warmup"] and overlap["on"]:
@@ -385,6 +389,37 @@ def measure(a, model, world, rank, dev, dist):
     return res
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as child processes of this one
+    (same arguments; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), pass rank 0's JSON line
+    through, return the worst exit status.  The parent makes no HIP call (nothing here imports torch): a process that has
+    initialised the GPU must not be the one that starts or replaces others on this pool."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:                       # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, status): {bad}", file=sys.stderr)
+        return max(abs(c) for _, c in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,13 +439,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the CGAN (configs[3]) measurement of the one-GPU run")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself and never touches the GPU
+        sys.exit(self_launch(a.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch one rank per GPU: torch.distributed.run "
+                 f"--nproc-per-node {a.gpus}, or run `python bench.py --gpus {a.gpus}` without WORLD_SIZE set)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
     # test hooks (tests/test_bench_multirank_gpu.py rehearses the N > 1 control flow on a one-GPU box): every rank on
     # cuda:0 and gloo instead of RCCL (RCCL needs one device per rank).  Never set by the driver.

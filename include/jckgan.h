@@ -293,6 +293,13 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
  * runs Adam over everything but the bottom conv weight - the last product of that stream - while it finishes, and that one
  * tensor behind it.  Any other phase that follows joins first.  Same kernels on the same values: bitwise the plain order. */
 #define JCK_PHASE_LAZY_JOIN 0x100
+/* OR-ed into any phase: the BatchNorm backward launches of THIS call take the three-launch form instead of the resident
+ * (grid-barrier) one.  A resident launch needs every CU of the device: while a collective is in flight (data parallel, N > 1:
+ * RCCL's kernel holds CUs until every peer has arrived) its missing workgroups could not be placed and the placed ones would
+ * spin at the barrier until its time bound - hipgan/engine.py sets the flag on the phases it issues between the start of an
+ * all-reduce and the wait for it (train/dcgan_trainer.py:180,189 are the exchange points).  Same sums in another order: held to
+ * the oracle like the resident form. */
+#define JCK_PHASE_NO_RESIDENT 0x200
 typedef struct jck_step_inputs {
   const float* real_nchw; /* [B,3,64,64] fp32 */
   const float* noise_real; /* [B,3,64,64] N(0,1); NULL (with noise_fake NULL): drawn inside the kernels (jck_engine_set_noise_seed) */
@@ -319,8 +326,12 @@ long long jck_engine_grad_tail(const jck_engine*, int net);
  * gradient stream (the stall cost more than the early all-reduce hid); the caller starts the tail's all-reduce from ANOTHER stream
  * that it first passes here - it then waits for the tail's last writers on both engine streams. */
 int jck_engine_order_after_tail(jck_engine*, void* stream);
+/* abandons a PHASE_D_REAL_FWD enqueued ahead for the next step (D's weights are about to be overwritten from outside the step:
+ * the replica guard's re-broadcast, load_model): `stream` waits for that forward, the next D phase recomputes it */
+int jck_engine_drop_prefetch(jck_engine*, void* stream);
 /* after a device synchronisation: JCK_E_HIP if a grid barrier of a resident launch (jck_bn_act_bwd_res) timed out since the last
- * call - the step's results are then invalid; the barrier state is re-armed */
+ * call - that launch went on with incomplete sums, so the step's results are invalid; the engine's optimiser phases read the same
+ * word on the device and leave parameters and Adam moments untouched while it is set.  The call re-arms the barrier state. */
 int jck_engine_check(jck_engine*);
 const float* jck_engine_scalars(const jck_engine*);
 const float* jck_engine_scalars_at(const jck_engine*, int step);   /* buffer of the given (1-based) step's parity */

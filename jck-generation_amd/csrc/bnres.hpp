@@ -21,7 +21,9 @@
 // top counter, the last of those publishes the generation; one lane polls it relaxed with s_sleep, ONE agent-scope acquire,
 // workgroup barrier, plain loads.  Counters are reset by their last arriver before the release and the generation is monotonic
 // across launches (read once at kernel start, before the first arrival): no memset per launch, graph replay safe.  Every spin is
-// bounded (s_memrealtime); a timeout sets the error word (checked by the host at its next synchronisation) and the launch ends.
+// bounded (s_memrealtime); a timeout sets the error word and the launch goes on with whatever rows it can read - its results are
+// invalid: the engine's Adam launches read the word and leave the weights alone, the host raises at jck_engine_check (step
+// scalars, replica guard, checkpoint / evaluation snapshots, end of training, bench.py).
 // All workgroups must be co-resident: the launcher sizes the grid to the CU count (one 512-thread workgroup with up to 256
 // VGPRs owns a CU), so two such launches must not run at the same time on one device (one stream per engine; set
 // JCK_BN_RES=0 when several processes share a GPU).

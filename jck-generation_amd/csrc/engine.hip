@@ -1048,7 +1048,11 @@ static int clear_acc(jck_engine* e, int step, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream);
 extern "C" int jck_engine_phase(jck_engine* e, int phase, const jck_step_inputs* in_, void* stream) {
-  const int rc = phase_impl(e, phase, in_, stream);
+  // JCK_PHASE_NO_RESIDENT: no grid-barrier launch in this call (a collective may be holding CUs: include/jckgan.h)
+  const bool keep_res = e ? e->bn_res : false;
+  if (e && (phase & JCK_PHASE_NO_RESIDENT)) e->bn_res = false;
+  const int rc = phase_impl(e, phase & ~JCK_PHASE_NO_RESIDENT, in_, stream);
+  if (e) e->bn_res = keep_res;
   if (rc != JCK_OK && e) {
     // a phase that failed half way leaves no promise behind: the next D phase clears its arenas itself and joins the
     // weight-gradient stream before anything else (state armed before a failing call must not outlive it)
@@ -1323,14 +1327,15 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         const long long cut = c1->offset + c1->numel;
         HIPCHK(hipStreamWaitEvent(st, e->mid_recorded ? e->evWmid : e->evWdone, 0));
         JCK_TRY(jck_adam_hp(e->dp + cut, e->dg + cut, e->dm + cut, e->dv + cut, e->LD.n_params - cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st,
-                            zg, e->LG.n_params));
+                            zg, e->LG.n_params, jck_grid_sync_error_word(e->gsync)));
         JCK_TRY(repack_linear(e, st));
         if (e->mid_recorded) HIPCHK(hipStreamWaitEvent(st, e->evWdone, 0));
         e->join_pending = e->mid_recorded = false;
-        JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st));
+        JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, cut, 0.5, 0.999, 1e-8, in->grad_scale, hp, st, nullptr, 0, jck_grid_sync_error_word(e->gsync)));
         return repack_convs(e, 1, st);
       }
-      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, hp, st, zg, e->LG.n_params));
+      JCK_TRY(jck_adam_hp(e->dp, e->dg, e->dm, e->dv, e->LD.n_params, 0.5, 0.999, 1e-8, in->grad_scale, hp, st, zg, e->LG.n_params,
+                          jck_grid_sync_error_word(e->gsync)));
       return jck_engine_repack(e, 1, st);
     }
     case JCK_PHASE_G_LOSS: {                                                                      // :182-188
@@ -1353,7 +1358,8 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
     }
     case JCK_PHASE_G_STEP: {                                                                      // :189
       if (!e->hp_holds(in->step, in->lr) && !e->capturing) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
-      JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st));
+      JCK_TRY(jck_adam_hp(e->gp, e->gg, e->gm, e->gv, e->LG.n_params, 0.5, 0.999, 1e-8, in->grad_scale, e->hp2 + 8 * e->parity, st, nullptr, 0,
+                          jck_grid_sync_error_word(e->gsync)));
       {   // G's repack, the four D passes' BatchNorm records in the reference's order and the logged scalars: one launch
         TailJobs t = {};
         for (int i = 0; i < TT.NS; ++i) {
@@ -1502,6 +1508,16 @@ extern "C" int jck_engine_order_after_tail(jck_engine* e, void* stream) {
   if (!e->evTail) return JCK_OK;                    // no second stream: the tail is final in the phase's stream order
   if (e->tail_on_side) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evW[e->T.NS - 1], 0));
   HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evTail, 0));
+  return JCK_OK;
+}
+// A PHASE_D_REAL_FWD already enqueued for the next step is abandoned (its weights are about to change: a re-broadcast of the
+// replica guard, load_model): `stream` waits for it - it may still be reading D's packed operands on the weight-gradient stream -
+// and the next D phase computes D(real) itself.
+extern "C" int jck_engine_drop_prefetch(jck_engine* e, void* stream) {
+  if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
+  if (e->real_fwd_step >= 0 && e->pre_on_side && e->evReal && stream) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evReal, 0));
+  e->real_fwd_step = -1;
+  e->pre_on_side = false;
   return JCK_OK;
 }
 extern "C" long long jck_engine_grad_tail(const jck_engine* e, int net) {

@@ -714,12 +714,18 @@ __device__ __forceinline__ void adam_one(float& pi, float gi_raw, float& mi_io, 
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float w1 /*1-beta1*/, float beta2, float omb2 /*1-beta2*/,
                             float eps, float step_size, float bc2_sqrt, float grad_scale, const float* __restrict__ hp = nullptr,
-                            int vec = 1, float* __restrict__ zero = nullptr, long long nzero4 = 0) {
+                            int vec = 1, float* __restrict__ zero = nullptr, long long nzero4 = 0,
+                            const unsigned* __restrict__ skip_if = nullptr) {
   if (hp) { step_size = hp[0]; bc2_sqrt = hp[1]; }
+  // skip_if (the engine's grid-barrier error word): a resident launch of this step went on with incomplete sums - the gradients
+  // are invalid, so parameters and moments stay as they are (the host learns of it at jck_engine_check); the zero range below is
+  // still cleared: the next pass accumulates into it
+  const bool skip = skip_if && *skip_if != 0u;
   // zero (optional): a 16-byte aligned range of nzero4 float4 the same launch clears - the OTHER network's gradient arena, whose
   // zero_grad() (train/dcgan_trainer.py:182) is the next thing in the step
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nzero4; i += (long long)gridDim.x * blockDim.x)
     reinterpret_cast<f32x4*>(zero)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (skip) return;
   const long long n4 = vec ? (n >> 2) : 0;                 // vec = 0: a pointer is not 16-byte aligned -> element by element
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];

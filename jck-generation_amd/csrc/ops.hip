@@ -803,6 +803,7 @@ static unsigned long long* g_bnres_stamps = nullptr;
 extern "C" int jck_debug_bnres_stamps(void* buf) { g_bnres_stamps = (unsigned long long*)buf; return JCK_OK; }   // [256][8] u64, development aid
 extern "C" size_t jck_grid_sync_bytes(void) { return BNRES_SYNC_BYTES; }
 // 1 if a grid barrier of a resident launch timed out since the state was last zeroed (synchronises the device)
+const unsigned* jck_grid_sync_error_word(const void* sync_ws) { return sync_ws ? (const unsigned*)sync_ws + BNRES_W_ERR * 32 : nullptr; }
 extern "C" int jck_grid_sync_error(const void* sync_ws) {
   unsigned err = 0;
   if (!sync_ws) return 0;
@@ -1114,11 +1115,11 @@ extern "C" int jck_step_rng(float* hp, int step, unsigned long long seed, float*
   return jck_adam_set_step(hp, 2e-4, 0.5, 0.999, step, seed, (hipStream_t)stream, z, nz, alpha, nalpha, masks, nmask, keep_p);
 }
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
-                float grad_scale, const float* hp, hipStream_t st, float* zero, long long nzero) {
+                float grad_scale, const float* hp, hipStream_t st, float* zero, long long nzero, const unsigned* skip_if) {
   const int vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
   if (zero && (((uintptr_t)zero & 15) || (nzero & 3))) JCK_FAIL(JCK_E_ARG, "adam: the zero range must be 16-byte aligned, count % 4 == 0");
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp, vec, zero, zero ? nzero / 4 : 0);
+                     (float)(1.0 - beta2), (float)eps, 0.f, 1.f, grad_scale, hp, vec, zero, zero ? nzero / 4 : 0, skip_if);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }

@@ -40,7 +40,9 @@ int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step
                       long long nmask = 0, float keep_p = 0.75f, float* zero = nullptr, long long nzero = 0, float* zbig0 = nullptr,
                       long long nzbig0 = 0, float* zbig1 = nullptr, long long nzbig1 = 0);
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
-                float grad_scale, const float* hp, hipStream_t st, float* zero = nullptr, long long nzero = 0);
+                float grad_scale, const float* hp, hipStream_t st, float* zero = nullptr, long long nzero = 0,
+                const unsigned* skip_if = nullptr);      // skip_if: device word; non-zero = leave p, m, v untouched (a grid barrier of the step timed out)
+const unsigned* jck_grid_sync_error_word(const void* sync_ws);
 bool jck_prof_is_on();
 // Internal forms of the two launches whose result another stream waits for: `done` (may be null) is completed by the launch
 // that writes the result - the dispatch packet's own completion signal (hipExtLaunchKernel's stop event) instead of a

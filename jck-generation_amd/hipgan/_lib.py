@@ -104,6 +104,7 @@ PROTOS = {
     "jck_engine_repack": (i32, [vp, i32, vp]),
     "jck_engine_phase": (i32, [vp, i32, C.POINTER(StepInputs), vp]),
     "jck_engine_order_after_tail": (i32, [vp, vp]),
+    "jck_engine_drop_prefetch": (i32, [vp, vp]),
     "jck_engine_grad_tail": (i64, [vp, i32]),
     "jck_engine_check": (i32, [vp]),
     "jck_engine_scalars": (vp, [vp]),

@@ -49,12 +49,16 @@ class ReplicaGuard:
         eng = self.engines()[0]
         eng.join()
         a = eng.arenas
+        checks = [e for e in self.engines() if hasattr(e, "check")]
         c = torch.stack([a["d_params"].double().sum(), a["g_params"].double().sum(),
                          a["d_params"].double().abs().sum(), a["g_params"].double().abs().sum()])
         hi, lo = c.clone(), c.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(torch.equal(hi, lo))
+        same = bool(torch.equal(hi, lo))          # (host sync)
+        for e in checks:
+            e.check()                             # a grid-barrier timeout on this rank: raise rather than train on
+        return same
 
     def check(self, where=""):
         if self.in_sync():

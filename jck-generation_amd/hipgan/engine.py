@@ -15,6 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, lo
 (PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD, PHASE_D_LOSS_A,
  PHASE_D_LOSS_B) = range(10)
 PHASE_LAZY_JOIN = 0x100
+PHASE_NO_RESIDENT = 0x200          # include/jckgan.h: no grid-barrier launch in this phase call (a collective may be holding CUs)
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
 
@@ -229,6 +230,11 @@ class DcganEngine:
 
     def mark_weights_changed(self):
         self._shared["version"] += 1
+        if getattr(self, "_prefetched_real", None) is not None:
+            # the next step's D(real) forward is already in flight with the OLD weights (step_async(next_real=...)): the current
+            # stream waits for it before anything overwrites or repacks them, and the next step computes it afresh
+            lib.jck_engine_drop_prefetch(self._h, torch.cuda.current_stream().cuda_stream)
+            self._prefetched_real = None
 
     def adopt_modules(self, model_g, model_d):
         """Moves the parameters / buffers of reference-shaped nn.Modules INTO the arenas (zero copy afterwards):
@@ -546,6 +552,9 @@ class DcganEngine:
         st = torch.cuda.current_stream().cuda_stream
         h = self._h
         self.join()
+        # phases issued between the start of an all-reduce and the wait for it take the three-launch BatchNorm backward when the
+        # collective has peers to wait for (N > 1): a resident launch needs every CU and RCCL's kernel holds some
+        nores = PHASE_NO_RESIDENT if ((reduce_d or reduce_g) and self.collective_world() > 1) else 0
         tail = int(lib.jck_engine_grad_tail(h, 1)) if (reduce_d and self.family == 0 and self.ddp_overlap) else -1
         if tail > 0:
             # data parallel, batched schedule: the tail of D's gradient arena (conv4.weight .. conv5.weight, 76 % of its
@@ -564,9 +573,9 @@ class DcganEngine:
             else:
                 lib.jck_engine_phase(h, PHASE_D_LOSS_A, C.byref(si), st)
                 w_tail = reduce_d(flat[tail:])
-            lib.jck_engine_phase(h, PHASE_D_LOSS_B, C.byref(si), st)
+            lib.jck_engine_phase(h, PHASE_D_LOSS_B | nores, C.byref(si), st)      # the tail's all-reduce is in flight
             w_head = reduce_d(flat[:tail])
-            lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)
+            lib.jck_engine_phase(h, PHASE_D_GP | nores, C.byref(si), st)
             for w in (w_tail, w_head):
                 if w is not None:
                     w()
@@ -577,7 +586,7 @@ class DcganEngine:
             lib.jck_engine_phase(h, PHASE_D_LOSS | lazy, C.byref(si), st)
             if self.family == 0:
                 handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
-                lib.jck_engine_phase(h, PHASE_D_GP, C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
+                lib.jck_engine_phase(h, PHASE_D_GP | (nores if handle is not None else 0), C.byref(si), st)   # the penalty pass overlaps the D all-reduce (no gradients)
             else:                                                      # CGAN back-propagates the penalty: reduce after it
                 lib.jck_engine_phase(h, PHASE_D_GP | lazy, C.byref(si), st)
                 handle = reduce_d(self.arenas["d_grads"]) if reduce_d else None
@@ -637,8 +646,20 @@ class DcganEngine:
     def scalars(self):
         """Host copy of the eight step scalars (one device->host sync)."""
         vals = self.scalars_view().cpu().tolist()
-        lib.jck_engine_check(self._h)          # raises if a grid barrier of the step timed out (results invalid)
+        self.check()
         return dict(zip(SCALAR_NAMES, vals))
+
+    def check(self):
+        """Raises JckError if a grid barrier of a resident launch timed out since the last call (the step's results are invalid;
+        the optimiser phases left the weights untouched meanwhile).  Call behind a host synchronisation: the step scalars, the
+        replica guard, checkpoint / evaluation snapshots, the end of training and bench.py do."""
+        lib.jck_engine_check(self._h)
+
+    @staticmethod
+    def collective_world():
+        """Ranks a gradient all-reduce waits for: torch.distributed's world size, 1 without a process group."""
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
     def _ws_view(self, ptr, numel, dtype):
         """Typed view of a region of the bound workspace given its device address."""

@@ -96,6 +96,7 @@ class CGANTrainer(DCGANTrainer):
             "model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
             "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
             "optimizer_g": self.optimizer_g.state_dict(), "optimizer_d": self.optimizer_d.state_dict()}
+        self.engine.check()                     # (the copies above synchronised) never checkpoint a step whose grid barrier timed out
         torch.save(state, os.path.join(save_path, f"{iters}_{inception_score:.04f}_{fid:.04f}_{intra_fid:.04f}.pt"))
         self.save_image(save_path, iters, images)
 
@@ -231,6 +232,7 @@ class CGANTrainer(DCGANTrainer):
         self._finish_eval(best, wait=True)
         self.engine.join()
         torch.cuda.synchronize()
+        self.engine.check()
         self.logger.debug(f"train finish\ttiem: {time_to_str(time.time() - start)}")
         hist = history[:iters].cpu()
         self.losses_d, self.losses_g = hist[:, 0].tolist(), hist[:, 1].tolist()

@@ -189,6 +189,7 @@ class DCGANTrainer(Trainer):
             "model_g": {k: v.detach().cpu().clone() for k, v in self.model_g.state_dict().items()},
             "model_d": {k: v.detach().cpu().clone() for k, v in self.model_d.state_dict().items()},
             "optimizer_g": self.optimizer_g.state_dict(), "optimizer_d": self.optimizer_d.state_dict()}
+        self.engine.check()                     # (the copies above synchronised) never checkpoint a step whose grid barrier timed out
         torch.save(state, os.path.join(save_path, f"{iters}_{value:.04f}.pt"))
         _save_png(os.path.join(save_path, f"{iters}_fake_image.png"), _make_grid(images, padding=2, normalize=True), "fake images")
         self.logger.debug(f"{iters} model save")
@@ -309,6 +310,7 @@ class DCGANTrainer(Trainer):
         self._finish_eval(best, wait=True)
         self.engine.join()
         torch.cuda.synchronize()
+        self.engine.check()
         end = time.time()
         self.logger.debug(f"train finish\ttiem: {time_to_str(end - start)}")
         hist = history[:iters].cpu()

@@ -56,3 +56,28 @@ def test_one_rank_rccl_bench_reports_the_data_parallel_keys():
     assert d["comm_exposed_ms"]["d"] >= 0 and d["comm_exposed_ms"]["g"] >= 0
     assert 0 < d["n1_equivalent_ms"] < 50 and d["message_bytes"]["d"] > 1e7 and d["message_bytes"]["g"] > 1e7
     assert "two pieces" in d["mode"]
+
+
+def test_bare_bench_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment (the shape of the driver's N = 1 command
+    with another N): the parent spawns the two ranks itself, passes rank 0's single JSON line through and exits 0."""
+    env = dict(os.environ, JCK_BENCH_ONE_GPU="1", JCK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["ddp"]["rccl_world"] == 2
+    assert out["ddp"]["replicas_in_sync_at_end"]
+
+
+def test_a_failing_rank_fails_the_bare_launch():
+    """The self-launching parent returns the children's status: a world size the ranks refuse (--gpus 2 with WORLD_SIZE=3 set by
+    hand is a usage error in every rank) must not read as success."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

@@ -72,7 +72,11 @@ def _run(G, fn_res, y, ga, aux, slope, grad_groups, ws=None, inplace=False):
 # rows chosen to cover: one chunk per thread with most rows empty, ragged tails, several chunks, the production layer shapes
 # at a small batch (C = 64 / 128 / 256 / 512 -> 1 / 2 / 4 / 8 channel slices)
 CASES = [(512, 64, 1, 0.2, 1), (4096 + 37, 64, 3, 0.2, 2), (20000, 128, 2, 0.0, 2), (16384, 256, 3, 0.2, 2), (1000, 512, 1, 0.0, 1),
-         (4096, 512, 3, 0.2, 2), (70000, 64, 1, 0.0, 1), (3, 128, 2, 0.2, 0)]
+         (4096, 512, 3, 0.2, 2), (70000, 64, 1, 0.0, 1), (3, 128, 2, 0.2, 0),
+         # groups that do NOT fit the registers together (groups * chunks > 16): the launch walks them in several passes, refills the
+         # registers between the stores of one pass and the loads of the next and meets a second / third barrier generation - the
+         # path D.conv1's layer takes in production at batch 256 (16 chunks, 2 groups behind the loss / penalty split)
+         (262144, 64, 2, 0.2, 2), (140000, 64, 3, 0.2, 2)]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -94,8 +98,9 @@ def test_resident_backward_matches_autograd_and_the_three_launch_form(G, case):
     G.check(dg, dg3, 2e-4, "dgamma vs three-launch")
 
 
-def test_in_place_repeated_and_bitwise_reproducible(G):
-    rows, c, groups, slope = 16384 + 5, 128, 3, 0.2
+@pytest.mark.parametrize("shape", [(16384 + 5, 128, 3), (262144, 64, 2)])        # the second: two passes, two barrier generations per launch
+def test_in_place_repeated_and_bitwise_reproducible(G, shape):
+    (rows, c, groups), slope = shape, 0.2
     y, ga, gamma, beta, aux = _case(G, rows, c, groups, slope, seed=9)
     ws = _sync_ws(G)
     first = None
@@ -112,7 +117,7 @@ def test_in_place_repeated_and_bitwise_reproducible(G):
 def test_barrier_under_uneven_load_from_a_second_stream(G):
     """Another stream keeps a varying part of the chip busy (and the caches warm with the tensors) while the resident launch
     runs: the workgroups become resident at different times and the barrier must still hand over every partial row."""
-    rows, c, groups, slope = 65536, 64, 3, 0.2
+    rows, c, groups, slope = 140000, 64, 3, 0.2          # 9 chunks x 3 groups: more than the registers hold, three passes
     y, ga, gamma, beta, aux = _case(G, rows, c, groups, slope, seed=5)
     ws = _sync_ws(G)
     base = _run(G, True, y, ga, aux, slope, 2, ws)
