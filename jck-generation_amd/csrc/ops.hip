@@ -10,7 +10,12 @@
 static thread_local std::string g_err;
 void jck_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* jck_last_error(void) { return g_err.c_str(); }
-extern "C" int jck_version(void) { return 100; }
+// hash of csrc/ + include/jckgan.h at build time (hipgan/build.py passes it; the loader refuses a binary whose answer differs from
+// the sources beside it); 100 for a hand-made build without the define
+#ifndef JCK_BUILD_ID
+#define JCK_BUILD_ID 100
+#endif
+extern "C" int jck_version(void) { return JCK_BUILD_ID; }
 extern "C" int jck_pad_rows(int c) { return c <= 16 ? 16 : (c <= 64 ? 64 : (c + 127) / 128 * 128); }
 extern "C" int jck_pad_chan(int c) { return c == 3 ? 4 : c; }
 

@@ -158,6 +158,12 @@ def load_library(path=None):
             continue
         fn = getattr(dll, name)          # AttributeError here = header / library mismatch
         fn.restype, fn.argtypes = res, args
+    if os.path.abspath(path) == os.path.abspath(LIB_PATH) and os.environ.get("JCKGAN_ALLOW_STALE") != "1":
+        from . import build as _build
+        want, got = _build.source_id(), dll.jck_version()
+        if got != want:
+            raise JckError(f"{path} was built from other sources than the ones beside it (jck_version {got}, sources {want}): "
+                           f"rebuild with `python __graft_entry__.py build`")
     _cdll = dll
     return dll
 

@@ -1,0 +1,32 @@
+"""development aid: measured max-norm / L2 errors of the f32 step's gradients at batch 256 (the bounds the tests state)"""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jck-generation_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import test_step_gpu as T
+import test_cgan_gpu as Cg
+orc, eng, out = T._run(256, 1, "f32")
+ref, got, dgr, ggr = out[0]
+for tag, refs in (("d", dgr), ("g", ggr)):
+    v = eng.named_views(tag, "grads")
+    for k, r in refs.items():
+        g = v[k].detach().float().cpu().view(r.shape)
+        print("dcgan", tag, k, "max/max %.3e" % ((g - r).abs().max() / (r.abs().max() + 1e-30)).item(), "l2 %.3e" % ((g - r).norm() / (r.norm() + 1e-30)).item())
+from hipgan.engine import CganEngine
+from oracle.gan_oracle import GanOracle
+from util import synth_images
+B = 256
+orc = GanOracle("cgan", lr=2e-4, seed=12345)
+eng = CganEngine(batch=B, prec="f32")
+eng.load_state(orc.g, orc.d)
+real = synth_images(B)
+g = torch.Generator().manual_seed(77)
+lab = torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 100).to(torch.int64)
+nz = Cg._noise(B, 900, lab)
+ref = orc.step(real, lab, nz)
+got = eng.step(real.cuda(), {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in nz.items()}, lr=2e-4)
+for tag, refs in (("d", orc.d_grads), ("g", orc.g_grads)):
+    v = eng.named_views(tag, "grads")
+    for k, r in refs.items():
+        gg = v[k].detach().float().cpu().view(r.shape)
+        print("cgan", tag, k, "max/max %.3e" % ((gg - r).abs().max() / (r.abs().max() + 1e-30)).item(), "l2 %.3e" % ((gg - r).norm() / (r.norm() + 1e-30)).item())

@@ -25,7 +25,14 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(dll, s), f"{s} declared in include/jckgan.h but not exported"
         assert s in _lib.PROTOS, f"{s} has no ctypes prototype"
-    assert dll.jck_version() >= 100
+    # ... and nothing else: the unmangled jck_* symbols of the dynamic table are exactly the header's
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[2] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("jck_")})
+    assert exported == syms, (sorted(set(exported) - set(syms)), sorted(set(syms) - set(exported)))
+    assert set(_lib.PROTOS) == set(syms), sorted(set(_lib.PROTOS) ^ set(syms))
+    from hipgan import build as b
+    assert dll.jck_version() == b.source_id() >= 100          # the binary was built from the sources beside it
     assert dll.jck_pad_rows(3) == 16 and dll.jck_pad_rows(64) == 64 and dll.jck_pad_rows(200) == 256
     assert dll.jck_pad_chan(3) == 4
 
