@@ -604,6 +604,7 @@ class DcganEngine:
             handle()
         lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1
+        self._t_engine, self._module_epoch = self.t, getattr(self, "_module_epoch", 0) + 1      # (hipgan/optim.py: EngineAdam.step)
         self._shared["last_step"] = self.t
         self._shared["version"] += 1            # weights moved; this engine's packs were refreshed by the step itself
         self._packed_version = self._shared["version"]

@@ -20,8 +20,26 @@ class EngineAdam:
         self.engine.arenas[f"{self.tag}_grads"].zero_()
 
     def step(self):
-        raise RuntimeError("the optimiser step is fused into the native engine step (jck_engine_phase); it is not called "
-                           "separately")
+        """`optimizer.step()` of a caller that keeps the reference's loop (train/dcgan_trainer.py:180,189) on the HIP modules: one
+        flat jck_adam launch over this network's arena (parameters, gradients - what the modules' `.grad` alias - and moments),
+        torch.optim.Adam's arithmetic.  The trainers of this package never call it: their step runs Adam inside
+        jck_engine_phase.  Each optimiser counts its own steps from the engine's; the engine's count follows the larger one."""
+        from ._lib import cur_stream, lib
+        eng, a = self.engine, self.engine.arenas
+        eng.join()
+        # this network's step count: the engine's count at its last own step (or loaded checkpoint), plus the steps taken here since
+        ep = getattr(eng, "_module_epoch", 0)
+        if getattr(self, "_epoch", None) != ep:
+            self._epoch, self._own_t = ep, getattr(eng, "_t_engine", eng.t)
+        t = self._own_t + 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        p = a[f"{self.tag}_params"]
+        lib.jck_adam(p, a[f"{self.tag}_grads"], a[f"{self.tag}_m"], a[f"{self.tag}_v"], p.numel(), float(g["lr"]), float(b1), float(b2),
+                     float(g["eps"]), t, 1.0, cur_stream())
+        self._own_t = t
+        eng.t = max(eng.t, t)                   # what state_dict() writes as "step"
+        eng.mark_weights_changed()              # the packed GEMM operands are rebuilt before their next use
 
     def state_dict(self):
         m, v = self.engine.named_views(self.tag, "m"), self.engine.named_views(self.tag, "v")
@@ -51,5 +69,7 @@ class EngineAdam:
             raise ValueError(f"per-parameter step counts differ: {sorted(steps)}")
         if steps:
             self.engine.t = steps.pop()
+            self.engine._t_engine = self.engine.t
+            self.engine._module_epoch = getattr(self.engine, "_module_epoch", 0) + 1
         g = sd["param_groups"][0]
         self.param_groups[0]["lr"] = g["lr"]
