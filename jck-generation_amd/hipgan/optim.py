@@ -11,6 +11,8 @@ class EngineAdam:
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
                              capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
         self.param_groups = [dict(self.defaults, params=[p for _, p in self.params])]
+        if not hasattr(engine, "_t_engine"):
+            engine._t_engine = engine.t             # the step count every network of this engine shares so far (see step())
 
     @property
     def lr(self):
@@ -32,6 +34,17 @@ class EngineAdam:
         if getattr(self, "_epoch", None) != ep:
             self._epoch, self._own_t = ep, getattr(eng, "_t_engine", eng.t)
         t = self._own_t + 1
+        # gradients: autograd accumulates in place into `.grad` tensors that alias the arena (adopt_modules), but Module.zero_grad()
+        # drops them by default (set_to_none=True, what train/dcgan_trainer.py:155,182 do) and the next backward then allocates
+        # fresh ones - those are gathered into the arena here
+        views = eng.named_views(self.tag, "grads")
+        with torch.no_grad():
+            for name, prm in self.params:
+                v = views[name]
+                if prm.grad is None:
+                    v.zero_()
+                elif prm.grad.data_ptr() != v.data_ptr():
+                    v.copy_(prm.grad.to(v.dtype).view_as(v))
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         p = a[f"{self.tag}_params"]
