@@ -86,19 +86,48 @@ __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
 }
 
 // ---- wave reductions ---------------------------------------------------------------------------------
+// (DPP row rotations + four v_readlane instead of __shfl_xor = ds_bpermute_b32: an LDS-crossbar round trip per step and value -
+// the small finalize / sums / head kernels were mostly waiting on those)
+template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 64 lanes, valid in every lane: row sums by rotation, then the four rows' totals through SGPRs in a fixed order
 __device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_row<0x128>(v);
+  v += dpp_row<0x124>(v);
+  v += dpp_row<0x122>(v);
+  v += dpp_row<0x121>(v);
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int ctrl = 0; ctrl < 4; ++ctrl) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    if (ctrl == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false); }
+    if (ctrl == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false); }
+    if (ctrl == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, false); }
+    if (ctrl == 3) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false); }
+    v += __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+  }
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * k), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * k);
+    r[k] = __builtin_bit_cast(double, ((unsigned long long)h << 32) | l);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
 }
 // sum over the 16 lanes that share (lane>>4), valid in every lane.  DPP row rotations (v_add_f32 ... row_ror:n) instead of
 // __shfl_xor, which hipcc lowers to ds_bpermute_b32 - an LDS-crossbar round trip of ~100 cycles per step, 4 dependent steps per
 // value, hundreds of them in a GEMM tile epilogue (round 5: the per-tile statistics cost 8-23 us of a 65-100 us launch).  Lane i
 // adds, step by step, partial sums over the same lane sets as the xor butterfly does, and float addition is commutative: the
 // same bits.
-template <int CTRL> __device__ __forceinline__ float dpp_row(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_row<0x128>(v);      // row_ror:8
   v += dpp_row<0x124>(v);      // row_ror:4

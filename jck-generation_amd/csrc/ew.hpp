@@ -256,11 +256,6 @@ __global__ __launch_bounds__(256) void gp_norm_kernel(const T* __restrict__ g, i
 // aux layout (floats): [0,C) scale = gamma*invstd   [C,2C) shift = beta - mean*scale
 //                      [2C,3C) mean                 [3C,4C) invstd
 // One workgroup per 4 channels: 256 slot-lanes, 16-byte loads, double accumulation, wavefront + LDS reduction.
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int slots, float count,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ running_mean, float* __restrict__ running_var,

@@ -311,8 +311,9 @@ static __device__ unsigned long long g_wgd_stamps[1024 * 8 * 4];
 // 8 consumer waves (4 per gathered tile) + 4 loader waves = 768 threads, three 48 KB stages.  The S tile is filled once for
 // twice the columns, 87 instead of 64 FLOP per filled byte - the kernels are bound by the LDS fill rate (~24 B/clk/CU), so
 // bytes per FLOP is what sets their speed.
-template <int NSTG, int NW, bool STAMP = false, bool WS = false, int GT = 1>
+template <int NSTG, int NW, bool STAMP = false, bool WS = false, int GT = 1, bool PIPE = false>
 static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad_dma_kernel(const WgradParams p) {
+  static_assert(!PIPE || (WS && !STAMP), "the software-pipelined consumer exists in the wave-specialised form");
   static_assert(!WS || (NW == 4 && NSTG == 3), "wave specialisation: 4 loader + 4*GT consumer waves, 3 LDS stages");
   static_assert(GT == 1 || (WS && !STAMP && GT == 2), "the 256-column tile exists in the wave-specialised form only");
   constexpr int BG = 128 * GT, BS = 128, FM = 4, FN = NW == 8 ? 2 : 4;
@@ -478,6 +479,65 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
         slot = slot == 2 ? 0 : slot + 1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if constexpr (PIPE) {
+      // software-pipelined consumer (round 5, as igemm_dma_persist_kernel): the transposed reads of the next 32-pixel half-step are
+      // issued under the MFMAs of this one, one read per MFMA, across the k-step border too; lgkmcnt(0) in front of the barrier
+      // says every read of the stage the loaders refill next has completed.  Same products in the same order: the same bits.
+      const unsigned char* gt0 = lds + (wg >> 1) * TILE_BYTES;
+      const unsigned char* st0 = lds + GT * TILE_BYTES;
+      bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+      auto rdh = [&](bf16x8 (&a)[FM], bf16x8 (&b)[FN], int slot, int kk) __attribute__((always_inline)) {
+        const unsigned char* gt = gt0 + slot * STG_BYTES;
+        const unsigned char* st = st0 + slot * STG_BYTES;
+        const int row = kk * 32 + (lane >> 4) * 8 + (il >> 2);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int c0 = ws * SW + j * 16;
+          b[j] = join_tr(lds_tr4(tr_addr(st, row, c0)), lds_tr4(tr_addr(st, row + 4, c0)));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int c0 = (wg & 1) * 64 + i * 16;
+          a[i] = join_tr(lds_tr4(tr_addr(gt, row, c0)), lds_tr4(tr_addr(gt, row + 4, c0)));
+        }
+      };
+      auto mm = [&](bf16x8 (&a)[FM], bf16x8 (&b)[FN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+      };
+      auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2 * (FM + FN); ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (FM * FN) / (2 * (FM + FN)), 0);
+        }
+      };
+      if (nk > 0) {
+        int slot = 0;
+        __builtin_amdgcn_s_barrier();
+        rdh(a0, b0, slot, 0);
+        for (int k = 0; k < nk - 1; ++k) {
+          rdh(a1, b1, slot, 1);
+          mm(a0, b0);
+          interleave();
+          __builtin_amdgcn_sched_barrier(0);
+          slot = slot == 2 ? 0 : slot + 1;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          rdh(a0, b0, slot, 0);
+          mm(a1, b1);
+          interleave();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        rdh(a1, b1, slot, 1);
+        mm(a0, b0);
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+      }
     } else {
       int slot = 0;
       for (int k = 0; k < nk; ++k) {
