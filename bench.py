@@ -497,6 +497,19 @@ def main():
                                       f"back-propagated gradient penalty (BASELINE.json configs[3])"}, **sec}
         sec.pop("kernels", None)
         out["secondary"] = {"cgan": sec}
+        if a.prec == "bf16":
+            # the headline config on the PARITY path (exact-fp32 MFMA, fp32 storage): the precision that meets the north star's
+            # 1e-3 per-step criterion (tests/test_step_gpu.py), driver-run every round beside the bf16 number
+            import copy
+            a32 = copy.copy(a)
+            a32.prec, a32.steps, a32.warmup, a32.no_roofline = "f32", min(a.steps, 10), min(a.warmup, 3), True
+            s32 = measure(a32, "dcgan", world, rank, dev, dist)
+            s32.pop("kernels", None)
+            out["secondary"]["f32"] = {"metric": "images/sec (G+D step) DCGAN 64x64 bs256", "unit": "images/sec", "dtype": "f32",
+                                       "steps": a32.steps, "warmup": a32.warmup,
+                                       "config": {"workload": f"DCGAN 64x64x3 synthetic, batch {B}, the headline step on the parity path "
+                                                              f"(fp32 storage, v_mfma_f32_16x16x4_f32: losses within 1e-3 of the CPU oracle per step)"},
+                                       **s32}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:

@@ -269,11 +269,26 @@ static __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __
   aux += (long long)blockIdx.y * 4 * C;
   if (stat_out) stat_out += (long long)blockIdx.y * 2 * C;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  for (int k = threadIdx.x; k < slots; k += 256) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + c0);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + C + c0);
+  // eight rows of this thread's sequence in flight (the rows are 2C floats apart: every load is a line of its own, and a launch with
+  // a thousand rows was four to sixteen DEPENDENT memory round trips long - 5-9 us for a kernel that moves a megabyte); the adds
+  // stay in sequence order: the same sums, bit for bit
+  constexpr int FU = 8;
+  for (int k0 = threadIdx.x; k0 < slots; k0 += 256 * FU) {
+    f32x4 a[FU], b[FU];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i] += (double)a[i]; q[i] += (double)b[i]; }
+    for (int u = 0; u < FU; ++u) {
+      const int k = k0 + u * 256;
+      if (k < slots) {
+        a[u] = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + c0);
+        b[u] = *reinterpret_cast<const f32x4*>(stats + (long long)k * 2 * C + C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+      if (k0 + u * 256 >= slots) break;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[i] += (double)a[u][i]; q[i] += (double)b[u][i]; }
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) { s[i] = wave_sum_d(s[i]); q[i] = wave_sum_d(q[i]); }

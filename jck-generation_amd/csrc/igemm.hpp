@@ -523,20 +523,6 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
   long long poff[FN];
   igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
   const int g = lane >> 4;
-  if (p.stats && tile_stats) {
-    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
-    const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
-    float* sp = p.stats + slot * 2 * p.cstat;
-    const int r = lane & 15;
-#pragma unroll
-    for (int k = 0; k < FM / 2; ++k) {
-      float v[16];
-      igemm_pair_sums<FM, FN>(acc, k, v);
-      const float t = row16_transpose_sum(v, r);                     // lane r: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7)
-      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-      if (ch < p.NchStore) sp[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = t;
-    }
-  }
   bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -550,6 +536,21 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
                           acc[2 * k + 1][j][0], acc[2 * k + 1][j][1], acc[2 * k + 1][j][2], acc[2 * k + 1][j][3]};
       if constexpr (NOSTORE) asm volatile("" :: "v"(v[0]), "v"(v[7])); else
       st8(outp + off + ch, v);
+    }
+  }
+  // (the tile's statistics are formed AFTER its stores have been issued: ~1 us of DPP / VALU work that runs while they drain)
+  if (p.stats && tile_stats) {
+    const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
+    const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
+    float* sp = p.stats + slot * 2 * p.cstat;
+    const int r = lane & 15;
+#pragma unroll
+    for (int k = 0; k < FM / 2; ++k) {
+      float v[16];
+      igemm_pair_sums<FM, FN>(acc, k, v);
+      const float t = row16_transpose_sum(v, r);                     // lane r: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7)
+      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
+      if (ch < p.NchStore) sp[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = t;
     }
   }
 }

@@ -41,6 +41,7 @@ static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);
 static int g_bn_res_mb = env_int("JCK_BN_RES_MB", 120);         // multi-group passes: resident form above this many MB of (g_a, y)
+static int g_bn_res_small_mb = env_int("JCK_BN_RES_SMALL_MB", 0);   // multi-group passes: resident form also at or below this many MB (launch-latency-bound layers)
 static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
 static int g_wgrad_gt = env_int("JCK_WGRAD_GT", 1);          // 2: 256-column weight-gradient tile (measured: no gain)
@@ -51,7 +52,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_pipe", &g_igemm_pipe}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_pipe", &g_igemm_pipe}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}};
@@ -824,7 +825,8 @@ static int bnres_plan(int prec, long long rows, int C, int groups, int* nb_out, 
   // Infinity Cache while all groups fit it, and then it is as fast or faster in the step (measured, DESIGN.md section 5.3:
   // D.conv2's layer at 3 x 256 images 60 vs 70 us alone, the step 1.744 vs 1.733 ms); the resident form wins where they do not
   // fit (D.conv1's layer: 3 x 2 x 33.5 MB, or 2 x 2 x 33.5 MB for its loss groups alone).  bn_res = 2 takes the resident form whenever it fits the registers.
-  if (g_bn_res == 1 && groups > 1 && (long long)groups * rows * C * 4 <= ((long long)g_bn_res_mb << 20)) return 0;
+  if (g_bn_res == 1 && groups > 1 && (long long)groups * rows * C * 4 <= ((long long)g_bn_res_mb << 20) &&
+      (long long)groups * rows * C * 4 > ((long long)g_bn_res_small_mb << 20)) return 0;
   const int nsl = C / 64;
   int nb = std::min(bnres_cus(), 256);
   nb -= nb % std::max(nsl, 8);
