@@ -288,6 +288,13 @@ int jck_engine_repack(jck_engine*, int net, void* stream);
  * arena.  Same kernels in the same order on every tensor: bitwise the results of PHASE_D_LOSS. */
 #define JCK_PHASE_D_LOSS_A 8
 #define JCK_PHASE_D_LOSS_B 9
+/* The gradient penalty alone, for a caller that keeps the reference's loop on the HIP modules (compute_gradient_penalty,
+ * train/dcgan_trainer.py:110-127, train/cgan_trainer.py:114-131): real_nchw = real_data and noise_real = fake_data, both
+ * [B,3,S,S] fp32 taken as they are, alpha [B] (CGAN: labels, drop_mask[2]).  Afterwards jck_engine_tensor("norms") holds the
+ * per-image gradient norms - the penalty is mean((norm - 1)^2) - and, CGAN, D's gradient arena holds d(penalty)/d(theta_D)
+ * (cleared first; lambda = 1): the double backward the reference obtains with create_graph=True, in closed form
+ * (hipgan/functional.py: gradient_penalty). */
+#define JCK_PHASE_GP_ONLY 10
 /* OR-ed into PHASE_D_LOSS / PHASE_D_GP (CGAN): the caller reads nothing of D's gradient arena before PHASE_D_STEP (no
  * all-reduce in between), so the phase need not wait for the weight-gradient stream before it returns.  PHASE_D_STEP then
  * runs Adam over everything but the bottom conv weight - the last product of that stream - while it finishes, and that one

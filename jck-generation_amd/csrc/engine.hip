@@ -1292,6 +1292,26 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
       e->real_fwd_step = in->step;
       return JCK_OK;
     }
+    case JCK_PHASE_GP_ONLY: {
+      // The stand-alone gradient penalty of the module path (train/dcgan_trainer.py:110-127, train/cgan_trainer.py:114-131 called
+      // outside this engine's step): real_nchw = real_data, noise_real = fake_data - both [B,3,S,S] fp32, taken as they are -, alpha
+      // (CGAN: labels, drop_mask[2]).  Leaves the per-image gradient norms in "norms" (the caller forms mean((n - 1)^2)) and, CGAN,
+      // d(penalty)/d(theta_D) with lambda = 1 in D's gradient arena, which is cleared first: the double backward in closed form.
+      if (!in->real_nchw || !in->noise_real || !in_->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_GP_ONLY needs real_nchw (real), noise_real (fake) and alpha");
+      if (e->capturing) JCK_FAIL(JCK_E_ARG, "PHASE_GP_ONLY: not inside a capture");
+      if (cg && !in_->drop_mask[2]) JCK_FAIL(JCK_E_ARG, "PHASE_GP_ONLY (CGAN) needs drop_mask[2]");
+      HIPCHK(hipMemsetAsync(e->acc, 0, (size_t)8 * e->acc_ld * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(e->dg, 0, e->LD.n_params * sizeof(float), st));
+      if (cg) HIPCHK(hipMemsetAsync(e->gw1p, 0, (size_t)L1_OUT * L1_KPAD * sizeof(float), st));
+      e->acc_clean_step = e->dg_clean_step = -1;
+      e->gp_done = e->gp_inflight = false;
+      e->head_row0 = e->head_wrow0 = 0;
+      JCK_TRY(jck_img_prep(e->prec, in->real_nchw, nullptr, 1.0f, 0.0f, e->real_noisy, B, HW, st));
+      JCK_TRY(jck_img_prep(e->prec, in->noise_real, nullptr, 1.0f, 0.0f, e->fake, B, HW, st));
+      JCK_TRY(penalty_pass(D0, st));
+      if (cg) JCK_TRY(gp_double_backward(e, gp_src_dset0(e), e->xhat, B, 1.0f, in->drop_mask[2], st, nullptr));
+      return JCK_OK;
+    }
     case JCK_PHASE_D_GP: {
       if (!in->alpha) JCK_FAIL(JCK_E_ARG, "PHASE_D_GP needs alpha");
       if (e->gp_done && cg) {                         // forward and first backward ran as group 2 of the batched pass

@@ -15,6 +15,7 @@ from ._lib import PREC_BF16, PREC_F32, JckError, StepInputs, cur_stream, lib, lo
 (PHASE_D_LOSS, PHASE_D_GP, PHASE_D_STEP, PHASE_G_LOSS, PHASE_G_STEP, PHASE_D_REAL, PHASE_D_FAKE, PHASE_D_REAL_FWD, PHASE_D_LOSS_A,
  PHASE_D_LOSS_B) = range(10)
 PHASE_LAZY_JOIN = 0x100
+PHASE_GP_ONLY = 10                 # include/jckgan.h: the gradient penalty alone (module path)
 PHASE_NO_RESIDENT = 0x200          # include/jckgan.h: no grid-barrier launch in this phase call (a collective may be holding CUs)
 _PREC = {"bf16": PREC_BF16, "f32": PREC_F32, PREC_BF16: PREC_BF16, PREC_F32: PREC_F32}
 SCALAR_NAMES = ("loss_d", "loss_g", "d_x", "d_gz1", "d_gz2", "gp", "loss_real", "loss_fake")
@@ -649,6 +650,38 @@ class DcganEngine:
         vals = self.scalars_view().cpu().tolist()
         self.check()
         return dict(zip(SCALAR_NAMES, vals))
+
+    def gradient_penalty_pass(self, real, fake, alpha, labels=None, drop_mask=None):
+        """PHASE_GP_ONLY on this engine's D weights: -> per-image gradient norms [B] (device fp32 view, valid until the next
+        call).  CGAN engines also leave d(penalty)/d(theta_D) in arenas["d_grads"] (cleared first).  real / fake: [B,3,S,S]
+        fp32 device tensors taken as they are, alpha [B]; CGAN: labels int64 one-hot [B,100], drop_mask float keep-mask [B,256]."""
+        B, S = self.batch, self.size
+        self.join()
+        if self._packed_version != self._shared["version"]:
+            self.repack()
+        si, keep = StepInputs(), []
+
+        def f32(t, n, what):
+            t = t.detach().to(self.device, torch.float32).contiguous()
+            if t.numel() != n:
+                raise JckError(f"gradient_penalty_pass: {what} has {t.numel()} elements, expected {n}")
+            keep.append(t)
+            return t.data_ptr()
+        si.real_nchw, si.noise_real = f32(real, B * 3 * S * S, "real"), f32(fake, B * 3 * S * S, "fake")
+        si.alpha = f32(alpha, B, "alpha")
+        si.lr, si.grad_scale, si.step = 2e-4, 1.0, self.t + 1
+        if self.family == 1:
+            if labels is None or tuple(labels.shape) != (B, 100) or drop_mask is None:
+                raise JckError("CGAN gradient penalty needs labels (int64 one-hot [B,100]) and a dropout keep-mask [B,256]")
+            lab = labels.to(self.device, torch.int64).contiguous()
+            keep.append(lab)
+            si.labels = lab.data_ptr()
+            si.drop_mask[2] = f32(drop_mask, B * 256, "drop_mask")
+        lib.jck_engine_phase(self._h, PHASE_GP_ONLY, C.byref(si), torch.cuda.current_stream().cuda_stream)
+        self._keep = keep
+        n = C.c_longlong()
+        p = load_library().jck_engine_tensor(self._h, b"norms", C.byref(n))
+        return self._ws_view(p, n.value, torch.float32)[:B]
 
     def check(self):
         """Raises JckError if a grid barrier of a resident launch timed out since the last call (the step's results are invalid;

@@ -2,8 +2,10 @@
 torch.autograd.Functions over the C-ABI kernels.  Tensors between stages are NHWC in the library's element type
 (bf16 or fp32, `prec`); NCHW fp32 exists only at the module boundary.
 
-First-order only: double backward (the reference's CGAN gradient penalty) is not provided by these Functions and
-raises.  No CPU path: every Function requires device tensors.
+The layer Functions are first-order (`once_differentiable`).  The one second-order quantity the reference forms - the CGAN
+gradient penalty, back-propagated through `autograd.grad(..., create_graph=True)` (train/cgan_trainer.py:114-131,200-203) - is
+provided as ONE differentiable Function, `gradient_penalty`, whose backward is the closed-form double backward of the step engine
+(PHASE_GP_ONLY).  No CPU path: every Function requires device tensors.
 """
 import ctypes
 
@@ -420,3 +422,71 @@ def cgan_discriminator(mod, x, labels, prec="bf16", mask=None):
             torch.full((x.shape[0], L1_OUT), 0.75, device=x.device)
     return _CganHead.apply(h, labels.to(x.device), mask, mod.label_embedding.weight, mod.label_embedding.bias,
                            mod.linear1.weight, mod.linear1.bias, mod.linear2.weight, mod.linear2.bias, p)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the gradient penalty as a differentiable quantity (train/dcgan_trainer.py:110-127, train/cgan_trainer.py:114-131)
+# ---------------------------------------------------------------------------------------------------------------------
+class _GradientPenalty(Function):
+    """gp = mean((|| d D(x_hat) / d x_hat ||_2 - 1)^2), x_hat = alpha * real + (1 - alpha) * fake, differentiable with respect to
+    D's parameters: forward and backward are one PHASE_GP_ONLY call of a step engine that holds D's weights - the forward pass,
+    the first backward to the image, and (CGAN) the closed-form double backward through conv, train-mode BatchNorm, LeakyReLU,
+    Linear, Dropout and the sigmoid (derivation checked against autograd(create_graph=True) in
+    tests/test_gp_double_backward_math.py).  DCGAN never back-propagates its penalty (train/dcgan_trainer.py:178-179 only logs
+    it): its engine forms the value and the Function returns zero gradients."""
+
+    @staticmethod
+    def forward(ctx, eng, real, fake, alpha, labels, mask, names, *params):
+        views = eng.named_views("d")
+        with torch.no_grad():
+            for k, p in zip(names, params):                     # the engine computes with the module's CURRENT weights
+                if views[k].data_ptr() != p.data_ptr():
+                    views[k].copy_(p.detach().to(views[k].dtype).view_as(views[k]))
+            eng.mark_weights_changed()
+            norms = eng.gradient_penalty_pass(real, fake, alpha, labels, mask)
+            gp = ((norms - 1.0) ** 2).mean()
+            gviews = eng.named_views("d", "grads")
+            ctx.grads = [gviews[k].detach().clone().view_as(p) for k, p in zip(names, params)] if eng.family == 1 else None
+            ctx.shapes = [p.shape for p in params]
+        return gp.clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if ctx.grads is None:
+            raise JckError("the DCGAN penalty is a logged value only (train/dcgan_trainer.py:178-179): it has no gradient path")
+        return (None,) * 7 + tuple(g * t for t in ctx.grads)
+
+
+def gradient_penalty(model_d, real_data, fake_data, labels=None, alpha=None, drop_mask=None, prec=None, engine=None):
+    """`compute_gradient_penalty` of the reference's trainers for the HIP modules, as a tensor that can be back-propagated
+    (CGAN: `error_d = error_real + error_fake + 10 * gp; error_d.backward()`, train/cgan_trainer.py:200-203).
+    model_d: model.CGAN.Discriminator (labels required) or model.DCGAN.Discriminator of this package.  alpha ~ U[0,1) [B,1,1,1]
+    and the Dropout keep-mask (CGAN, p = 0.25) are drawn here when not given.  engine: a step engine to run on (default: one per
+    (module, batch), cached on the module; its D arena is overwritten with the module's weights on every call).
+    BatchNorm running statistics of the module are not moved by this pass (the reference's D(interpolates) call moves them once)."""
+    from .engine import CganEngine, DcganEngine
+    _need_cuda(real_data, "gradient_penalty")
+    B = real_data.size(0)
+    cg = labels is not None
+    p_ = prec or getattr(model_d, "prec", None) or __import__("os").environ.get("JCKGAN_PREC", "bf16")
+    if engine is None:
+        cache = model_d.__dict__.setdefault("_jck_gp_engines", {})
+        key = (B, p_, real_data.device.index)
+        if key not in cache:
+            size = getattr(model_d, "image_size", 64)
+            cache[key] = (CganEngine(batch=B, prec=p_, device=real_data.device) if cg else
+                          DcganEngine(batch=B, prec=p_, device=real_data.device, **({"image_size": size} if size != 64 else {})))
+        engine = cache[key]
+    if alpha is None:
+        alpha = torch.rand(B, 1, 1, 1, device=real_data.device)
+    if cg and drop_mask is None:
+        drop_mask = (torch.rand(B, 256, device=real_data.device) >= 0.25).float()
+    names = [k for k, _ in model_d.named_parameters()]
+    params = [p for _, p in model_d.named_parameters()]
+    with torch.no_grad():                                       # buffers (running statistics) ride along with the weights
+        views = engine.named_views("d")
+        for k, b in model_d.named_buffers():
+            if k in views and views[k].data_ptr() != b.data_ptr():
+                views[k].copy_(b.detach().to(views[k].dtype).view_as(views[k]))
+    return _GradientPenalty.apply(engine, real_data, fake_data, alpha.reshape(B), labels, drop_mask, names, *params)

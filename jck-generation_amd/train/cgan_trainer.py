@@ -119,11 +119,11 @@ class CGANTrainer(DCGANTrainer):
             self.logger.warning(f"could not write the class grid: {e}")
 
     def compute_gradient_penalty(self, real_data, fake_data, labels_data):
-        alpha = torch.rand(real_data.size(0), 1, 1, 1, device=self.device)
-        inter = (alpha * real_data + ((1 - alpha) * fake_data)).detach().requires_grad_(True)
-        d_inter = self.model_d(inter, labels_data)
-        grads = torch.autograd.grad(outputs=d_inter, inputs=inter, grad_outputs=torch.ones_like(d_inter))[0]
-        return ((grads.view(grads.size(0), -1).norm(2, dim=1) - 1) ** 2).mean()
+        """The reference's penalty (:114-131) as a tensor that can be back-propagated into D's parameters, as :200-203 do
+        (`error_d = error_real + error_fake + 10 * gp; error_d.backward()`): hipgan.functional.gradient_penalty, whose backward
+        is the engine's closed-form double backward.  train() itself runs the penalty inside the native step."""
+        from hipgan import functional as HF
+        return HF.gradient_penalty(self.model_d, real_data.detach(), fake_data.detach(), labels=labels_data)
 
     # ------------------------------------------------------------------------------------------------------
     def _evaluate(self, fixed_noise, fixed_labels, iters, best, image_save_path):
