@@ -122,11 +122,8 @@ struct BnBuf { float *stats, *sums, *aux; int slots; };
 }  // namespace
 
 // the engine's events order kernels of ONE device across its streams: no system-scope fence (cache write-back for the host's sake)
-// when they are recorded; JCK_EVENT_FENCE=1 restores the default
-static unsigned jck_event_flags() {
-  static const bool fence = getenv("JCK_EVENT_FENCE") && atoi(getenv("JCK_EVENT_FENCE")) != 0;
-  return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
-}
+// when they are recorded
+static unsigned jck_event_flags() { return hipEventDisableTiming | hipEventDisableSystemFence; }
 struct jck_engine {
   int family, prec, B;
   Topo T;

@@ -565,7 +565,7 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
 // the same results.  Forward statistics (p.stat_accum) are accumulated per workgroup and BatchNorm group.
 // Both roles execute exactly (tiles of this workgroup) x (K / 64) barriers.
 // ------------------------------------------------------------------------------------------------------------------
-template <int BCH, int BPIX, int NCW, int ADIV = 1, bool PIPE = false>
+template <int BCH, int BPIX, int NCW, int ADIV = 1>
 __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const IgemmParams p) {
   typedef PrecBf16 P;
   typedef IgemmCfg<P, BCH, BPIX, NCW> C;
@@ -729,28 +729,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (!PIPE) {
-    for (int k = 0; k < nk; ++k) {
-      __builtin_amdgcn_s_barrier();
-      const bf16_t* wt0 = reinterpret_cast<const bf16_t*>(lds + slot * STG_BYTES);
-      const bf16_t* wt = wt0 + (wch * FM * 16 + (lane & 15)) * LD;
-      const bf16_t* at = wt0 + BCH * LD + (wpix * FN * 16 + (lane & 15)) * LD;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int col = (((lane >> 4) + ks * 4) ^ sw) * 8;
-        bf16x8 a[FM], b[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = lds_frag(wt + i * 16 * LD + col);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = lds_frag(at + j * 16 * LD + col);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-      }
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-    } else {
+    {
       // Software-pipelined consumer (round 5).  The fragments of a 32-deep half-step are read into registers while the MFMAs of
       // the half-step before run, across the k-step border too: the plain loop above exposes the LDS latency of every read group
       // (6 reads, 8 MFMAs, 2 reads, 4 MFMAs, ... - the disassembly), and both consumer waves of a SIMD do so at the same moment.

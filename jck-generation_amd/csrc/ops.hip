@@ -34,8 +34,7 @@ static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wa
 // s_setprio 1 for the loader waves of the wave-specialised kernels: the younger half of a workgroup loses the issue arbitration
 // (MI355X guide, "Two waves per SIMD", item 4), and the kernels are bound by how fast the loaders issue their LDS-DMA pieces -
 // +0.3..3 % per gather-GEMM (tests/_mb2.py igemm_prio 0 1 ...)
-static int g_igemm_dbg = 0;
-static int g_igemm_pipe = env_int("JCK_IGEMM_PIPE", 1);      // software-pipelined consumer waves (igemm.hpp)
+static int g_igemm_dbg = 0;            // JCK_DIAG builds only: timing-experiment variant of the persistent gather-GEMM
 static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neutral (1.905 vs 1.907 ms)
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
@@ -52,7 +51,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_pipe", &g_igemm_pipe}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_res_small_mb", &g_bn_res_small_mb},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}};
@@ -206,12 +205,18 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2;
   constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
   ProfScope prof(variant, p.flops, st);
-  auto kern = g_igemm_dbg == 2 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 2, true> : g_igemm_dbg == 4 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, (BPIX >= 128 ? 4 : 2), true>
-              : g_igemm_dbg == 101 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 101, true> : g_igemm_dbg == 102 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 102, true>
-              : g_igemm_dbg == 103 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 103, true> : g_igemm_dbg == 104 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 104, true>
-              : g_igemm_dbg == 105 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 105, true> : g_igemm_dbg == 106 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 106, true>
-              : g_igemm_dbg == 107 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 107, true> : g_igemm_dbg == 108 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 108, true>
-              : g_igemm_pipe ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 1, true> : igemm_dma_persist_kernel<BCH, BPIX, NCW>;
+  // JCK_DIAG builds (hipgan/build.py with JCK_DIAG=1 in the environment) carry the timing-experiment variants of igemm.hpp - part of
+  // the gather skipped, no loads / MFMAs / LDS reads / epilogue / stores / statistics (wrong results; jck_tune("igemm_dbg", code)):
+  // the ablation table of DESIGN.md section 7 comes from them
+#ifdef JCK_DIAG
+#define JCK_DBG_VARIANT(code) g_igemm_dbg == code ? igemm_dma_persist_kernel<BCH, BPIX, NCW, code>
+  auto kern = g_igemm_dbg == 2 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, 2> : g_igemm_dbg == 4 ? igemm_dma_persist_kernel<BCH, BPIX, NCW, (BPIX >= 128 ? 4 : 2)>
+              : JCK_DBG_VARIANT(101) : JCK_DBG_VARIANT(102) : JCK_DBG_VARIANT(103) : JCK_DBG_VARIANT(104) : JCK_DBG_VARIANT(105)
+              : JCK_DBG_VARIANT(106) : JCK_DBG_VARIANT(107) : JCK_DBG_VARIANT(108) : igemm_dma_persist_kernel<BCH, BPIX, NCW>;
+#undef JCK_DBG_VARIANT
+#else
+  auto kern = igemm_dma_persist_kernel<BCH, BPIX, NCW>;
+#endif
   static const void* attr_done[16] = {};                             // the variants of this tile that have their LDS attribute set
   {
     int i = 0;

@@ -42,7 +42,8 @@ def build(force=False, verbose=True):
     procs = []
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DJCK_BUILD_ID={bid}", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DJCK_BUILD_ID={bid}"] + \
+              (["-DJCK_DIAG"] if os.environ.get("JCK_DIAG") == "1" else []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))
