@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void conv2d_nhwc_f32_kernel(const ConvP p) {
 // 16-byte loads per thread and k-step (4 consecutive input channels of a pixel) instead of eight scalar loads behind an integer
 // division.  128 pixels x 64 channels per workgroup (each weight value is used by twice the pixels), register double buffering:
 // the loads of k-step i+1 are in flight while step i is multiplied, one barrier per step.  Same k order and the same exact-fp32
-// MFMA as the generic kernel above - the results are bitwise the same.  Measured (tests/_eval_prof.py, 64 images): see DESIGN.md.
+// MFMA as the generic kernel above - the results are bitwise the same.  Measured (tools/eval_prof.py, 64 images): see DESIGN.md.
 constexpr int CV_M = 128, CV_N = 64, CV_K = 16, CV_LDA = 20, CV_LDB = 80;
 __global__ __launch_bounds__(256) void conv2d_nhwc_f32_c16_kernel(const ConvP p) {
   __shared__ __attribute__((aligned(16))) float As[2][CV_M][CV_LDA];       // [pixel][k]: 16-byte rows; (20 m + k) % 64 is conflict-free

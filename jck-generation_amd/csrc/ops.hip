@@ -33,7 +33,7 @@ static int g_igemm_256 = env_int("JCK_IGEMM_256", 250);      // minimum number o
 static int g_igemm_persist = env_int("JCK_IGEMM_PERSIST", 7);   // persistent wave-specialised gather-GEMMs (igemm.hpp); bit 0: 128x256, 1: 128x64, 2: 64x128 tiles
 // s_setprio 1 for the loader waves of the wave-specialised kernels: the younger half of a workgroup loses the issue arbitration
 // (MI355X guide, "Two waves per SIMD", item 4), and the kernels are bound by how fast the loaders issue their LDS-DMA pieces -
-// +0.3..3 % per gather-GEMM (tests/_mb2.py igemm_prio 0 1 ...)
+// +0.3..3 % per gather-GEMM (tools/mb2.py igemm_prio 0 1 ...)
 static int g_igemm_dbg = 0;            // JCK_DIAG builds only: timing-experiment variant of the persistent gather-GEMM
 static int g_igemm_prio = env_int("JCK_IGEMM_PRIO", 1);      // in the step: neutral (1.905 vs 1.907 ms)
 static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
@@ -257,7 +257,7 @@ template <class P>
 static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsub, hipStream_t st, int* slots) {
   // bf16 tiles with >= 128 channel rows run on the LDS-DMA kernel with 2 LDS stages (64 / 48 KB -> 2-3 workgroups per CU,
   // which hide each other's load latency): 128x128 tiles while that still gives >= 512 workgroups, else 128x64.
-  // Measured on MI355X at B=256 (tests/_micro.py, us): down2 36.2 -> 29.7, down3 43.0 -> 30.3, down4 65.8 -> 40.3,
+  // Measured on MI355X at B=256 (tools/micro.py, us): down2 36.2 -> 29.7, down3 43.0 -> 30.3, down4 65.8 -> 40.3,
   // up2 47.2 -> 30.8, up3 34.5 -> 28.8; 3-4 stages at one workgroup per CU are slower.  JCK_IGEMM_DMA=0 disables.
   const int use_dma = g_igemm_dma;
   if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && p.ksplit <= 1 && !p.rows_are_phases) {

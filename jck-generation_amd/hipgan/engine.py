@@ -114,7 +114,7 @@ class DcganEngine:
         # hipGraph replay of the step (JCK_GRAPH=1 enables): one captured graph per (segment, step parity, input kind).
         # Default: off.  A captured step is linear (see jck_engine_phase), so it gives up the second stream that runs the weight
         # gradients beside the dgrad chain (+8 % DCGAN, +1.4 % CGAN), and the host is not the bottleneck: 1.15 ms of enqueue for
-        # DCGAN's 1.8 ms step, 1.9 ms for CGAN's 2.9 ms (round 3, tests/_ab.sh: CGAN eager 2.886 ms, replayed 2.97 ms - in round 2
+        # DCGAN's 1.8 ms step, 1.9 ms for CGAN's 2.9 ms (round 3, tools/ab.sh: CGAN eager 2.886 ms, replayed 2.97 ms - in round 2
         # the eager CGAN step was enqueue-bound at 3.4 ms and the graph was its default).  Replay remains the answer when the host
         # is busy or slow: 0.10-0.13 ms of host time per step.
         self.graphs = os.environ.get("JCK_GRAPH", "0") != "0"

@@ -94,7 +94,7 @@ def test_cgan_full_size_step_batch256(prec, tol, gtol):
         assert _rel(got[k], ref[k]) < tol, (k, got[k], ref[k])
     _cmp(eng.named_views("d", "grads"), orc.d_grads, gtol, "d_grads")
     # G's gradients come through the D that Adam has just stepped (tests/test_step_gpu.py::test_full_size_step_batch256): measured
-    # relative L2 <= 1.5e-2 per tensor at this batch (tests/_measure_tol.py, round 5); D's are <= 5e-4
+    # relative L2 <= 1.5e-2 per tensor at this batch (tools/measure_tol.py, round 5); D's are <= 5e-4
     _cmp(eng.named_views("g", "grads"), orc.g_grads, gtol, "g_grads")
 
 

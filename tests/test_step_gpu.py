@@ -204,7 +204,7 @@ def test_full_size_step_batch256(prec, tol):
     # D's gradients come from identical weights.  G's come through the D that Adam has just stepped: an element of D whose
     # gradient was within rounding of 0 moved the other way (2*lr), which at batch 256 shows as ~1e-2 in G's gradients.
     if prec == "f32":
-        # max-norm bounds = 4x what round 5 measured at this batch (tests/_measure_tol.py: D <= 4.9e-3, G <= 1.7e-2 of a tensor's largest
+        # max-norm bounds = 4x what round 5 measured at this batch (tools/measure_tol.py: D <= 4.9e-3, G <= 1.7e-2 of a tensor's largest
         # element; relative L2: D <= 1.4e-3, G <= 1.7e-2)
         _cmp_tensors(eng.named_views("d", "grads"), dgr, 2e-2, "d_grads", 5e-3)
         _cmp_tensors(eng.named_views("g", "grads"), ggr, 6e-2, "g_grads", 3e-2)

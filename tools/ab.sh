@@ -1,5 +1,5 @@
 # development aid: A/B runs of the bench under two settings of one environment switch on the same box
-# usage (on the GPU box): bash tests/_ab.sh VAR A B [--model cgan]
+# usage (on the GPU box): bash tools/ab.sh VAR A B [--model cgan]
 cd "$GRAFT_REPO_ROOT"
 VAR=$1; A=$2; B=$3; shift 3
 for i in 1 2; do

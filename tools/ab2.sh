@@ -1,4 +1,4 @@
-# development aid: A/B of the bench with a set of switches all 0 / all 1 on the same box.  usage: bash tests/_ab2.sh "VAR1 VAR2" [bench args]
+# development aid: A/B of the bench with a set of switches all 0 / all 1 on the same box.  usage: bash tools/ab2.sh "VAR1 VAR2" [bench args]
 cd "$GRAFT_REPO_ROOT"
 VARS=$1; shift
 for i in 1 2 3; do

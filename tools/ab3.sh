@@ -1,4 +1,4 @@
-# development aid: bench under several values of one environment switch on the same box: bash tests/_ab3.sh VAR v1 v2 v3 ...
+# development aid: bench under several values of one environment switch on the same box: bash tools/ab3.sh VAR v1 v2 v3 ...
 cd "$GRAFT_REPO_ROOT"
 VAR=$1; shift
 for i in 1 2; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# development aid: the determinism tests under several switch settings, a few runs each (usage: tests/_det.sh "ENV=.." ...; DET_K / DET_N)
+# development aid: the determinism tests under several switch settings, a few runs each (usage: tools/det.sh "ENV=.." ...; DET_K / DET_N)
 cd "$GRAFT_REPO_ROOT"
 for cfg in "$@"; do
   for rep in $(seq 1 ${DET_N:-3}); do

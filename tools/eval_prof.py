@@ -2,7 +2,7 @@
   * one pass of the metric network (InceptionV3Hip, seeded random weights - the fine-tuned ones exist nowhere offline) over the
     reference's 64 fixed-noise images: ms, images/sec, achieved TFLOP/s of the fp32 convolution chain;
   * the training step (DCGAN, batch 256, bf16) alone and while such a pass runs on a side stream.
-Run under rocprofv3 for the per-kernel table:  rocprofv3 --kernel-trace --stats -d gpurun_out/eval -o ev -- python3 tests/_eval_prof.py --only-eval
+Run under rocprofv3 for the per-kernel table:  rocprofv3 --kernel-trace --stats -d gpurun_out/eval -o ev -- python3 tools/eval_prof.py --only-eval
 Prints one JSON line."""
 import argparse
 import json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick per-kernel time table of the default bench under rocprofv3 (development aid): tests/_kstat.sh <tag> [ENV=val ...]
+# quick per-kernel time table of the default bench under rocprofv3 (development aid): tools/kstat.sh <tag> [ENV=val ...]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done

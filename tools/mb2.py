@@ -1,7 +1,7 @@
 """A/B micro-benchmark of single conv products in ONE process (jck_tune switches the variant between interleaved rounds).
-usage: python tests/_mb2.py <knob> <valA> <valB> <shape>[,<shape>...] [B ...]      (development / profiling aid)"""
+usage: python tools/mb2.py <knob> <valA> <valB> <shape>[,<shape>...] [B ...]      (development / profiling aid)"""
 import ctypes, sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jck-generation_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jck-generation_amd")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import torch
 import gpu_util as G
 knob, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

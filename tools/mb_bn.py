@@ -1,7 +1,7 @@
 """A/B micro-benchmark: BatchNorm backward as reduce + sums + apply (three launches) vs the resident one-launch form, at the
-layer shapes of a batch-256 DCGAN step (development / profiling aid).  usage: python tests/_mb_bn.py [B]"""
+layer shapes of a batch-256 DCGAN step (development / profiling aid).  usage: python tools/mb_bn.py [B]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jck-generation_amd")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jck-generation_amd")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import torch
 import gpu_util as G
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

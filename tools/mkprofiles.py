@@ -1,7 +1,7 @@
-"""Turns the rocprofv3 output of tests/_prof.sh (gpurun_out/prof) into the committed round artifacts under profiles/:
+"""Turns the rocprofv3 output of tools/prof.sh (gpurun_out/prof) into the committed round artifacts under profiles/:
 rNN_bench_kernel_stats.csv, rNN_bench_domain_stats.csv, rNN_traffic.json (HBM bytes per launch from the separate
 FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the gfx950 guide prescribes, KB -> bytes) and rNN_summary.md.
-Usage: python tests/_mkprofiles.py r01 [bench.json ...]   (development aid; reads only gpurun_out/ and profiles/)"""
+Usage: python tools/mkprofiles.py r01 [bench.json ...]   (development aid; reads only gpurun_out/ and profiles/)"""
 import collections
 import csv
 import json
@@ -29,7 +29,7 @@ def counters(path):
 
 
 def cgan_summary(tag):
-    """profiles/rNN_cgan_summary.md + rNN_cgan_kernel_stats.csv from tests/_prof_cgan.sh's output (gpurun_out/prof_cgan), if present."""
+    """profiles/rNN_cgan_summary.md + rNN_cgan_kernel_stats.csv from tools/prof_cgan.sh's output (gpurun_out/prof_cgan), if present."""
     src = os.path.join(ROOT, "gpurun_out", "prof_cgan")
     stats = os.path.join(src, "bench_kernel_stats.csv")
     if not os.path.exists(stats):

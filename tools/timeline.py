@@ -1,4 +1,4 @@
-"""One traced step of a rocprofv3 kernel trace as a timeline (development aid): python tests/_timeline.py <kernel_trace.csv> [out.txt]
+"""One traced step of a rocprofv3 kernel trace as a timeline (development aid): python tools/timeline.py <kernel_trace.csv> [out.txt]
 start offset us | duration us | HIP stream | kernel | grid, between the last-but-two and last-but-one end-of-step (pack_tail) launches."""
 import csv
 import re
