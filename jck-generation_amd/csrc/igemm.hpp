@@ -516,9 +516,33 @@ __device__ __forceinline__ void igemm_pair_sums(const f32x4 (&acc)[FM][FN], int 
     v[c] = s; v[8 + c] = q;
   }
 }
+// One row of BatchNorm partial sums per WORKGROUP (round 5): the WPIXN pixel-waves of a channel block leave their lane values in LDS
+// (sx[wave][pair][lane]) and arrive on an LDS counter; the wave that arrives last adds them in wave order - the sum does not depend
+// on who is last - and stores the block's 64 channels of the row.  No barrier (the loader waves never come here), 4x / 2x fewer
+// rows for whoever sums them (bn_fwd_fused_kernel's prologue, bn_finalize).  The counter is back at zero when the last wave leaves.
+template <int NPAIR, int WPIXN>
+__device__ __forceinline__ void igemm_wg_row(float* sx, unsigned* scnt, int wave, int lane, int wch, const float (&val)[NPAIR], float* row,
+                                             int cstat, int ch_base, int nch_store) {
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) sx[(wave * NPAIR + k) * 64 + lane] = val[k];
+  unsigned old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(scnt + wch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old != (unsigned)(WPIXN - 1)) return;
+  if (lane == 0) __hip_atomic_store(scnt + wch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < WPIXN; ++q) t += sx[((wch * WPIXN + q) * NPAIR + k) * 64 + lane];
+    const int ch = ch_base + k * 32 + 8 * g;
+    if (ch < nch_store) row[(r >> 3) * cstat + (ch & (cstat - 1)) + (r & 7)] = t;
+  }
+}
 template <int BCH, int BPIX, int FM, int FN, int WPIXN, bool NOSTORE = false>
 __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 (&acc)[FM][FN], int lane, int wch, int wpix, int z,
-                                                    int bidx, int bidy, int m0, int ch0, bool tile_stats = true) {
+                                                    int bidx, int bidy, int m0, int ch0, bool tile_stats, float* sx, unsigned* scnt) {
   static_assert(FM % 2 == 0, "fragment pairs");
   long long poff[FN];
   igemm_pixel_offsets<FN>(p, lane, wpix, m0, poff);
@@ -540,18 +564,17 @@ __device__ __forceinline__ void igemm_epilogue_perm(const IgemmParams& p, f32x4 
   }
   // (the tile's statistics are formed AFTER its stores have been issued: ~1 us of DPP / VALU work that runs while they drain)
   if (p.stats && tile_stats) {
+    // slot = one (pixel tile, phase, channel-set replica): ONE row per tile
     const int yrep = bidy / p.ytiles_per_cset, nyrep = p.gy / p.ytiles_per_cset;
-    const long long slot = (((long long)bidx * p.gz + z) * nyrep + yrep) * WPIXN + wpix;
-    float* sp = p.stats + slot * 2 * p.cstat;
-    const int r = lane & 15;
+    const long long slot = ((long long)bidx * p.gz + z) * nyrep + yrep;
+    float t[FM / 2];
 #pragma unroll
     for (int k = 0; k < FM / 2; ++k) {
       float v[16];
       igemm_pair_sums<FM, FN>(acc, k, v);
-      const float t = row16_transpose_sum(v, r);                     // lane r: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7)
-      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * g;
-      if (ch < p.NchStore) sp[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = t;
+      t[k] = row16_transpose_sum(v, lane & 15);                      // lane r: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7)
     }
+    igemm_wg_row<FM / 2, WPIXN>(sx, scnt, wch * WPIXN + wpix, lane, wch, t, p.stats + slot * 2 * p.cstat, p.cstat, ch0 + wch * FM * 16, p.NchStore);
   }
 }
 
@@ -688,7 +711,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
   int slot = 0;
   // Forward statistics (p.stats && p.stat_accum) are accumulated per LANE over the tiles of the workgroup that share a BatchNorm
   // group and leave the lanes only when the group changes and at the end (a workgroup keeps its channel tile and meets its tiles
-  // in increasing pixel order): rows [group][rank * WPIX + wpix][2][cstat], rank = position of this workgroup among those with
+  // in increasing pixel order): rows [group][rank][2][cstat] - one per workgroup (igemm_wg_row) -, rank = position of this workgroup among those with
   // its channel tile; needs the launcher's divisibility conditions.  Rows of groups a workgroup has no tile in are zeros.
   constexpr int NPAIR = FM / 2;
   float S[NPAIR];                // lane r = lane & 15: sum (r < 8) / sum of squares (r >= 8) of channel 8g + (r & 7) of pair k (row16_transpose_sum)
@@ -701,18 +724,28 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
     // first-tile wgid = base(xcd) + idx with base % gy == 0 (launcher): channel tile = idx % gy, rank = xcd * (G/8/gy) + idx / gy
     const int idx = blockIdx.x >> 3, xcd = blockIdx.x & 7, per_xcd = (int)(gridDim.x >> 3) / p.gy;
     rank = xcd * per_xcd + idx / p.gy;
-    rows_per_group = (int)(gridDim.x / p.gy) * C::WPIX;
+    rows_per_group = (int)(gridDim.x / p.gy);
 #pragma unroll
     for (int k = 0; k < NPAIR; ++k) S[k] = 0.f;
   }
+  float* sx = reinterpret_cast<float*>(lds + 3 * STG_BYTES);                    // [NCW][NPAIR][64] lane values, then WCH counters (igemm_wg_row)
+  unsigned* scnt = reinterpret_cast<unsigned*>(sx + NCW * NPAIR * 64);
+  if (wave == 0 && lane < C::WCH) scnt[lane] = 0u;                              // (ordered before its first use by the k-loop's barriers)
   auto rows_write = [&](int grp, bool zero) __attribute__((always_inline)) {
-    float* row = p.stats + ((long long)grp * rows_per_group + rank * C::WPIX + wpix) * 2 * p.cstat;
-    const int r = lane & 15;
+    float* row = p.stats + ((long long)grp * rows_per_group + rank) * 2 * p.cstat;
+    if (zero) {              // a group this workgroup has no tile in: its first pixel-wave writes the zeros (no LDS exchange: several of
+                             // these can follow one another without a barrier in between)
+      if (wpix == 0) {
+        const int r = lane & 15;
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-      const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * (lane >> 4);
-      if (ch < p.NchStore) row[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = zero ? 0.f : S[k];
+        for (int k = 0; k < NPAIR; ++k) {
+          const int ch = ch0 + wch * FM * 16 + k * 32 + 8 * (lane >> 4);
+          if (ch < p.NchStore) row[(r >> 3) * p.cstat + (ch & (p.cstat - 1)) + (r & 7)] = 0.f;
+        }
+      }
+      return;
     }
+    igemm_wg_row<NPAIR, C::WPIX>(sx, scnt, wave, lane, wch, S, row, p.cstat, ch0 + wch * FM * 16, p.NchStore);
   };
   auto stat_switch = [&](int grp) __attribute__((always_inline)) {        // grp: the group of the next tile (ngroups at the end)
     if (cur_group >= 0) { rows_write(cur_group, false); next_row_group = cur_group + 1; }
@@ -803,7 +836,7 @@ __global__ __launch_bounds__((NCW + 4) * 64) void igemm_dma_persist_kernel(const
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
     } else
-    igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX, NOSTORE>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats && !NOSTAT);
+    igemm_epilogue_perm<BCH, BPIX, FM, FN, C::WPIX, NOSTORE>(p, acc, lane, wch, wpix, z, bidx, bidy, m0, ch0, !acc_stats && !NOSTAT, sx, scnt);
     if (acc_stats && !NOEPI && !NOSTAT) {     // rows past M and taps outside the image contributed zeros to acc: no masks needed
 #pragma unroll
       for (int k = 0; k < NPAIR; ++k) {

@@ -202,7 +202,8 @@ static int launch_igemm_dma(const IgemmParams& p, int nch_pad, int phases, hipSt
 // persistent wave-specialised form: at most `cap` workgroups (what the chip holds at this tile's LDS footprint) walk the tiles
 template <int BCH, int BPIX, int NCW>
 static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phases, hipStream_t st, int* slots) {
-  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2;
+  // three stages + the per-wave BatchNorm lane values and their arrival counters (igemm_wg_row)
+  constexpr int LDSB = 3 * (BCH + BPIX) * IG_BK * 2 + NCW * (BCH >= 128 ? 2 : 1) * 256 + 64;
   constexpr int variant = BCH == 64 ? 3 : BPIX == 256 ? 20 : 1;
   ProfScope prof(variant, p.flops, st);
   // JCK_DIAG builds (hipgan/build.py with JCK_DIAG=1 in the environment) carry the timing-experiment variants of igemm.hpp - part of
@@ -242,11 +243,11 @@ static int launch_igemm_dma_persist(const IgemmParams& p, int nch_pad, int phase
   }
   if (q.stats && !q.stat_accum) {
     q.ytiles_per_cset = std::max(1, q.cstat / BCH);
-    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX);
+    if (slots) *slots = (int)(grid.x * grid.z * (grid.y / q.ytiles_per_cset));            // one row per tile (igemm_wg_row)
   }
-  if (q.stats && q.stat_accum) {    // accumulated forward statistics: rows [group][(nwg / gy) * WPIX][2][cstat] (igemm.hpp)
+  if (q.stats && q.stat_accum) {    // accumulated forward statistics: rows [group][nwg / gy][2][cstat], one per workgroup (igemm.hpp)
     const int groups = q.bn_group_rows > 0 ? (q.M + q.bn_group_rows - 1) / q.bn_group_rows : 1;
-    if (slots) *slots = groups * (nwg / (int)grid.y) * IgemmCfg<PrecBf16, BCH, BPIX, NCW>::WPIX;
+    if (slots) *slots = groups * (nwg / (int)grid.y);
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3((NCW + 4) * 64), LDSB, st, q);
   HIPCHK(hipGetLastError());
