@@ -96,6 +96,14 @@ int jck_bn_act_bwd(int prec, const void* g_a, const void* y, const float* aux, f
  * dgamma / dbeta. */
 int jck_bn_finalize_grouped(const float* stats, int slots_per_group, float count, const float* gamma, const float* beta, float eps,
                             float* aux, float* stat_out, int C, int groups, void* stream);
+/* jck_bn_finalize_grouped + jck_bn_act_fwd_grouped as ONE launch where the statistics rows are few (each workgroup owns a 64-channel
+ * slice and sums that slice's rows itself; otherwise the two launches are issued): a = act(scale * y + shift) with the batch
+ * statistics of each group, aux [groups][4C] and stat_out [groups][2C] (may be NULL) written as jck_bn_finalize_grouped writes
+ * them; running_mean / running_var / nbt (may be NULL; groups == 1 only) updated as jck_bn_finalize updates them
+ * (aten::native_batch_norm + the activation, model/DCGAN.py:30-33,62-65). */
+int jck_bn_fwd(int prec, const void* y, const float* stats, int slots_per_group, float count, const float* gamma, const float* beta,
+               float eps, float slope, void* a, float* aux, float* stat_out, float* running_mean, float* running_var, int64_t* nbt,
+               float momentum, long long rows_per_group, int C, int groups, void* stream);
 int jck_bn_act_fwd_grouped(int prec, const void* y, const float* aux, float slope, void* a, long long rows_per_group, int C,
                            int groups, void* stream);
 int jck_bn_act_bwd_grouped(int prec, const void* g_a, const void* y, const float* aux, float slope, float* sums, void* g_y,

@@ -513,12 +513,19 @@ static int d_convs_forward(jck_engine* e, DSet& D, const void* x_in, int B, int 
     const int hb = TT.D_HB[i], cs = TT.D_CS[i];
     const long long rows = (long long)B * (hb / 2) * (hb / 2);
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], D.y[i], D.bn[i].stats, &D.bn[i].slots, B, hb, hb, TT.D_CB[i], cs, B, st));
+    const bool cb = to_cbuf && i == TT.NS - 1;
+    bool fused = false;                           // finalize + apply as one launch where the statistics rows are few (ops.hip)
+    JCK_TRY(bn_fwd_fused(e->prec, D.y[i], D.bn[i].stats, D.bn[i].slots, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), BN_EPS,
+                         LRELU, cb ? e->cbuf : D.a[i], D.bn[i].aux, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs, nullptr, nullptr, nullptr,
+                         BN_MOM, rows, cs, 1, cb ? TT.FEAT : 0, cb ? L1_KPAD : 0, st, &fused));
+    if (!fused) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cs / 4), dim3(256), 0, st, D.bn[i].stats, D.bn[i].slots, (float)rows,
                        e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]), (float*)nullptr, (float*)nullptr,
                        (long long*)nullptr, BN_MOM, BN_EPS, D.bn[i].aux, cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass) * 2 * cs);
     HIPCHK(hipGetLastError());
-    if (to_cbuf && i == TT.NS - 1) JCK_TRY(bn_act_fwd_pitched(e->prec, D.y[i], D.bn[i].aux, LRELU, e->cbuf, rows, cs, 1, TT.FEAT, L1_KPAD, st));
+    if (cb) JCK_TRY(bn_act_fwd_pitched(e->prec, D.y[i], D.bn[i].aux, LRELU, e->cbuf, rows, cs, 1, TT.FEAT, L1_KPAD, st));
     else JCK_TRY(jck_bn_act_fwd(e->prec, D.y[i], D.bn[i].aux, LRELU, D.a[i], rows, cs, st));
+    }
     in = D.a[i];
   }
   return JCK_OK;
@@ -713,14 +720,22 @@ static int d_batched_forward(jck_engine* e, const void* x_in, int B, int g0, int
     int slots = 0;
     JCK_TRY(jck_conv_down_grouped(e->prec, in, e->d_down[i], at(S.y[i], (size_t)g0 * rows * cs), stats, &slots, n * B, hb, hb, TT.D_CB[i], cs, B, st));
     if (slots % n) JCK_FAIL(JCK_E_ARG, "batched D pass: statistic slots do not split by group");
+    const bool cb = to_cbuf && i == TT.NS - 1;      // CGAN: rows [g0 * B, (g0 + n) * B) of the head's concat buffer
+    bool fused = false;
+    JCK_TRY(bn_fwd_fused(e->prec, at(S.y[i], (size_t)g0 * rows * cs), stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
+                         BN_EPS, LRELU, cb ? at(e->cbuf, (size_t)g0 * B * L1_KPAD) : at(S.a[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs,
+                         e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, nullptr, nullptr, nullptr, BN_MOM, rows, cs, n, cb ? TT.FEAT : 0,
+                         cb ? L1_KPAD : 0, st, &fused));
+    if (!fused) {
     JCK_TRY(jck_bn_finalize_grouped(stats, slots / n, (float)rows, e->P(e->LD, e->dp, NWN[i]), e->P(e->LD, e->dp, NBN[i]),
                                     BN_EPS, S.aux[i] + (size_t)g0 * 4 * cs, e->d_rs[i] + ((size_t)e->parity * 4 + pass0 + g0) * 2 * cs, cs, n, st));
-    if (to_cbuf && i == TT.NS - 1)      // CGAN: rows [g0 * B, (g0 + n) * B) of the head's concat buffer
+    if (cb)
       JCK_TRY(bn_act_fwd_pitched(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
                                  at(e->cbuf, (size_t)g0 * B * L1_KPAD), rows, cs, n, TT.FEAT, L1_KPAD, st));
     else
       JCK_TRY(jck_bn_act_fwd_grouped(e->prec, at(S.y[i], (size_t)g0 * rows * cs), S.aux[i] + (size_t)g0 * 4 * cs, LRELU,
                                      at(S.a[i], (size_t)g0 * rows * cs), rows, cs, n, st));
+    }
     in = at(S.a[i], (size_t)g0 * rows * cs);
   }
   return JCK_OK;
@@ -956,10 +971,16 @@ static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B
   for (int i = 0; i < TT.NS; ++i) {
     const int h = 4 << i, C = TT.G_C1 >> i;
     const long long rows = (long long)B * h * h;
+    bool fused = false;
+    JCK_TRY(bn_fwd_fused(e->prec, e->g_y[i], e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]), BN_EPS,
+                         0.f, e->g_a[i], e->g_bn[i].aux, nullptr, e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset,
+                         (int64_t*)(e->gnbt + i), BN_MOM, rows, C, 1, 0, 0, st, &fused));
+    if (!fused) {
     JCK_TRY(jck_bn_finalize(e->g_bn[i].stats, e->g_bn[i].slots, (float)rows, e->P(e->LG, e->gp, NWN[i]), e->P(e->LG, e->gp, NBN[i]),
                             e->gbn + find(e->LG, RMN[i])->offset, e->gbn + find(e->LG, RVN[i])->offset,
                             e->gnbt + i, BN_MOM, BN_EPS, e->g_bn[i].aux, C, st));
     JCK_TRY(jck_bn_act_fwd(e->prec, e->g_y[i], e->g_bn[i].aux, 0.f, e->g_a[i], rows, C, st));
+    }
     if (i < TT.NS - 1)
       JCK_TRY(jck_conv_up_grouped(e->prec, e->g_a[i], e->g_up[i], e->g_y[i + 1], e->g_bn[i + 1].stats, &e->g_bn[i + 1].slots, B, h, h, TT.G_CS[i], TT.G_CB[i], B, st));
     else                                             // last ConvTranspose + tanh -> the image

@@ -345,6 +345,109 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
   }
 }
 
+// BatchNorm finalize + apply as ONE launch with no hand-over between workgroups (round 5): a workgroup owns a 64-channel SLICE of a
+// pixel range (128 contiguous bytes per row in bf16), sums the statistics rows of ITS 64 channels itself - rows of 2 x 64 floats,
+// double accumulation in an order fixed by the geometry - forms scale / shift in LDS and streams its pixels.  What bn_finalize did for
+// everybody in a launch of its own (4.2 us of the step each, measured by skipping them: DESIGN.md section 7.2) every workgroup does
+// for itself in ~2 us that overlap its first loads; it pays while the rows are few (the gather-GEMMs write one per workgroup).  The
+// workgroups with blockIdx.x == 0 also write the aux table the backward reads, the deferred running-statistics record / the
+// running statistics themselves.  aux, stats, stat_out: as bn_finalize_kernel; a: as bn_act_fwd_kernel (pitched output included).
+#define BNF_THREADS 256
+template <typename T>
+__global__ __launch_bounds__(BNF_THREADS) void bn_fwd_fused_kernel(const T* __restrict__ y, const float* __restrict__ stats, int slots, float count,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float slope,
+                                                                   T* __restrict__ a, float* __restrict__ aux, float* __restrict__ stat_out,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   long long* __restrict__ nbt, float momentum, long long rows, int C,
+                                                                   int log_row, long long pitch) {
+  __shared__ double part[8][128];
+  __shared__ float tab[2][64];
+  __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
+  const int t = threadIdx.x, s = blockIdx.y, grp = blockIdx.z;
+  stats += (long long)grp * slots * 2 * C;
+  aux += (long long)grp * 4 * C;
+  if (stat_out) stat_out += (long long)grp * 2 * C;
+  const long long g0 = (long long)grp * rows * C;              // first element of this group
+  // the first rows of this thread are requested BEFORE the table is formed: their latency hides under the row sums
+  constexpr int BU = 4;
+  const int u8 = t & 7;
+  const long long rstep = (long long)gridDim.x * 32, rfirst = (long long)blockIdx.x * 32 + (t >> 3);
+  Raw8<T> raw[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u)
+    if (rfirst + u * rstep < rows) ldraw(y + g0 + (rfirst + u * rstep) * C + s * 64 + u8 * 8, raw[u]);
+  // ---- the slice's sums: thread = (row lane 0..7, stat, 4 channels)
+  {
+    const int q4 = t & 31, rl = t >> 5;
+    const float* col = stats + (q4 >> 4) * C + s * 64 + (q4 & 15) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r0 = rl; r0 < slots; r0 += 64) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r0 + u * 8 < slots) v[u] = *reinterpret_cast<const f32x4*>(col + (long long)(r0 + u * 8) * 2 * C);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + u * 8 >= slots) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += (double)v[u][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[rl][q4 * 4 + i] = acc[i];
+  }
+  __syncthreads();
+  if (t < 64) {
+    double sd = 0.0, qd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sd += part[k][t]; qd += part[k][64 + t]; }
+    const int c = s * 64 + t;
+    const double meand = sd / (double)count;
+    double vard = qd / (double)count - meand * meand;
+    if (vard < 0.0) vard = 0.0;
+    const float mean = (float)meand, var = (float)vard;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    tab[0][t] = sc; tab[1][t] = sh;
+    if (blockIdx.x == 0) {
+      aux[c] = sc; aux[C + c] = sh; aux[2 * C + c] = mean; aux[3 * C + c] = invstd;
+      const float unbiased = var * (count / fmaxf(count - 1.f, 1.f));
+      if (stat_out) { stat_out[c] = mean; stat_out[C + c] = unbiased; }
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+      if (nbt && s == 0 && grp == 0 && t == 0) *nbt += 1;
+    }
+  }
+  __syncthreads();
+  // ---- stream: 8 threads per row slice (8 channels = 16 / 32 bytes each), 32 rows per pass
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = tab[0][u8 * 8 + k]; sh[k] = tab[1][u8 * 8 + k]; }
+  // four rows of this thread in flight (few workgroups - each paid for its own table - so the bytes in flight come from the unroll)
+  for (long long r0 = rfirst; r0 < rows; r0 += rstep * BU) {
+    if (r0 != rfirst) {
+#pragma unroll
+      for (int u = 0; u < BU; ++u)
+        if (r0 + u * rstep < rows) ldraw(y + g0 + (r0 + u * rstep) * C + s * 64 + u8 * 8, raw[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      if (r0 + u * rstep >= rows) break;
+      const long long e = g0 + (r0 + u * rstep) * C + s * 64 + u8 * 8;
+      float v[8];
+      unraw(raw[u], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = v[k] * sc[k] + sh[k];
+        v[k] = z > 0.f ? z : slope * z;
+      }
+      st8(a + (pitch ? (e >> log_row) * pitch + (e & ((1ll << log_row) - 1)) : e), v);
+    }
+  }
+}
+
 // stage 1: partial[blk][0..C) = sum g_z,  partial[blk][C..2C) = sum g_z * xhat over this workgroup's rows,
 // g_z = g_a * act'(z).  Register accumulation per (row-lane, 8-channel unit), one LDS pass over the row-lanes; no atomics:
 // the summation order per (thread, channel) is fixed by the launch geometry alone, so the result is bitwise reproducible.

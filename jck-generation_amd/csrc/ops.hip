@@ -40,6 +40,8 @@ static int g_wgrad_prio = env_int("JCK_WGRAD_PRIO", 0);
 static int g_stat_accum = env_int("JCK_STAT_ACCUM", 1);         // forward statistics accumulated per workgroup (persistent kernels, *_grouped calls)
 static int g_bn_unr = env_int("JCK_BN_UNR", 2);
 static int g_bn_res_mb = env_int("JCK_BN_RES_MB", 120);         // multi-group passes: resident form above this many MB of (g_a, y)
+static int g_bn_fuse = env_int("JCK_BN_FUSE", 1);               // forward BatchNorm finalize + apply as one launch (bn_fwd_fused_kernel) ...
+static int g_bn_fuse_rows = env_int("JCK_BN_FUSE_ROWS", 320);   // ... while a group has at most this many statistics rows
 static int g_bn_res_small_mb = env_int("JCK_BN_RES_SMALL_MB", 0);   // multi-group passes: resident form also at or below this many MB (launch-latency-bound layers)
 static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
@@ -51,7 +53,7 @@ static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_res_small_mb", &g_bn_res_small_mb},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}};
@@ -721,6 +723,42 @@ extern "C" int jck_bn_act_fwd(int prec, const void* y, const float* aux, float s
                                       (const T*)y, aux, slope, (T*)a, total8, C));
   HIPCHK(hipGetLastError());
   return JCK_OK;
+}
+
+// finalize + apply in one launch (ew.hpp: bn_fwd_fused_kernel).  Taken while the statistics rows are few (every workgroup sums the rows of
+// its channel slice itself); *fused = false and nothing launched otherwise - the caller then issues jck_bn_finalize* + jck_bn_act_fwd*.
+int bn_fwd_fused(int prec, const void* y, const float* stats, int slots_per_group, float count, const float* gamma, const float* beta,
+                 float eps, float slope, void* a, float* aux, float* stat_out, float* running_mean, float* running_var, int64_t* nbt,
+                 float momentum, long long rows_per_group, int C, int groups, long long out_row, long long out_pitch, hipStream_t stream,
+                 bool* fused) {
+  *fused = g_bn_fuse && C >= 64 && C % 64 == 0 && is_pow2(C) && slots_per_group >= 1 && slots_per_group <= g_bn_fuse_rows && groups >= 1 &&
+           (!out_pitch || (out_row >= 8 && !(out_row & (out_row - 1)) && out_pitch >= out_row && out_pitch % 8 == 0));
+  if (!*fused) return JCK_OK;
+  // ~512 workgroups: each re-reads slots x 512 bytes of rows (L2-resident), so more of them cost more than they hide
+  const int nsl = C / 64;
+  const long long per = std::max<long long>(1, 512 / ((long long)nsl * groups));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((rows_per_group + 31) / 32, per));
+  ProfScope prof(PROF_BN_ACT_FWD, 0.0, stream, 2.0 * groups * rows_per_group * C * (prec == JCK_PREC_F32 ? 4 : 2));
+  DISPATCH_T(prec, hipLaunchKernelGGL(bn_fwd_fused_kernel<T>, dim3(gx, nsl, groups), dim3(BNF_THREADS), 0, stream, (const T*)y, stats,
+                                      slots_per_group, count, gamma, beta, eps, slope, (T*)a, aux, stat_out, running_mean, running_var,
+                                      (long long*)nbt, momentum, rows_per_group, C, out_pitch ? ilog2((int)out_row) : 0, out_pitch));
+  HIPCHK(hipGetLastError());
+  return JCK_OK;
+}
+// C-ABI form: falls back to the two launches itself where the fused form does not apply
+extern "C" int jck_bn_fwd(int prec, const void* y, const float* stats, int slots_per_group, float count, const float* gamma, const float* beta,
+                          float eps, float slope, void* a, float* aux, float* stat_out, float* running_mean, float* running_var, int64_t* nbt,
+                          float momentum, long long rows_per_group, int C, int groups, void* stream) {
+  if ((running_mean || nbt) && groups != 1) JCK_FAIL(JCK_E_ARG, "bn_fwd: running statistics are updated in place for ONE group only");
+  bool fused = false;
+  JCK_TRY(bn_fwd_fused(prec, y, stats, slots_per_group, count, gamma, beta, eps, slope, a, aux, stat_out, running_mean, running_var, nbt, momentum,
+                       rows_per_group, C, groups, 0, 0, (hipStream_t)stream, &fused));
+  if (fused) return JCK_OK;
+  if (slots_per_group < 1 || groups < 1 || C % 4) JCK_FAIL(JCK_E_ARG, "bn_fwd: slots and groups must be >= 1, C % 4 == 0");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 4, groups), dim3(256), 0, (hipStream_t)stream, stats, slots_per_group, count, gamma, beta,
+                     running_mean, running_var, (long long*)nbt, momentum, eps, aux, C, stat_out);
+  HIPCHK(hipGetLastError());
+  return bn_act_fwd_pitched(prec, y, aux, slope, a, rows_per_group, C, groups, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" size_t jck_bn_bwd_ws_floats(int C) { return (size_t)(2 + 2 * BN_BWD_MAX_BLOCKS) * C; }

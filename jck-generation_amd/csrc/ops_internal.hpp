@@ -44,6 +44,11 @@ int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, doubl
                 const unsigned* skip_if = nullptr);      // skip_if: device word; non-zero = leave p, m, v untouched (a grid barrier of the step timed out)
 const unsigned* jck_grid_sync_error_word(const void* sync_ws);
 bool jck_prof_is_on();
+// BatchNorm finalize + apply as one launch where the statistics rows are few (ops.hip); *fused = false: nothing was launched
+int bn_fwd_fused(int prec, const void* y, const float* stats, int slots_per_group, float count, const float* gamma, const float* beta,
+                 float eps, float slope, void* a, float* aux, float* stat_out, float* running_mean, float* running_var, int64_t* nbt,
+                 float momentum, long long rows_per_group, int C, int groups, long long out_row, long long out_pitch, hipStream_t stream,
+                 bool* fused);
 // Internal forms of the two launches whose result another stream waits for: `done` (may be null) is completed by the launch
 // that writes the result - the dispatch packet's own completion signal (hipExtLaunchKernel's stop event) instead of a
 // hipEventRecord behind it, whose marker packet costs the launch stream ~6-7 us of idle time on this runtime.  The event is an

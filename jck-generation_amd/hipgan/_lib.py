@@ -42,6 +42,7 @@ PROTOS = {
     "jck_bn_act_bwd": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, vp]),
     "jck_bn_finalize_grouped": (i32, [vp, i32, f32, vp, vp, f32, vp, vp, i32, i32, vp]),
     "jck_bn_act_fwd_grouped": (i32, [i32, vp, vp, f32, vp, i64, i32, i32, vp]),
+    "jck_bn_fwd": (i32, [i32, vp, vp, i32, f32, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, f32, i64, i32, i32, vp]),
     "jck_conv_down_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jck_conv_up_grouped": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "jck_bn_act_bwd_grouped": (i32, [i32, vp, vp, vp, f32, vp, vp, vp, vp, i64, i32, i32, i32, vp]),

@@ -187,6 +187,50 @@ def test_bn_act(G, prec, cfg):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [(1, 700, 64, 0.2, 3), (3, 4096 + 5, 128, 0.0, 37), (2, 1024, 512, 0.2, 256), (1, 64, 256, 0.2, 1),
+                                 (2, 300, 128, 0.2, 400)])          # the last: more rows than the fused form takes - the two launches
+def test_bn_fwd_one_launch(G, prec, cfg):
+    """jck_bn_fwd (finalize + apply as one launch: every workgroup sums the statistics rows of its 64-channel slice itself) against
+    aten::native_batch_norm + the activation (F.batch_norm in training mode on the CPU) group by group, and against the two launches
+    it replaces (jck_bn_finalize_grouped + jck_bn_act_fwd_grouped): aux table, deferred running-statistics record, output."""
+    groups, rows, c, slope, slots = cfg
+    g = torch.Generator().manual_seed(11)
+    y = G.rnd(torch.randn(groups, rows, c, generator=g) * 1.5 + 0.3, prec)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    yd = y.to(G.DT[prec]).cuda().contiguous()
+    # statistics rows: the group's rows dealt over `slots` partial sums (some empty), as a producer would leave them
+    stats = torch.zeros(groups, slots, 2, c, device="cuda")
+    owner = torch.randint(0, slots, (rows,), generator=g).cuda()
+    for k in range(groups):
+        yf = yd[k].float()
+        stats[k, :, 0].index_add_(0, owner, yf)
+        stats[k, :, 1].index_add_(0, owner, yf * yf)
+    gam, bet = gamma.cuda(), beta.cuda()
+    a1, aux1, rec1 = torch.empty_like(yd), torch.empty(groups, 4 * c, device="cuda"), torch.empty(groups, 2 * c, device="cuda")
+    G.lib.jck_bn_fwd(prec, yd, stats, slots, float(rows), gam, bet, 1e-5, slope, a1, aux1, rec1, None, None, None, 0.1, rows, c, groups, G.cur_stream())
+    a2, aux2, rec2 = torch.empty_like(yd), torch.empty(groups, 4 * c, device="cuda"), torch.empty(groups, 2 * c, device="cuda")
+    G.lib.jck_bn_finalize_grouped(stats, slots, float(rows), gam, bet, 1e-5, aux2, rec2, c, groups, G.cur_stream())
+    G.lib.jck_bn_act_fwd_grouped(prec, yd, aux2, slope, a2, rows, c, groups, G.cur_stream())
+    torch.cuda.synchronize()
+    G.check(aux1.cpu(), aux2.cpu(), 2e-6, "aux vs the finalize launch")
+    G.check(rec1.cpu(), rec2.cpu(), 2e-6, "record vs the finalize launch")
+    G.check(a1.float().cpu(), a2.float().cpu(), 1e-6 if prec == 1 else 8e-3, "output vs the two launches")       # <= one bf16 ulp of the largest value
+    for k in range(groups):
+        yk = y[k].t().contiguous().unsqueeze(0)                          # [1, C, rows]
+        ref = F.batch_norm(yk, None, None, gamma, beta, True, 0.1, 1e-5)
+        ref = (F.leaky_relu(ref, slope) if slope else F.relu(ref))[0].t()
+        G.check(a1[k].float().cpu(), ref, 1e-5 if prec == 1 else 1.5e-2, f"group {k} vs F.batch_norm")
+    if groups == 1:                                                      # the in-place running statistics of the one-group form (G's layers)
+        rm, rv, nbt = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+        G.lib.jck_bn_fwd(prec, yd, stats, slots, float(rows), gam, bet, 1e-5, slope, a1, aux1, None, rm, rv, nbt, 0.1, rows, c, 1, G.cur_stream())
+        rmr, rvr = torch.zeros(c), torch.ones(c)
+        F.batch_norm(y[0].t().contiguous().unsqueeze(0), rmr, rvr, gamma, beta, True, 0.1, 1e-5)
+        G.check(rm.cpu(), rmr, 1e-5, "running_mean")
+        G.check(rv.cpu(), rvr, 1e-5, "running_var")
+        assert int(nbt) == 1
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_head(G, prec):
     b, c = 16, 512
     g = torch.Generator().manual_seed(6)
