@@ -169,3 +169,33 @@ def test_cgan_bf16_emulation_differentiates_twice_and_stays_near_the_fp32_oracle
         assert be.rel(e[k], r[k]) < 5e-2, (k, e[k], r[k])
     dist = [be.rel_l2(eg[k], t) for rg, eg in ((ref.d_grads, emu.d_grads), (ref.g_grads, emu.g_grads)) for k, t in rg.items()]
     assert max(dist) < 0.3 and max(dist) > 1e-3, dist
+
+
+def test_bench_parent_starts_ranks_without_touching_torch(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns the ranks itself, never imports torch (a process that has
+    initialised the GPU must not start others on this pool) and returns the children's status - here, without a GPU, every rank
+    refuses to run (no CPU fallback on the product path), so the launch as a whole must fail and say which ranks did."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_bench_multirank_gpu.py covers the launch")
+    # sitecustomize in a scratch directory makes `import torch` fatal in the PARENT only (children get a clean PYTHONPATH back)
+    (tmp_path / "sitecustomize.py").write_text(
+        "import os, sys\n"
+        "if 'WORLD_SIZE' not in os.environ:\n"
+        "    class _NoTorch:\n"
+        "        def find_spec(self, name, path=None, target=None):\n"
+        "            if name == 'torch':\n"
+        "                raise ImportError('the self-launching parent must not import torch')\n"
+        "            return None\n"
+        "    sys.meta_path.insert(0, _NoTorch())\n")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and "must not import torch" not in r.stderr, r.stderr[-1500:]
