@@ -59,8 +59,8 @@ def step_flops_per_image(dead_wgrad=False):
 # profiler variant label (csrc/ops.hip PROF_NAMES) -> substring of the kernel symbol rocprofv3 reports
 _SYMBOL = {"igemm<bf16,128,256>": "_kernel<128, 256,", "igemm<bf16,128,128>": "igemm_dma_kernel<128, 128,",
            "igemm<bf16,128,64>": "_kernel<128, 64,", "igemm<bf16,64,128>": "_kernel<64, 128,",      # igemm_dma_kernel / igemm_dma_persist_kernel
-           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1>",
-           "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2>",
+           "wgrad<bf16,128,128>": "wgrad_dma_kernel<3, 4, false, true, 1,",
+           "wgrad<bf16,256,128>": "wgrad_dma_kernel<3, 4, false, true, 2,",
            "wgrad<bf16,64,64,img>": "wgrad_kernel<PrecBf16, 64, 64, 2>", "img_down<bf16>": "img_down_kernel", "img_up<bf16>": "img_up_kernel",
            "bn_act_fwd": "bn_act_fwd_kernel<", "bn_bwd_resident": "bn_bwd_res_kernel<"}
 

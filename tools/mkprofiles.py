@@ -91,7 +91,7 @@ def main():
         return sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in keys)) / nsteps / 1e6
     md.insert(3, f"By class (ms/step): gather-GEMMs {part(('igemm',)):.3f}, weight gradients {part(('wgrad',)):.3f} (second stream), "
                  f"BatchNorm backward {part(('bn_bwd',)):.3f} (resident form {part(('bn_bwd_res',)):.3f}), BatchNorm forward "
-                 f"{part(('bn_act_fwd', 'bn_finalize')):.3f}, image-side convs {part(('img_down', 'img_up')):.3f}; "
+                 f"{part(('bn_act_fwd', 'bn_finalize', 'bn_fwd_fused')):.3f}, image-side convs {part(('img_down', 'img_up')):.3f}; "
                  f"{sum(int(r['Calls']) for r in rows) / nsteps:.0f} launches/step.")
     md.insert(4, "")
     for r in rows[:40]:
