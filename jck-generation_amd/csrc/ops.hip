@@ -51,12 +51,13 @@ static int g_wgrad_small_wgs = env_int("JCK_WGRAD_SMALL_WGS", 512);
 static int g_wgrad_stamp = env_int("JCK_WGRAD_STAMP", 0);
 static int g_wgrad_ws = env_int("JCK_WGRAD_WS", 1);
 static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
+static int g_wgrad_dbg = 0;             // JCK_DIAG builds only: timing-experiment variant of the weight-gradient kernel (wgrad.hpp WDBG)
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
   struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
-                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}};
+                                              {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}, {"wgrad_dbg", &g_wgrad_dbg}};
   for (auto& t : tab)
     if (key && !strcmp(t.k, key)) { *t.p = value; return JCK_OK; }
   JCK_FAIL(JCK_E_ARG, std::string("jck_tune: unknown key ") + (key ? key : "(null)"));
@@ -535,15 +536,15 @@ static int launch_wgrad_t(const WgradParams& p, const WgradPlan& pl, hipStream_t
 // LDS-DMA weight gradient: wave-specialised (4 loader + 4 consumer waves, 3 stages = 96 KB) by default; JCK_WGRAD_WS=0 selects
 // the 4-wave, 2-stage form (48.4 vs 33.7 us at B=256 on the isolated product; 3-4 stages or 8 symmetric waves: within 7 %).
 // JCK_WGRAD_STAMP=1 (development) launches the instrumented twin read back by jck_debug_wgrad_stamps.
-template <int NSTG, bool STAMP, bool WS, int GT = 1, bool PIPE = false>
+template <int NSTG, bool STAMP, bool WS, int GT = 1, bool PIPE = false, int WDBG = 0>
 static int launch_wgrad_dma_t(const WgradParams& q, int grid, hipStream_t st) {
   constexpr int LDSB = NSTG * (GT + 1) * WGD_BKP * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT, PIPE, WDBG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT, PIPE>), dim3(grid), dim3(WS ? (4 + 4 * GT) * 64 : 256), LDSB, st, q);
+  hipLaunchKernelGGL((wgrad_dma_kernel<NSTG, 4, STAMP, WS, GT, PIPE, WDBG>), dim3(grid), dim3(WS ? (4 + 4 * GT) * 64 : 256), LDSB, st, q);
   HIPCHK(hipGetLastError());
   return JCK_OK;
 }
@@ -555,6 +556,12 @@ static int launch_wgrad_dma(const WgradParams& p, const WgradPlan& pl, hipStream
   const int grid = pl.gx * pl.gy * pl.Z;
   const int stamp = g_wgrad_stamp, wsp = g_wgrad_ws;
   if (pl.BG == 256) return launch_wgrad_dma_t<3, false, true, 2>(q, grid, st);
+#ifdef JCK_DIAG
+  if (g_wgrad_dbg == 1) return launch_wgrad_dma_t<3, false, true, 1, true, 1>(q, grid, st);
+  if (g_wgrad_dbg == 2) return launch_wgrad_dma_t<3, false, true, 1, true, 2>(q, grid, st);
+  if (g_wgrad_dbg == 3) return launch_wgrad_dma_t<3, false, true, 1, true, 3>(q, grid, st);
+  if (g_wgrad_dbg == 4) return launch_wgrad_dma_t<3, false, true, 1, true, 4>(q, grid, st);
+#endif
   if (wsp && !stamp && g_wgrad_pipe) return launch_wgrad_dma_t<3, false, true, 1, true>(q, grid, st);
   if (wsp) return stamp ? launch_wgrad_dma_t<3, true, true>(q, grid, st) : launch_wgrad_dma_t<3, false, true>(q, grid, st);
   return stamp ? launch_wgrad_dma_t<2, true, false>(q, grid, st) : launch_wgrad_dma_t<2, false, false>(q, grid, st);

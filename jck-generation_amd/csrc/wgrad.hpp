@@ -311,7 +311,7 @@ static __device__ unsigned long long g_wgd_stamps[1024 * 8 * 4];
 // 8 consumer waves (4 per gathered tile) + 4 loader waves = 768 threads, three 48 KB stages.  The S tile is filled once for
 // twice the columns, 87 instead of 64 FLOP per filled byte - the kernels are bound by the LDS fill rate (~24 B/clk/CU), so
 // bytes per FLOP is what sets their speed.
-template <int NSTG, int NW, bool STAMP = false, bool WS = false, int GT = 1, bool PIPE = false>
+template <int NSTG, int NW, bool STAMP = false, bool WS = false, int GT = 1, bool PIPE = false, int WDBG = 0>
 static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad_dma_kernel(const WgradParams p) {
   static_assert(!PIPE || (WS && !STAMP), "the software-pipelined consumer exists in the wave-specialised form");
   static_assert(!WS || (NW == 4 && NSTG == 3), "wave specialisation: 4 loader + 4*GT consumer waves, 3 LDS stages");
@@ -396,7 +396,9 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
   // zeros - no zero page): the issue of a piece costs less than with a 64-bit address pair per lane (round 3: +4-14 %)
   const auto rs_big = make_rsrc(p.big, p.big_bytes);
   const auto rs_s = make_rsrc(p.sside, p.s_bytes);
+  // WDBG (JCK_DIAG builds, timing experiments with wrong results): 1 no loads, 2 no MFMAs, 3 no slab stores, 4 no transposed reads
   auto issue = [&](int stage) {
+    if constexpr (WDBG == 1) return;
     unsigned char* gt = lds + stage * STG_BYTES;
     unsigned char* st = gt + GT * TILE_BYTES;
 #pragma unroll
@@ -470,7 +472,8 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
       for (int k = 0; k < nk; ++k) {
         if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
         // stage k has landed (this wave's pieces): (GT + 1) * NQ = 8 or 12 younger pieces may stay in flight
-        if constexpr (GT == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (WDBG == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (GT == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                 // consumers may read stage k; stage k-1 is free
         if constexpr (STAMP) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tw += t1 - t0; t0 = t1; }
@@ -490,6 +493,13 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
         const unsigned char* gt = gt0 + slot * STG_BYTES;
         const unsigned char* st = st0 + slot * STG_BYTES;
         const int row = kk * 32 + (lane >> 4) * 8 + (il >> 2);
+        if constexpr (WDBG == 4) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(b[j]));
+#pragma unroll
+          for (int i = 0; i < FM; ++i) asm volatile("" : "=v"(a[i]));
+          return;
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int c0 = ws * SW + j * 16;
@@ -505,7 +515,7 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+          for (int j = 0; j < FN; ++j) { if constexpr (WDBG == 2) asm volatile("" :: "v"(a[i]), "v"(b[j])); else acc[i][j] = mfma16(a[i], b[j], acc[i][j]); }
       };
       auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -600,6 +610,7 @@ static __global__ __launch_bounds__(WS ? (4 + 4 * GT) * 64 : NW * 64) void wgrad
     for (int i = 0; i < FM; ++i) {
       const int col = g0 + wg * 64 + i * 16 + (lane >> 4) * 4;
       if (col >= p.ncols) continue;
+      if constexpr (WDBG == 3) asm volatile("" :: "v"(acc[i][j])); else
       *reinterpret_cast<f32x4*>(part + (long long)cs * p.ncols + col) = acc[i][j];
     }
   }
