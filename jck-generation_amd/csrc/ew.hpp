@@ -381,13 +381,14 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_fwd_fused_kernel(const T* __re
     const int q4 = t & 31, rl = t >> 5;
     const float* col = stats + (q4 >> 4) * C + s * 64 + (q4 & 15) * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r0 = rl; r0 < slots; r0 += 64) {
-      f32x4 v[8];
+    constexpr int RU = 16;                                       // rows of this thread in flight (256 rows: two round trips)
+    for (int r0 = rl; r0 < slots; r0 += 8 * RU) {
+      f32x4 v[RU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < RU; ++u)
         if (r0 + u * 8 < slots) v[u] = *reinterpret_cast<const f32x4*>(col + (long long)(r0 + u * 8) * 2 * C);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < RU; ++u) {
         if (r0 + u * 8 >= slots) break;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] += (double)v[u][i];
