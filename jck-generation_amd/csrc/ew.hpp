@@ -597,6 +597,125 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, const T* __restric
   }
 }
 
+// Backward sums + apply as ONE launch (round 5, the backward twin of bn_fwd_fused_kernel): the three-launch form's middle launch -
+// bn_bwd_sums_kernel, 10-13 us on the main stream's chain between two streaming kernels - is done by every workgroup for itself.
+// A workgroup owns a 64-channel slice of a pixel range of ONE group, sums the partial rows bn_bwd_reduce_kernel wrote for ITS 64
+// channels ([blk][2][C] floats: <= 256 rows of 512 bytes, L2-resident; double accumulation in an order fixed by the geometry),
+// keeps s1/n, s2/n in LDS and streams its pixels.  The workgroups with blockIdx.x == 0 write the group's sums (CGAN's v-chain
+// reads them); those of group 0 also form the parameter gradients: dgamma += sum_{g < grad_groups} s2_g, dbeta likewise, the
+// groups walked in order.  Its first rows are requested before the sums are formed.
+template <typename T>
+__global__ __launch_bounds__(BNF_THREADS) void bn_bwd_apply_fused_kernel(const T* __restrict__ ga, const T* __restrict__ y, const float* __restrict__ aux,
+                                                                         const float* __restrict__ partial, int nblk, float* __restrict__ sums,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float slope,
+                                                                         float inv_count, T* __restrict__ gy, long long rows, int C,
+                                                                         long long group_stride, int grad_groups) {
+  __shared__ double part[8][128];
+  __shared__ float tab[2][64];
+  __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
+  const int t = threadIdx.x, s = blockIdx.y, grp = blockIdx.z;
+  const long long g0 = (long long)grp * rows * C;              // first element of this group
+  constexpr int BU = 2;
+  const int u8 = t & 7;
+  const long long rstep = (long long)gridDim.x * 32, rfirst = (long long)blockIdx.x * 32 + (t >> 3);
+  Raw8<T> rg[BU], ry[BU];
+#pragma unroll
+  for (int u = 0; u < BU; ++u)
+    if (rfirst + u * rstep < rows) {
+      ldraw(ga + g0 + (rfirst + u * rstep) * C + s * 64 + u8 * 8, rg[u]);
+      ldraw(y + g0 + (rfirst + u * rstep) * C + s * 64 + u8 * 8, ry[u]);
+    }
+  // ---- the slice's sums of group g: thread = (row lane 0..7, stat, 4 channels); result of thread t < 64: (s1, s2) of channel s*64 + t
+  const int q4 = t & 31, rl = t >> 5;
+  auto slice_sums = [&](int g, double& s1, double& s2) {
+    const float* col = partial + (long long)g * group_stride + (q4 >> 4) * C + s * 64 + (q4 & 15) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int RU = 16;
+    for (int r0 = rl; r0 < nblk; r0 += 8 * RU) {
+      f32x4 v[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (r0 + u * 8 < nblk) v[u] = *reinterpret_cast<const f32x4*>(col + (long long)(r0 + u * 8) * 2 * C);
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (r0 + u * 8 >= nblk) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += (double)v[u][i];
+      }
+    }
+    __syncthreads();                                           // part[] of the previous call has been read
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[rl][q4 * 4 + i] = acc[i];
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    if (t < 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1 += part[k][t]; s2 += part[k][64 + t]; }
+    }
+  };
+  double s1d, s2d;
+  slice_sums(grp, s1d, s2d);
+  if (t < 64) {
+    const float s1 = (float)s1d, s2 = (float)s2d;
+    tab[0][t] = s1 * inv_count; tab[1][t] = s2 * inv_count;
+    if (blockIdx.x == 0) {
+      const int c = s * 64 + t;
+      sums[(long long)grp * group_stride + c] = s1;
+      sums[(long long)grp * group_stride + C + c] = s2;
+    }
+  }
+  __syncthreads();
+  // ---- stream: 8 threads per row slice, 32 rows per pass, BU rows of this thread in flight
+  float sc[8], sh[8], mu[8], is[8], m1[8], m2[8];
+  {
+    const float* ax = aux + (long long)grp * 4 * C + s * 64 + u8 * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sc[k] = ax[k]; sh[k] = ax[C + k]; mu[k] = ax[2 * C + k]; is[k] = ax[3 * C + k];
+      m1[k] = tab[0][u8 * 8 + k]; m2[k] = tab[1][u8 * 8 + k];
+    }
+  }
+  for (long long r0 = rfirst; r0 < rows; r0 += rstep * BU) {
+    if (r0 != rfirst) {
+#pragma unroll
+      for (int u = 0; u < BU; ++u)
+        if (r0 + u * rstep < rows) {
+          ldraw(ga + g0 + (r0 + u * rstep) * C + s * 64 + u8 * 8, rg[u]);
+          ldraw(y + g0 + (r0 + u * rstep) * C + s * 64 + u8 * 8, ry[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      if (r0 + u * rstep >= rows) break;
+      float vg[8], vy[8];
+      unraw(rg[u], vg);
+      unraw(ry[u], vy);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = vy[k] * sc[k] + sh[k];
+        const float gz = z > 0.f ? vg[k] : slope * vg[k];
+        const float xh = (vy[k] - mu[k]) * is[k];
+        vg[k] = sc[k] * (gz - m1[k] - xh * m2[k]);
+      }
+      st8(gy + g0 + (r0 + u * rstep) * C + s * 64 + u8 * 8, vg);
+    }
+  }
+  // ---- parameter gradients: the first workgroup of a slice in group 0 walks the gradient groups in order
+  if (blockIdx.x == 0 && grp == 0 && (dgamma || dbeta) && grad_groups > 0) {      // (uniform per workgroup)
+    float dg = (float)s2d, db = (float)s1d;
+    for (int g = 1; g < grad_groups; ++g) {
+      double a1, a2;
+      slice_sums(g, a1, a2);
+      dg += (float)a2; db += (float)a1;
+    }
+    if (t < 64) {
+      const int c = s * 64 + t;
+      if (dgamma) dgamma[c] += dg;
+      if (dbeta) dbeta[c] += db;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // D head: logit[n] = <a4[n,:], w[:]>,  p = sigmoid, BCE(p, t) with the -100 clamp, ds = dL/dlogit
 //   mode 0: loss = mean BCE;  dp = (p - t) / max(p(1-p), 1e-12) / B;  ds = dp * p(1-p)      (ATen formulas)

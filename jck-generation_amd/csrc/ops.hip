@@ -45,6 +45,8 @@ static int g_bn_res_mb = env_int("JCK_BN_RES_MB", 120);         // multi-group p
 static int g_bn_fuse = env_int("JCK_BN_FUSE", 1);               // forward BatchNorm finalize + apply as one launch (bn_fwd_fused_kernel) ...
 static int g_bn_fuse_wgs = env_int("JCK_BN_FUSE_WGS", 256);     // ... on about this many workgroups (each re-reads its slice's rows)
 static int g_bn_fuse_rows = env_int("JCK_BN_FUSE_ROWS", 320);   // ... while a group has at most this many statistics rows
+static int g_bn_bwd_fuse = env_int("JCK_BN_BWD_FUSE", 1);       // three-launch BatchNorm backward as two: the apply sums its slice's partial rows itself (bn_bwd_apply_fused_kernel) ...
+static int g_bn_bwd_fuse_wgs = env_int("JCK_BN_BWD_FUSE_WGS", 512);   // ... on about this many workgroups
 static int g_bn_res_small_mb = env_int("JCK_BN_RES_SMALL_MB", 0);   // multi-group passes: resident form also at or below this many MB (launch-latency-bound layers)
 static int g_bn_res = env_int("JCK_BN_RES", 1);                  // resident one-launch BatchNorm backward (bnres.hpp); 0: reduce + sums + apply, 2: whenever it fits                  // rows in flight per thread in bn_bwd_reduce (1, 2, 4)
 static int g_thin = env_int("JCK_THIN", 1);                  // streaming kernels for the image-side layers
@@ -57,7 +59,7 @@ static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_dbg = 0;             // JCK_DIAG builds only: timing-experiment variant of the weight-gradient kernel (wgrad.hpp WDBG)
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_128", &g_igemm_128}, {"igemm_eff", &g_igemm_eff}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_fuse_wgs", &g_bn_fuse_wgs}, {"bn_res_small_mb", &g_bn_res_small_mb},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_128", &g_igemm_128}, {"igemm_eff", &g_igemm_eff}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_fuse_wgs", &g_bn_fuse_wgs}, {"bn_bwd_fuse", &g_bn_bwd_fuse}, {"bn_bwd_fuse_wgs", &g_bn_bwd_fuse_wgs}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}, {"wgrad_dbg", &g_wgrad_dbg}};
@@ -850,6 +852,17 @@ static int bn_act_bwd_grouped_ev(int prec, const void* g_a, const void* y, const
   else { DISPATCH_T(prec, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, 1>), dim3(blocks, groups), dim3(256), 2 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)g_a, (const T*)y, aux, slope, partial, rows, C, gstride)); }
   HIPCHK(hipGetLastError());
+  if (g_bn_bwd_fuse && C >= 64 && C % 64 == 0) {
+    // two launches: every workgroup of the apply sums the partial rows of its 64-channel slice itself (ew.hpp)
+    const int nsl = C / 64;
+    const long long per = std::max<long long>(1, g_bn_bwd_fuse_wgs / ((long long)nsl * groups));
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((rows + 31) / 32, per));
+    DISPATCH_T(prec, LAUNCH_EV(bn_bwd_apply_fused_kernel<T>, dim3(gx, nsl, groups), dim3(BNF_THREADS), 0, (hipStream_t)stream, done,
+                               (const T*)g_a, (const T*)y, (const float*)aux, (const float*)partial, blocks, sums, dgamma, dbeta, slope,
+                               1.0f / (float)rows, (T*)g_y, rows, C, gstride, grad_groups));
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, sums, dgamma, dbeta, C,
                      gstride, groups, grad_groups);
   HIPCHK(hipGetLastError());
