@@ -310,6 +310,9 @@ def measure(a, model, world, rank, dev, dist):
         ddp["n1_equivalent_ms"] = round(float(tn1[0]), 4)
         ddp["rccl_world"] = dist.get_world_size() if dist else 1
         ddp["backend"] = dist.get_backend() if dist else None
+        # who runs the all-reduce: torch.distributed's ProcessGroupNCCL (default) or the library's own RCCL communicator behind the
+        # C ABI (JCK_RCCL_NATIVE=1: include/jckgan.h jck_comm_*)
+        ddp["collective"] = "jck_comm_* (RCCL behind the C ABI)" if getattr(red, "_comm", None) is not None else "torch.distributed.all_reduce"
         ddp["message_bytes"] = {"d": int(eng.arenas["d_grads"].numel()) * 4, "g": int(eng.arenas["g_grads"].numel()) * 4}
         res["ddp"] = ddp
     if not a.no_roofline:

@@ -419,6 +419,25 @@ int jck_debug_bnres_stamps(void* buf);
  * slot, first 1024 workgroups); synchronises the device */
 int jck_debug_wgrad_stamps(unsigned long long* out, int n);
 
+/* ---- RCCL gradient all-reduce {init, enqueue, wait} ------------------------------------------------------------------------
+ * The reference's multi-GPU form is DistributedDataParallel around G and D: what optimizer_d.step() / optimizer_g.step() consume
+ * (train/dcgan_trainer.py:180,189, train/cgan_trainer.py:204,212) are gradients averaged over the ranks.  A network's gradients
+ * are one flat fp32 arena here, so the exchange is one SUM all-reduce per arena (or slice); the 1/world factor goes into jck_adam's
+ * grad_scale.  The collective runs on the communicator's OWN stream: enqueue orders it behind everything `producer_stream` holds
+ * at the time of the call, wait makes `consumer_stream` wait for it on the device; the host never blocks.  Up to 8 tickets in
+ * flight.  librccl is resolved at the first call (a copy already in the process - PyTorch's - is preferred; JCK_RCCL_LIB names
+ * another), so a single-GPU process never maps it.
+ *   rank 0: jck_comm_unique_id(id); every rank receives the 128 bytes over any host channel; every rank: jck_comm_create (a
+ *   collective call, with its device current). */
+typedef struct jck_comm jck_comm;
+#define JCK_COMM_ID_BYTES 128
+int jck_comm_unique_id(unsigned char* id128);
+int jck_comm_create(jck_comm** out, const unsigned char* id128, int world, int rank);
+int jck_comm_world(const jck_comm*);
+int jck_comm_allreduce_enqueue(jck_comm*, float* buf, size_t count, void* producer_stream, int* ticket);
+int jck_comm_wait(jck_comm*, int ticket, void* consumer_stream);
+int jck_comm_destroy(jck_comm*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,12 @@ PROTOS = {
     "jck_engine_capture_abort": (i32, [vp, vp]),
     "jck_graph_launch": (i32, [vp, vp]),
     "jck_graph_destroy": (None, [vp]),
+    "jck_comm_unique_id": (i32, [vp]),
+    "jck_comm_create": (i32, [C.POINTER(vp), vp, i32, i32]),
+    "jck_comm_world": (i32, [vp]),
+    "jck_comm_allreduce_enqueue": (i32, [vp, vp, sz, vp, C.POINTER(i32)]),
+    "jck_comm_wait": (i32, [vp, i32, vp]),
+    "jck_comm_destroy": (i32, [vp]),
     "jck_prof_enable": (i32, [i32]),
     "jck_prof_collect": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), C.POINTER(vp)]),
 }
@@ -192,7 +198,7 @@ class _Lib:
                     if not a.is_contiguous():
                         raise JckError(f"{name}: non-contiguous tensor argument")
             r = fn(*[_arg(a) for a in args])
-            if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect", "jck_grid_sync_error") \
+            if fn.restype is i32 and name not in ("jck_version", "jck_pad_rows", "jck_pad_chan", "jck_engine_num_tensors", "jck_prof_collect", "jck_grid_sync_error", "jck_comm_world") \
                     and r != 0:
                 raise JckError(f"{name} failed ({r}): {dll.jck_last_error().decode()}")
             return r

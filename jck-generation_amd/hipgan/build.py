@@ -8,7 +8,7 @@ PKG = os.path.dirname(HERE)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libjckgan_hip.so")
-SOURCES = ["ops.hip", "engine.hip", "infer.hip"]
+SOURCES = ["ops.hip", "engine.hip", "infer.hip", "comm.hip"]
 
 
 def source_id():
@@ -51,7 +51,7 @@ def build(force=False, verbose=True):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

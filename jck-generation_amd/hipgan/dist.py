@@ -15,18 +15,64 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, world, group=None, force=False):
+    def __init__(self, world, group=None, force=False, native=None):
         """force: issue the collectives even for world == 1 (tests: a one-rank RCCL group runs the real ProcessGroupNCCL
-        stream path, and SUM over one rank must leave every bit unchanged)."""
+        stream path, and SUM over one rank must leave every bit unchanged).
+        native (default: the environment's JCK_RCCL_NATIVE == "1"): the collectives go through the library's own RCCL
+        communicator (include/jckgan.h jck_comm_*: {init, enqueue, wait} on a stream of its own, ordered by events) instead of
+        torch.distributed.all_reduce; torch.distributed only carries the 128-byte communicator id to the ranks.  Opt-in:
+        like every N > 1 path of this build it has run against one device only."""
+        import os
         self.world = world
         self.group = group
         self.force = force
+        self.native = (os.environ.get("JCK_RCCL_NATIVE") == "1") if native is None else bool(native)
+        self._comm = None
+        if self.native and (world > 1 or force):
+            self._comm = self._create_comm()
+
+    def _create_comm(self):
+        import ctypes as C
+        from ._lib import lib
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ident = torch.zeros(128, dtype=torch.uint8)
+        rank = dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            lib.jck_comm_unique_id(buf)
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.world > 1:
+            # the id travels over the process group that exists anyway (device tensors under "nccl", host tensors under "gloo")
+            on_dev = dist.get_backend(self.group) == "nccl"
+            t = ident.to(dev) if on_dev else ident
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            ident = t.cpu()
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        out = C.c_void_p()
+        lib.jck_comm_create(C.byref(out), raw, self.world, rank)
+        return out
+
+    def close(self):
+        if self._comm is not None:
+            from ._lib import lib
+            lib.jck_comm_destroy(self._comm)
+            self._comm = None
 
     def start(self, flat):
         """All-reduce (SUM) of a flat gradient arena (or a slice of one); returns a callable that makes the current stream wait
         for it, or None when there is nothing to exchange."""
         if self.world == 1 and not self.force:
             return None
+        if self._comm is not None:
+            import ctypes as C
+            from ._lib import lib
+            if flat.dtype != torch.float32 or not flat.is_contiguous() or not flat.is_cuda:
+                raise ValueError("native RCCL all-reduce takes a contiguous float32 device tensor")
+            ticket = C.c_int(-1)
+            lib.jck_comm_allreduce_enqueue(self._comm, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream,
+                                           C.byref(ticket))
+            comm, tk = self._comm, ticket.value
+            return lambda: lib.jck_comm_wait(comm, tk, torch.cuda.current_stream().cuda_stream)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return work.wait
 

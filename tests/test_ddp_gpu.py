@@ -168,11 +168,12 @@ B = 16
 torch.manual_seed(12345)
 g, d = build_params("dcgan")
 imgs = synth_images(B * 3)
-def run(reduce, overlap):
+def run(reduce, overlap, native=False):
     eng = DcganEngine(batch=B, prec="bf16", device="cuda:0")
     eng.ddp_overlap = overlap                # D's arena in two pieces under its own backward / one all-reduce per network
     eng.load_state(g, d)
-    red = GradReducer(1, force=True) if reduce else None
+    # native: the library's own communicator (jck_comm_*: RCCL on a stream of its own, ordered by events) instead of ProcessGroupNCCL
+    red = GradReducer(1, force=True, native=native) if reduce else None
     for s in range(3):
         nz = {k: v.cuda() for k, v in be.noise_for("dcgan", B, 70 + s).items()}
         kw = dict(reduce_d=red.start, reduce_g=red.start) if red else {}
@@ -181,11 +182,21 @@ def run(reduce, overlap):
     torch.cuda.synchronize()
     return {k: v.clone() for k, v in eng.arenas.items()}, eng.scalars()
 base, sb = run(False, True)
-for overlap in (False, True):
-    got, sg = run(True, overlap)
-    assert sg == sb, (overlap, sg, sb)
-    for k in base:
-        assert torch.equal(base[k], got[k]), (overlap, k)
+for native in (False, True):
+    for overlap in (False, True):
+        got, sg = run(True, overlap, native)
+        assert sg == sb, (native, overlap, sg, sb)
+        for k in base:
+            assert torch.equal(base[k], got[k]), (native, overlap, k)
+# the C-ABI communicator by itself: SUM over one rank leaves a buffer as it is, in stream order behind its producer
+red = GradReducer(1, force=True, native=True)
+assert red._comm is not None
+x = torch.randn(1 << 20, device="cuda")
+y = x * 2.0
+w = red.start(y)
+w()
+assert torch.equal(y, x * 2.0)
+red.close()
 dist.destroy_process_group()
 print("RCCL1-OK")
 """

@@ -231,6 +231,55 @@ def test_bn_fwd_one_launch(G, prec, cfg):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [(1, 700, 64, 0.2, 1), (3, 4096 + 5, 128, 0.0, 2), (3, 3000, 512, 0.2, 3), (2, 64, 256, 0.2, 0)])
+def test_bn_bwd_two_launches(G, prec, cfg):
+    """jck_bn_act_bwd_grouped as two launches (reduce, then an apply whose workgroups sum the partial rows of their own 64-channel
+    slice: bn_bwd_apply_fused_kernel) against the three launches it replaces (jck_tune bn_bwd_fuse 0: reduce, sums, apply) - g_y, the
+    per-group sums CGAN's double backward reads, dgamma / dbeta over the first grad_groups groups - and against
+    aten::native_batch_norm_backward + the activation's backward (autograd on the CPU), group by group."""
+    groups, rows, c, slope, gg = cfg
+    g = torch.Generator().manual_seed(23)
+    y = G.rnd(torch.randn(groups, rows, c, generator=g) * 1.5 + 0.3, prec)
+    ga = G.rnd(torch.randn(groups, rows, c, generator=g), prec)
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    yd, gad = y.to(G.DT[prec]).cuda().contiguous(), ga.to(G.DT[prec]).cuda().contiguous()
+    stats = torch.stack([torch.stack([yd[k].float().sum(0), (yd[k].float() ** 2).sum(0)]) for k in range(groups)]).contiguous()
+    aux = torch.empty(groups, 4 * c, device="cuda")
+    G.lib.jck_bn_finalize_grouped(stats, 1, float(rows), gamma.cuda(), beta.cuda(), 1e-5, aux, None, c, groups, G.cur_stream())
+    wsf = G.lib.jck_bn_bwd_ws_floats(c)
+    out = {}
+    for fuse in (1, 0):
+        G.lib.jck_tune(b"bn_bwd_fuse", fuse)
+        try:
+            sums = torch.full((groups, wsf), float("nan"), device="cuda")
+            gy = torch.empty_like(yd)
+            dgam, dbet = torch.ones(c, device="cuda"), torch.ones(c, device="cuda")
+            G.lib.jck_bn_act_bwd_grouped(prec, gad, yd, aux, slope, sums, gy, dgam if gg else None, dbet if gg else None, rows, c, groups, gg,
+                                         G.cur_stream())
+            torch.cuda.synchronize()
+            out[fuse] = (gy.float().cpu(), sums[:, :2 * c].cpu(), dgam.cpu(), dbet.cpu())
+        finally:
+            G.lib.jck_tune(b"bn_bwd_fuse", 1)
+    G.check(out[1][1], out[0][1], 2e-6, "sums vs the sums launch")
+    G.check(out[1][2], out[0][2], 2e-6, "dgamma vs the sums launch")
+    G.check(out[1][3], out[0][3], 2e-6, "dbeta vs the sums launch")
+    G.check(out[1][0], out[0][0], 1e-6 if prec == 1 else 8e-3, "g_y vs the three launches")
+    dg_ref, db_ref = torch.zeros(c), torch.zeros(c)
+    for k in range(groups):
+        yk = y[k].t().contiguous().unsqueeze(0).requires_grad_(True)                          # [1, C, rows]
+        gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        bn = F.batch_norm(yk, None, None, gm, bt, True, 0.1, 1e-5)
+        (F.leaky_relu(bn, slope) if slope else F.relu(bn)).backward(ga[k].t().contiguous().unsqueeze(0))
+        G.check(out[1][0][k], yk.grad[0].t(), 2e-5 if prec == 1 else 2e-2, f"group {k} vs autograd")
+        if k < gg:
+            dg_ref += gm.grad
+            db_ref += bt.grad
+    if gg:
+        G.check(out[1][2] - 1, dg_ref, 2e-5 if prec == 1 else 1e-2, "dgamma vs autograd")
+        G.check(out[1][3] - 1, db_ref, 2e-5 if prec == 1 else 1e-2, "dbeta vs autograd")
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_head(G, prec):
     b, c = 16, 512
     g = torch.Generator().manual_seed(6)
