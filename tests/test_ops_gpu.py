@@ -249,7 +249,7 @@ def test_bn_bwd_two_launches(G, prec, cfg):
     wsf = G.lib.jck_bn_bwd_ws_floats(c)
     out = {}
     for fuse in (1, 0):
-        G.lib.jck_tune(b"bn_bwd_fuse", fuse)
+        G.lib.jck_tune(b"bn_bwd_fuse", 2 * fuse)         # 2: also on the fp32 path (by default the fast path's form only)
         try:
             sums = torch.full((groups, wsf), float("nan"), device="cuda")
             gy = torch.empty_like(yd)
