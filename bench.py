@@ -513,6 +513,17 @@ def main():
                                        "config": {"workload": f"DCGAN 64x64x3 synthetic, batch {B}, the headline step on the parity path "
                                                               f"(fp32 storage, v_mfma_f32_16x16x4_f32: losses within 1e-3 of the CPU oracle per step)"},
                                        **s32}
+            # BASELINE.json configs[4]'s per-GPU workload (128x128 topology, batch 128; without the Inception / FID evaluation, which
+            # profiles/r03_eval.json measures): a driver-run number for the one config that is otherwise exercised by tests only
+            a128 = copy.copy(a)
+            a128.size, a128.batch, a128.steps, a128.warmup, a128.no_roofline = 128, 128, min(a.steps, 20), min(a.warmup, 5), True
+            s128 = measure(a128, "dcgan", world, rank, dev, dist)
+            s128.pop("kernels", None)
+            out["secondary"]["size128"] = {"metric": "images/sec (G+D step) DCGAN 128x128 bs128", "unit": "images/sec", "dtype": "bf16",
+                                           "steps": a128.steps, "warmup": a128.warmup,
+                                           "config": {"workload": "DCGAN 128x128x3 synthetic (one more stride-2 stage, 1024 channels at 4x4), batch 128, "
+                                                                  "full G+D step (BASELINE.json configs[4] per GPU, without the Inception/FID evaluation)"},
+                                           **s128}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:
