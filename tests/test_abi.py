@@ -44,3 +44,25 @@ def test_product_path_fails_loudly_without_gpu():
     from hipgan import JckError, lib
     with pytest.raises(JckError):
         lib.jck_adam(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 4, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None)
+
+
+def test_comm_entry_points_validate_their_arguments_on_the_host():
+    """jck_comm_* (RCCL behind the C ABI): argument errors come back as JCK_E_ARG with a message before any device or RCCL call;
+    the data-parallel binding keeps torch.distributed unless asked (no GPU, no communicator here)."""
+    import ctypes as C
+    from hipgan import _lib
+    dll = _lib.load_library()
+    out = C.c_void_p()
+    ident = (C.c_ubyte * 128)()
+    assert dll.jck_comm_create(C.byref(out), ident, 0, 0) == -1 and b"world" in dll.jck_last_error()       # JCK_E_ARG
+    assert dll.jck_comm_create(C.byref(out), ident, 2, 2) == -1
+    assert dll.jck_comm_create(None, ident, 1, 0) == -1
+    assert dll.jck_comm_unique_id(None) == -1
+    assert dll.jck_comm_wait(None, 0, None) == -1 and dll.jck_comm_wait(None, 99, None) == -1
+    tk = C.c_int(-1)
+    assert dll.jck_comm_allreduce_enqueue(None, None, 0, None, C.byref(tk)) == -1
+    assert dll.jck_comm_world(None) == 0 and dll.jck_comm_destroy(None) == 0
+    from hipgan.dist import GradReducer
+    os.environ.pop("JCK_RCCL_NATIVE", None)
+    r = GradReducer(1)
+    assert r.native is False and r._comm is None and r.start(None) is None      # one rank, nothing to exchange
