@@ -913,6 +913,12 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
   // head: gc[:, :8192] = gh W1 -> adj(gh) = [u4 | 0] W1^T, dW1 += gh^T [u4 | 0]; gh = gh' * m/(1-p); gh' = ds w2; ds = p(1-p)
   JCK_TRY(jck_concat_rows(e->prec, e->d_v[TT.NS - 1], TT.FEAT, e->cbuf2, L1_KPAD, B, st));          // tail columns of cbuf2 stay zero
   JCK_TRY(jck_linear_wgrad(e->prec, gh1, L1_OUT, e->cbuf2, L1_KPAD, e->wg_ws, e->wg_ws_bytes, e->gw1p, 1, B, L1_OUT, fork(0)));
+  // What the reverse sweep must wait for are the v-chain's products (they read the v_i it overwrites): the weight-gradient stream is
+  // marked HERE, behind the last of them - not after the head's parameter gradients, which are forked to it below and which nothing
+  // on the main stream waits for before the optimiser (JCK_GP_NARROW_JOIN=0: the join covers them too)
+  static const bool narrow_join = !(getenv("JCK_GP_NARROW_JOIN") && atoi(getenv("JCK_GP_NARROW_JOIN")) == 0);
+  const bool narrow = side && narrow_join;
+  if (narrow) (void)hipEventRecord(e->evGP, side);
   JCK_TRY(jck_linear_fwd(e->prec, e->cbuf2, e->l1_w, nullptr, e->l1_slab, B, L1_KPAD, L1_OUT, L1_OUT, L1_KSPLIT, st));
   const bool fuse = e->head_fuse && L1_OUT == 256;    // the next four launches as one (ops.hip: gp_head_mid_ev)
   if (!fuse) JCK_TRY(jck_linear_finish(e->prec, e->l1_slab, L1_KSPLIT, nullptr, drop_mask, 1.0f / 0.75f, nullptr, e->ughd, B, L1_OUT, st));
@@ -930,7 +936,7 @@ static int gp_double_backward(jck_engine* e, const GpSrc& P, const void* xhat, i
     JCK_TRY(gp_head2_ev(e->prec, e->ughd, e->P(e->LD, e->dp, "linear2.weight"), prob1, B, L1_OUT, e->rs,
                         e->P(e->LD, e->dg, "linear2.weight"), e->gp2_ws, st, hs, hs ? e->evHead : nullptr));
   // ---- reverse sweep through the forward pass from the logit adjoint rs, with the extra BatchNorm inputs
-  join();
+  if (narrow) (void)hipStreamWaitEvent(st, e->evGP, 0); else join();
   JCK_TRY(d_head_backward(e, e->dset[0], e->rs, B, true, drop_mask, e->d_v[TT.NS - 1], st, hs, fuse));
   // the last sum into the permuted Linear gradient is enqueued: back to the reference's layout, on the stream that holds it
   JCK_TRY(jck_unperm_linear_grad(e->gw1p, L1_OUT, L1_K, L1_KPAD, 512, 16, e->P(e->LD, e->dg, "linear1.weight"), 1, hs ? hs : st));
