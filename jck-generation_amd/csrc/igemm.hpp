@@ -369,7 +369,8 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
   wgid = __builtin_amdgcn_readfirstlane(wgid);                      // provably wave-uniform: tap tables come by s_load
   const int bidy = wgid % p.gy;
   const int zraw = (wgid / p.gy) % p.gz;
-  const int z = zraw;
+  const int z = p.ksplit > 1 ? 0 : zraw;                            // parity phase (tables, weights, output base)
+  const int kc0 = p.ksplit > 1 ? zraw * p.ksteps : 0;               // split-K (plain GEMMs): first k-step of this layer of workgroups
   const int bidx = wgid / (p.gy * p.gz);
   const int m0 = bidx * BPIX, ch0 = bidy * BCH;
   const int Cc = 1 << p.logC;
@@ -398,13 +399,13 @@ __global__ __launch_bounds__(WS ? (NCW + 4) * 64 : 256) void igemm_dma_kernel(co
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const int nk = p.K / IG_BK;
+  const int nkt = p.K / IG_BK, nk = p.ksplit > 1 ? p.ksteps : nkt;   // k-steps of the product / of this workgroup
   // k-steps past the end re-load the last tile into a stage nobody reads: no predicate, no branch, exact vmcnt arithmetic
   // buffer loads (descriptor + 32-bit offset per lane, zeros past the operand) - see igemm_dma_persist_kernel
   const auto rs_a = make_rsrc(p.act, p.act_bytes);
   const auto rs_wt = make_rsrc(p.w, p.w_bytes);
   auto issue = [&](int kc, int stage) {
-    const int kbase = min(kc, nk - 1) * IG_BK;
+    const int kbase = min(kc0 + kc, nkt - 1) * IG_BK;
     unsigned char* sb = lds + stage * STG_BYTES + (wave & 3) * (8 * LD * 2);     // this wave's 8 rows of each 32-row pass
 #pragma unroll
     for (int ps = 0; ps < C::WPASS; ++ps)

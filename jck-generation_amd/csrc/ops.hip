@@ -45,6 +45,7 @@ static int g_bn_res_mb = env_int("JCK_BN_RES_MB", 120);         // multi-group p
 static int g_bn_fuse = env_int("JCK_BN_FUSE", 1);               // forward BatchNorm finalize + apply as one launch (bn_fwd_fused_kernel) ...
 static int g_bn_fuse_wgs = env_int("JCK_BN_FUSE_WGS", 256);     // ... on about this many workgroups (each re-reads its slice's rows)
 static int g_bn_fuse_rows = env_int("JCK_BN_FUSE_ROWS", 320);   // ... while a group has at most this many statistics rows
+static int g_igemm_dma_ksplit = env_int("JCK_IGEMM_DMA_KSPLIT", 1);
 static int g_bn_bwd_fuse = env_int("JCK_BN_BWD_FUSE", 1);       // three-launch BatchNorm backward as two: the apply sums its slice's partial rows itself (bn_bwd_apply_fused_kernel) ...
 static int g_bn_bwd_fuse_wgs = env_int("JCK_BN_BWD_FUSE_WGS", 256);   // ... on about this many workgroups
 static int g_bn_res_small_mb = env_int("JCK_BN_RES_SMALL_MB", 0);   // multi-group passes: resident form also at or below this many MB (launch-latency-bound layers)
@@ -59,7 +60,7 @@ static int g_wgrad_dma = env_int("JCK_WGRAD_DMA", 1);
 static int g_wgrad_dbg = 0;             // JCK_DIAG builds only: timing-experiment variant of the weight-gradient kernel (wgrad.hpp WDBG)
 static int g_wgrad_pipe = env_int("JCK_WGRAD_PIPE", 1);      // software-pipelined consumer waves of the wave-specialised weight gradient
 extern "C" int jck_tune(const char* key, int value) {
-  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_128", &g_igemm_128}, {"igemm_eff", &g_igemm_eff}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_fuse_wgs", &g_bn_fuse_wgs}, {"bn_bwd_fuse", &g_bn_bwd_fuse}, {"bn_bwd_fuse_wgs", &g_bn_bwd_fuse_wgs}, {"bn_res_small_mb", &g_bn_res_small_mb},
+  struct { const char* k; int* p; } tab[] = {{"igemm_dma", &g_igemm_dma}, {"igemm_ws", &g_igemm_ws}, {"igemm_256", &g_igemm_256}, {"igemm_128", &g_igemm_128}, {"igemm_eff", &g_igemm_eff}, {"igemm_persist", &g_igemm_persist}, {"igemm_dbg", &g_igemm_dbg}, {"igemm_prio", &g_igemm_prio}, {"wgrad_prio", &g_wgrad_prio},  {"stat_accum", &g_stat_accum}, {"bn_unr", &g_bn_unr}, {"bn_res", &g_bn_res}, {"bn_res_mb", &g_bn_res_mb}, {"bn_fuse", &g_bn_fuse}, {"bn_fuse_rows", &g_bn_fuse_rows}, {"bn_fuse_wgs", &g_bn_fuse_wgs}, {"igemm_dma_ksplit", &g_igemm_dma_ksplit}, {"bn_bwd_fuse", &g_bn_bwd_fuse}, {"bn_bwd_fuse_wgs", &g_bn_bwd_fuse_wgs}, {"bn_res_small_mb", &g_bn_res_small_mb},
                                               {"thin", &g_thin}, {"wgrad_gt", &g_wgrad_gt}, {"wgrad_wgs", &g_wgrad_wgs},
                                               {"wgrad_small_wgs", &g_wgrad_small_wgs}, {"wgrad_stamp", &g_wgrad_stamp},
                                               {"wgrad_ws", &g_wgrad_ws}, {"wgrad_dma", &g_wgrad_dma}, {"wgrad_pipe", &g_wgrad_pipe}, {"wgrad_dbg", &g_wgrad_dbg}};
@@ -269,7 +270,8 @@ static int launch_igemm_p(const IgemmParams& p, int nch_pad, int phases, int nsu
   // Measured on MI355X at B=256 (tools/micro.py, us): down2 36.2 -> 29.7, down3 43.0 -> 30.3, down4 65.8 -> 40.3,
   // up2 47.2 -> 30.8, up3 34.5 -> 28.8; 3-4 stages at one workgroup per CU are slower.  JCK_IGEMM_DMA=0 disables.
   const int use_dma = g_igemm_dma;
-  if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && p.ksplit <= 1 && !p.rows_are_phases) {
+  // (split-K plain GEMMs - CGAN's Linear(8392,256) - take the non-persistent LDS-DMA kernels: round 5, JCK_IGEMM_DMA_KSPLIT=0 the register-staged one)
+  if (use_dma && !P::IS_F32 && nsub == 1 && nch_pad % 128 == 0 && (p.ksplit <= 1 || (g_igemm_dma_ksplit && p.act_row_elems)) && !p.rows_are_phases) {
     const long long wgs = (long long)cdiv(p.M, 128) * (nch_pad / 128) * phases;
     // wave-specialised variant for the launches that would run 128x64 tiles (< 512 tiles of 128x128: one or two workgroups
     // per CU); JCK_IGEMM_WS=0 disables.  128x128 WS (one workgroup per CU) and WS for the 64-channel tile measured slower.

@@ -279,6 +279,35 @@ def test_bn_bwd_two_launches(G, prec, cfg):
         G.check(out[1][3] - 1, db_ref, 2e-5 if prec == 1 else 1e-2, "dbeta vs autograd")
 
 
+@pytest.mark.parametrize("B", [16, 300, 768])
+def test_linear_fwd_split_k_on_the_lds_dma_kernel(G, B):
+    """CGAN's Linear(8392,256) forward (model/CGAN.py:104) as a split-K plain GEMM: fp32 slabs [ksplit][B][N] from the LDS-DMA
+    gather-GEMM (round 5) against the register-staged kernel it replaces there (jck_tune igemm_dma_ksplit 0) - same products in the
+    same order per accumulator: the same bits - and, summed, against torch (bf16 operands, fp32 accumulation)."""
+    prec, N, K, KP, KS = 0, 256, 8392, 8448, 12
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(B, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.02)
+    xp = torch.zeros(B, KP, dtype=torch.bfloat16)
+    xp[:, :K] = x
+    xd = xp.cuda()
+    wp = torch.empty(N * KP, dtype=torch.bfloat16, device="cuda")
+    G.lib.jck_pack_linear(prec, w.cuda(), N, K, N, KP, 0, 0, 0, wp, G.cur_stream())
+    out = {}
+    for dma in (1, 0):
+        G.lib.jck_tune(b"igemm_dma_ksplit", dma)
+        try:
+            slab = torch.full((KS, B, N), float("nan"), device="cuda")
+            G.lib.jck_linear_fwd(prec, xd, wp, None, slab, B, KP, N, N, KS, G.cur_stream())
+            torch.cuda.synchronize()
+            out[dma] = slab.cpu()
+        finally:
+            G.lib.jck_tune(b"igemm_dma_ksplit", 1)
+    assert torch.equal(out[1], out[0]), float((out[1] - out[0]).abs().max())
+    ref = x.float() @ w.to(torch.bfloat16).float().t()
+    G.check(out[1].sum(0), ref, 2e-5, "sum of the slabs vs torch")
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_head(G, prec):
     b, c = 16, 512
