@@ -1634,6 +1634,178 @@ __global__ void bn2_reverse_apply_kernel(const T* __restrict__ ua, const T* __re
     st8(uy + i * 8, o);
   }
 }
+// The second-order chains as two launches instead of three (round 5; the backward twin bn_bwd_apply_fused_kernel above): the apply
+// kernel's workgroups own a 64-channel slice of a pixel range and sum the partial rows of bn2_reduce_kernel for THEIR channels
+// themselves ([blk][NA][C] floats; double accumulation in an order fixed by the geometry) - bn2_sums_kernel, ~6 us on the main
+// stream's chain eight times per CGAN step, is gone.  The first workgroup of a slice writes the sums (ws[q*C + c], as bn2_sums_kernel
+// did: the reverse sweep reads the v-chain's) and the direct parameter gradients.
+// -> LDS tot[q][j] = sum over the nblk rows of accumulator q, channel slice*64 + j   (q < NA)
+template <int NA>
+__device__ __forceinline__ void bn2_slice_sums(const float* __restrict__ partial, int nblk, int C, int slice, double (*part)[NA * 64], float (*tot)[64]) {
+  constexpr int NCOL = NA * 16, RL = 256 / NCOL;            // float4 columns of a slice row, row lanes (5 or 4)
+  const int t = threadIdx.x, q4 = t % NCOL, rl = t / NCOL;
+  if (rl < RL) {
+    const float* col = partial + (q4 >> 4) * C + slice * 64 + (q4 & 15) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int RU = 8;
+    for (int r0 = rl; r0 < nblk; r0 += RL * RU) {
+      f32x4 v[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (r0 + u * RL < nblk) v[u] = *reinterpret_cast<const f32x4*>(col + (long long)(r0 + u * RL) * NA * C);
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        if (r0 + u * RL >= nblk) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += (double)v[u][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[rl][q4 * 4 + i] = acc[i];
+  }
+  __syncthreads();
+  if (t < NA * 64) {
+    double sd = 0.0;
+#pragma unroll
+    for (int k = 0; k < RL; ++k) sd += part[k][t];
+    tot[t >> 6][t & 63] = (float)sd;
+  }
+  __syncthreads();
+}
+
+// v-chain apply (bn2_vchain_apply_kernel's arithmetic) with the sums of ITS slice formed in the prologue
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_vchain_apply_fused_kernel(const T* __restrict__ v, const T* __restrict__ y, const T* __restrict__ gy,
+                                                                     const float* __restrict__ aux, const float* __restrict__ s1,
+                                                                     const float* __restrict__ partial, int nblk, float* __restrict__ ws,
+                                                                     const float* __restrict__ gamma, float* __restrict__ dgamma, float slope,
+                                                                     float inv_count, T* __restrict__ u, T* __restrict__ xdir, long long rows, int C) {
+  __shared__ double part[5][3 * 64];
+  __shared__ float tot[3][64];
+  __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
+  const int t = threadIdx.x, s = blockIdx.y, u8 = t & 7;
+  const long long rstep = (long long)gridDim.x * 32, rfirst = (long long)blockIdx.x * 32 + (t >> 3);
+  constexpr int BU = 2;
+  Raw8<T> rv[BU], ry[BU], rg[BU];
+#pragma unroll
+  for (int q = 0; q < BU; ++q)
+    if (rfirst + q * rstep < rows) {
+      const long long e = (rfirst + q * rstep) * C + s * 64 + u8 * 8;
+      ldraw(v + e, rv[q]); ldraw(y + e, ry[q]); ldraw(gy + e, rg[q]);
+    }
+  bn2_slice_sums<3>(partial, nblk, C, s, part, tot);
+  if (blockIdx.x == 0 && t < 64) {
+    const int c = s * 64 + t;
+    ws[c] = tot[0][t]; ws[C + c] = tot[1][t]; ws[2 * C + c] = tot[2][t];
+    if (dgamma) dgamma[c] += tot[2][t] / gamma[c];
+  }
+  float sc[8], sh[8], mu[8], is[8], m1[8], m2[8], mv[8], mvx[8];
+  {
+    const int c0 = s * 64 + u8 * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sc[k] = aux[c0 + k]; sh[k] = aux[C + c0 + k]; mu[k] = aux[2 * C + c0 + k]; is[k] = aux[3 * C + c0 + k];
+      m1[k] = s1[c0 + k] * inv_count; m2[k] = s1[C + c0 + k] * inv_count;
+      mv[k] = tot[0][u8 * 8 + k] * inv_count; mvx[k] = tot[1][u8 * 8 + k] * inv_count;
+    }
+  }
+  for (long long r0 = rfirst; r0 < rows; r0 += rstep * BU) {
+    if (r0 != rfirst) {
+#pragma unroll
+      for (int q = 0; q < BU; ++q)
+        if (r0 + q * rstep < rows) {
+          const long long e = (r0 + q * rstep) * C + s * 64 + u8 * 8;
+          ldraw(v + e, rv[q]); ldraw(y + e, ry[q]); ldraw(gy + e, rg[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BU; ++q) {
+      if (r0 + q * rstep >= rows) break;
+      float vv[8], vy[8], vg[8], ou[8], ox[8];
+      unraw(rv[q], vv); unraw(ry[q], vy); unraw(rg[q], vg);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = vy[k] * sc[k] + sh[k];
+        const float xh = (vy[k] - mu[k]) * is[k];
+        const float gz = vg[k] / sc[k] + m1[k] + xh * m2[k];
+        ox[k] = -sc[k] * (vv[k] * m2[k] + gz * mvx[k]);
+        const float ugz = sc[k] * (vv[k] - mv[k] - xh * mvx[k]);
+        ou[k] = z > 0.f ? ugz : slope * ugz;
+      }
+      const long long e = (r0 + q * rstep) * C + s * 64 + u8 * 8;
+      st8(u + e, ou);
+      st8(xdir + e, ox);
+    }
+  }
+}
+
+// reverse-sweep apply (bn2_reverse_apply_kernel's arithmetic) with the sums of ITS slice formed in the prologue
+template <typename T>
+__global__ __launch_bounds__(256) void bn2_reverse_apply_fused_kernel(const T* __restrict__ ua, const T* __restrict__ y, const T* __restrict__ xdir,
+                                                                      const float* __restrict__ aux, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ partial, int nblk, float* __restrict__ ws,
+                                                                      const float* __restrict__ vgy, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, float slope, float inv_count, T* __restrict__ uy,
+                                                                      long long rows, int C) {
+  __shared__ double part[4][4 * 64];
+  __shared__ float tot[4][64];
+  __builtin_amdgcn_s_setprio(JCK_BN_PRIO);
+  const int t = threadIdx.x, s = blockIdx.y, u8 = t & 7;
+  const long long rstep = (long long)gridDim.x * 32, rfirst = (long long)blockIdx.x * 32 + (t >> 3);
+  constexpr int BU = 2;
+  Raw8<T> ra[BU], ry[BU], rx[BU];
+#pragma unroll
+  for (int q = 0; q < BU; ++q)
+    if (rfirst + q * rstep < rows) {
+      const long long e = (rfirst + q * rstep) * C + s * 64 + u8 * 8;
+      ldraw(ua + e, ra[q]); ldraw(y + e, ry[q]); ldraw(xdir + e, rx[q]);
+    }
+  bn2_slice_sums<4>(partial, nblk, C, s, part, tot);
+  if (blockIdx.x == 0 && t < 64) {
+    const int c = s * 64 + t;
+    ws[c] = tot[0][t]; ws[C + c] = tot[1][t]; ws[2 * C + c] = tot[2][t]; ws[3 * C + c] = tot[3][t];
+    if (dbeta) dbeta[c] += tot[0][t];
+    if (dgamma) dgamma[c] += tot[1][t];
+  }
+  float g[8], sc[8], sh[8], mu[8], is[8], mq[8], mqx[8], kv[8];
+  {
+    const int c0 = s * 64 + u8 * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      g[k] = gamma[c0 + k];
+      sc[k] = aux[c0 + k]; sh[k] = aux[C + c0 + k]; mu[k] = aux[2 * C + c0 + k]; is[k] = aux[3 * C + c0 + k];
+      mq[k] = (g[k] * tot[0][u8 * 8 + k] + tot[2][u8 * 8 + k]) * inv_count;
+      mqx[k] = (g[k] * tot[1][u8 * 8 + k] + tot[3][u8 * 8 + k]) * inv_count;
+      kv[k] = vgy[c0 + k];
+    }
+  }
+  for (long long r0 = rfirst; r0 < rows; r0 += rstep * BU) {
+    if (r0 != rfirst) {
+#pragma unroll
+      for (int q = 0; q < BU; ++q)
+        if (r0 + q * rstep < rows) {
+          const long long e = (r0 + q * rstep) * C + s * 64 + u8 * 8;
+          ldraw(ua + e, ra[q]); ldraw(y + e, ry[q]); ldraw(xdir + e, rx[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BU; ++q) {
+      if (r0 + q * rstep >= rows) break;
+      float va[8], vy[8], vx[8], o[8];
+      unraw(ra[q], va); unraw(ry[q], vy); unraw(rx[q], vx);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = vy[k] * sc[k] + sh[k];
+        const float xh = (vy[k] - mu[k]) * is[k];
+        const float uz = z > 0.f ? va[k] : slope * va[k];
+        const float qq = g[k] * uz + vx[k];
+        o[k] = (qq - mq[k] - xh * mqx[k]) * is[k] - kv[k] * is[k] * xh * inv_count;
+      }
+      st8(uy + (r0 + q * rstep) * C + s * 64 + u8 * 8, o);
+    }
+  }
+}
+
 // h[b][j] = sum_z slab[z][b][j] + bias[j];  hd = h * mask * scale     (Linear(8392,256) finish + Dropout, model/CGAN.py:104-105,122)
 template <typename T>
 __global__ void linear_finish_kernel(const float* __restrict__ slab, int Z, long long zstride, const float* __restrict__ bias,

@@ -1428,6 +1428,16 @@ extern "C" int jck_bn2_vchain(int prec, const void* v, const void* y, const void
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 1>), dim3(blocks), dim3(256), 3 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)v, (const T*)y, (const T*)gy, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
+  if (g_bn_bwd_fuse && C >= 64 && C % 64 == 0 && (prec == JCK_PREC_BF16 || g_bn_bwd_fuse > 1)) {
+    // two launches: the apply sums the partial rows of its own channel slice (ew.hpp: bn2_vchain_apply_fused_kernel)
+    const int nsl = C / 64;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((rows + 31) / 32, std::max(1, g_bn_bwd_fuse_wgs / nsl)));
+    DISPATCH_T(prec, hipLaunchKernelGGL(bn2_vchain_apply_fused_kernel<T>, dim3(gx, nsl), dim3(256), 0, (hipStream_t)stream, (const T*)v, (const T*)y,
+                                        (const T*)gy, aux, s1, (const float*)partial, blocks, ws, gamma, dgamma, slope, 1.0f / (float)rows,
+                                        (T*)u, (T*)xdir, rows, C));
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   hipLaunchKernelGGL(bn2_sums_kernel, dim3(3 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 3, C, ws, dgamma ? 1 : 0, gamma,
                      dgamma, (float*)nullptr);
   HIPCHK(hipGetLastError());
@@ -1448,6 +1458,16 @@ extern "C" int jck_bn2_reverse(int prec, const void* ua, const void* y, const vo
   DISPATCH_T(prec, hipLaunchKernelGGL((bn2_reduce_kernel<T, 2>), dim3(blocks), dim3(256), 4 * C * rstep * sizeof(float),
                                       (hipStream_t)stream, (const T*)ua, (const T*)y, (const T*)xdir, aux, slope, partial, rows, C));
   HIPCHK(hipGetLastError());
+  if (g_bn_bwd_fuse && C >= 64 && C % 64 == 0 && (prec == JCK_PREC_BF16 || g_bn_bwd_fuse > 1)) {
+    const int nsl = C / 64;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((rows + 31) / 32, std::max(1, g_bn_bwd_fuse_wgs / nsl)));
+    DISPATCH_T(prec, hipLaunchKernelGGL(bn2_reverse_apply_fused_kernel<T>, dim3(gx, nsl), dim3(256), 0, (hipStream_t)stream, (const T*)ua,
+                                        (const T*)y, (const T*)xdir, aux, gamma, (const float*)partial, blocks, ws, vsums + 2 * C,
+                                        (dgamma && dbeta) ? dgamma : nullptr, (dgamma && dbeta) ? dbeta : nullptr, slope,
+                                        1.0f / (float)rows, (T*)uy, rows, C));
+    HIPCHK(hipGetLastError());
+    return JCK_OK;
+  }
   hipLaunchKernelGGL(bn2_sums_kernel, dim3(4 * C / 4), dim3(256), 0, (hipStream_t)stream, partial, blocks, 4, C, ws,
                      (dgamma && dbeta) ? 2 : 0, (const float*)nullptr, dgamma, dbeta);
   HIPCHK(hipGetLastError());

@@ -279,6 +279,49 @@ def test_bn_bwd_two_launches(G, prec, cfg):
         G.check(out[1][3] - 1, db_ref, 2e-5 if prec == 1 else 1e-2, "dbeta vs autograd")
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cfg", [(4096 + 7, 64), (3000, 128), (700, 512)])
+def test_bn2_chains_two_launches(G, prec, cfg):
+    """The second-order BatchNorm steps of CGAN's back-propagated penalty (jck_bn2_vchain, jck_bn2_reverse; the closed form is held
+    to fp64 autograd in tests/test_gp_double_backward_math.py and the step to the oracle in tests/test_cgan_gpu.py) as two launches -
+    reduce, then an apply whose workgroups sum the partial rows of their own channel slice - against the three launches they replace
+    (jck_tune bn_bwd_fuse 0): outputs, the sums the reverse sweep reads from the v-chain, the direct parameter gradients."""
+    rows, c = cfg
+    g = torch.Generator().manual_seed(41)
+    rnd = lambda: G.rnd(torch.randn(rows, c, generator=g), prec).to(G.DT[prec]).cuda().contiguous()
+    v, gy, ua = rnd(), rnd(), rnd()
+    y = G.rnd(torch.randn(rows, c, generator=g) * 1.5 + 0.3, prec).to(G.DT[prec]).cuda().contiguous()
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).cuda()
+    beta = (0.1 * torch.randn(c, generator=g)).cuda()
+    stats = torch.stack([y.float().sum(0), (y.float() ** 2).sum(0)]).unsqueeze(0).contiguous()
+    aux = torch.empty(4 * c, device="cuda")
+    G.lib.jck_bn_finalize_grouped(stats, 1, float(rows), gamma, beta, 1e-5, aux, None, c, 1, G.cur_stream())
+    s1 = torch.randn(2 * c, generator=g).cuda() * rows ** 0.5        # sums of a first backward: any values of that size
+    wsf = G.lib.jck_bn2_ws_floats(c)
+    out = {}
+    for fuse in (2, 0):
+        G.lib.jck_tune(b"bn_bwd_fuse", fuse)
+        try:
+            ws1 = torch.full((wsf,), float("nan"), device="cuda")
+            u, xdir = torch.empty_like(v), torch.empty_like(v)
+            dg1 = torch.ones(c, device="cuda")
+            G.lib.jck_bn2_vchain(prec, v, y, gy, aux, s1, gamma, 0.2, ws1, u, xdir, dg1, rows, c, G.cur_stream())
+            ws2 = torch.full((wsf,), float("nan"), device="cuda")
+            uy = torch.empty_like(v)
+            dg2, db2 = torch.ones(c, device="cuda"), torch.ones(c, device="cuda")
+            G.lib.jck_bn2_reverse(prec, ua, y, xdir, aux, gamma, ws1, 0.2, ws2, uy, dg2, db2, rows, c, G.cur_stream())
+            torch.cuda.synchronize()
+            out[fuse] = dict(u=u.float().cpu(), xdir=xdir.float().cpu(), uy=uy.float().cpu(), s3=ws1[:3 * c].cpu(), s4=ws2[:4 * c].cpu(),
+                             dg1=dg1.cpu(), dg2=dg2.cpu(), db2=db2.cpu())
+        finally:
+            G.lib.jck_tune(b"bn_bwd_fuse", 1)
+    for k in ("s3", "s4", "dg1", "dg2", "db2"):
+        G.check(out[2][k], out[0][k], 3e-6, f"{k} vs the sums launch")
+    for k in ("u", "xdir", "uy"):
+        assert torch.isfinite(out[2][k]).all()
+        G.check(out[2][k], out[0][k], 2e-6 if prec == 1 else 8e-3, f"{k} vs the three launches")
+
+
 @pytest.mark.parametrize("B", [16, 300, 768])
 def test_linear_fwd_split_k_on_the_lds_dma_kernel(G, B):
     """CGAN's Linear(8392,256) forward (model/CGAN.py:104) as a split-K plain GEMM: fp32 slabs [ksplit][B][N] from the LDS-DMA
