@@ -195,6 +195,7 @@ struct jck_engine {
   bool capturing = false;
   float* g1_ws = nullptr; size_t g1_ws_bytes = 0;
   float* wg_ws; size_t wg_ws_bytes;
+  long long gz_step = -1;               // the step whose set-step launch wrote its own z into g_z (G.conv1's operand) as well
   // family 1 (CGAN): Linear head, label path, second-order penalty buffers
   void *l1_w, *l1_wT;                 // packed linear1: [256][8448] and transposed [8448][256]
   void *cbuf, *cbuf2;                 // [B][8448] concat(flatten(a4), e) ; [u4 | 0]
@@ -964,12 +965,13 @@ static void launch_pad_rows(const float* z, int B, int zd, int zp, void* out, hi
   hipLaunchKernelGGL(pad_rows_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, B, zd, zp, (T*)out);
 }
 
-static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B, hipStream_t st) {
+static int g_forward(jck_engine* e, const float* z, const int64_t* labels, int B, hipStream_t st, bool z_in_place = false) {
   const int zp = z_pad(e->family);
   if (e->family == 1) {
     if (!labels) JCK_FAIL(JCK_E_ARG, "CGAN generator needs labels");
     JCK_TRY(jck_cgan_z(e->prec, z, labels, B, 100, N_CLASS, zp, e->g_z, st));            // model/CGAN.py:154-155
-  } else {
+  } else if (!z_in_place) {                 // (z_in_place: the step's set-step launch drew this z and wrote the operand rows itself)
+    e->gz_step = -1;                        // the operand rows now hold somebody else's z
     if (e->prec == JCK_PREC_BF16) launch_pad_rows<bf16_t>(z, B, 100, zp, e->g_z, st); else launch_pad_rows<float>(z, B, 100, zp, e->g_z, st);
     HIPCHK(hipGetLastError());
   }
@@ -1177,7 +1179,7 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         JCK_TRY(prep_real(e, in, B, sr));
         if (split) JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr, direct));
         if (beside) HIPCHK(hipEventRecord(e->evReal, sA));
-        JCK_TRY(g_forward(e, in->z, in->labels, B, st));
+        JCK_TRY(g_forward(e, in->z, in->labels, B, st, in->z == e->rz[in->step & 1] && e->gz_step == (long long)in->step));
         if (beside) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));     // :171, :111-113
         if (split) JCK_TRY(d_batched_forward(e, e->fake, B, 1, 2, 0, st, direct));
@@ -1245,7 +1247,7 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         if (!pre) JCK_TRY(prep_real(e, in, B, sr));                                               // :160
         if (!pre && split) JCK_TRY(d_batched_forward(e, e->real_noisy, B, 0, 1, 0, sr));          // :162
         if (beside) HIPCHK(hipEventRecord(e->evReal, sA));
-        JCK_TRY(g_forward(e, in->z, in->labels, B, st));                                          // :168-169
+        JCK_TRY(g_forward(e, in->z, in->labels, B, st, in->z == e->rz[in->step & 1] && e->gz_step == (long long)in->step));                                          // :168-169
         if (beside || pre_side) HIPCHK(hipStreamWaitEvent(st, e->evReal, 0));
         JCK_TRY(e->mix_fake_noise_interp(in, B, st));                                             // :171, :111-113
         const float tg[2] = {0.9f, 0.1f};
@@ -1269,7 +1271,7 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
         if (!in->z) JCK_FAIL(JCK_E_ARG, "G forward needs z");
         if (ov_gp && !in->alpha) JCK_FAIL(JCK_E_ARG, "alpha is needed here (the penalty pass starts inside this phase)");
         if (ov_g) { HIPCHK(hipEventRecord(e->ev0, st)); HIPCHK(hipStreamWaitEvent(e->sB, e->ev0, 0)); sG = e->sB; }
-        JCK_TRY(g_forward(e, in->z, in->labels, B, sG));                                          // :168-169
+        JCK_TRY(g_forward(e, in->z, in->labels, B, sG, in->z == e->rz[in->step & 1] && e->gz_step == (long long)in->step));                                          // :168-169
         JCK_TRY(e->mix_fake_noise(in, B, sG));   // :171
         if (ov_g) HIPCHK(hipEventRecord(e->evF, sG));
       }
@@ -1432,11 +1434,16 @@ static int set_step_impl(jck_engine* e, int step, float lr, void* stream, bool z
   if (!e || !e->bound) JCK_FAIL(JCK_E_ARG, "engine not bound");
   if (e->capturing) JCK_FAIL(JCK_E_ARG, "set_step inside a graph capture would bake one step's scalars into the graph");
   const int q = step & 1;
+  static const bool fold_z = !(getenv("JCK_FOLD_Z") && atoi(getenv("JCK_FOLD_Z")) == 0);      // (=0: pad_rows_kernel in front of G's forward)
   zero_d = zero_d && e->fold_zero && e->LD.n_params % 4 == 0;
   JCK_TRY(jck_adam_set_step(e->hp2 + 8 * q, (double)lr, 0.5, 0.999, step, e->noise_seed, (hipStream_t)stream, e->rz[q], (long long)e->B * 100,
                             e->ralpha[q], e->B, e->rmask[q], e->rmask[q] ? (long long)4 * e->B * L1_OUT : 0, 0.75f,
                             e->acc2 + (size_t)8 * e->acc_ld * q, (long long)8 * e->acc_ld,
-                            zero_d ? e->dg : nullptr, e->LD.n_params, zero_d && e->family == 1 ? e->gw1p : nullptr, (long long)L1_OUT * L1_KPAD));
+                            zero_d ? e->dg : nullptr, e->LD.n_params, zero_d && e->family == 1 ? e->gw1p : nullptr, (long long)L1_OUT * L1_KPAD,
+                            // DCGAN: the drawn z goes straight into G.conv1's operand rows too (no pad_rows launch in front of G's forward
+                            // when the step uses the engine's own z)
+                            e->family == 0 && e->fold_zero && fold_z ? e->g_z : nullptr, 100, z_pad(e->family), e->prec == JCK_PREC_F32 ? 1 : 0));
+  e->gz_step = (e->family == 0 && e->fold_zero && fold_z) ? step : -1;
   if (zero_d) e->dg_clean_step = step;
   e->acc_clean_step = step;
   e->hp_step[step & 1] = step;

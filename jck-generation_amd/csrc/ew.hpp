@@ -890,7 +890,8 @@ __global__ __launch_bounds__(256) void head_bwd_fused_kernel(const float* __rest
 // (model/CGAN.py:105) - Philox4x32-10, counter = (index/4, tensor id 8 / 9 / 10, step), key = seed.  No ATen launch is left
 // in the step, and a captured step replays with fresh draws without any copy into static buffers.
 struct StepRng { float* z; long long nz; float* alpha; long long nalpha; float* masks; long long nmask; float keep_p; float* zero; long long nzero;
-                 float* zbig[2]; long long nzbig[2]; };
+                 float* zbig[2]; long long nzbig[2];
+                 void* zpad; int zd, zp, zpad_f32; };     // zpad (optional): the same z as the rows [nz / zd][zp] of G.conv1's operand (bf16 | fp32)
 // (zero / nzero: a small buffer the same launch clears - the engine's per-step accumulator rows, instead of a memset node;
 // zbig: up to two large 16-byte aligned ranges, counts % 4 == 0 - D's gradient arena and CGAN's permuted Linear gradient, which
 // D.zero_grad() (train/dcgan_trainer.py:155) would clear with a launch of its own a few microseconds later)
@@ -918,7 +919,17 @@ static __global__ void adam_hp_kernel(float* __restrict__ hp, float step_size, f
       sincosf(6.283185307179586f * u01(o[3]), &s1, &c1);
       const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
       for (int k = 0; k < 4; ++k)
-        if (i * 4 + k < r.nz) r.z[i * 4 + k] = v[k];
+        if (i * 4 + k < r.nz) {
+          r.z[i * 4 + k] = v[k];
+          // ... and, in the same launch, into G.conv1's operand rows (what pad_rows_kernel would copy a launch later; the padding
+          // columns [zd, zp) are never written by anybody: they keep the zeros of the zero-initialised workspace)
+          if (r.zpad) {
+            const long long e = i * 4 + k, b = e / r.zd;
+            const int c = (int)(e - b * r.zd);
+            if (r.zpad_f32) reinterpret_cast<float*>(r.zpad)[b * r.zp + c] = v[k];
+            else stf(reinterpret_cast<bf16_t*>(r.zpad) + b * r.zp + c, v[k]);
+          }
+        }
     } else if (i < q0 + q1) {
       const long long j = i - q0;
       philox4x32_10((unsigned)j, (unsigned)(j >> 32), 9u, step, seed_lo, seed_hi, o);

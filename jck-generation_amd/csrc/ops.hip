@@ -1183,12 +1183,12 @@ extern "C" int jck_adam(float* p, const float* g, float* m, float* v, long long 
 // ... and (rz / ralpha / rmasks, each optional) the step's small random inputs, drawn by the same launch (ew.hpp: adam_hp_kernel)
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st, float* rz,
                       long long nz, float* ralpha, long long nalpha, float* rmasks, long long nmask, float keep_p, float* zero,
-                      long long nzero, float* zbig0, long long nzbig0, float* zbig1, long long nzbig1) {
+                      long long nzero, float* zbig0, long long nzbig0, float* zbig1, long long nzbig1, void* zpad, int zd, int zp, int zpad_f32) {
   if (step < 1) JCK_FAIL(JCK_E_ARG, "adam: step is 1-based");
   if (((uintptr_t)zbig0 | (uintptr_t)zbig1) & 15 || (nzbig0 | nzbig1) & 3) JCK_FAIL(JCK_E_ARG, "set_step: large zero ranges must be 16-byte aligned, counts % 4 == 0");
   const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
   StepRng r = {rz, rz ? nz : 0, ralpha, ralpha ? nalpha : 0, rmasks, rmasks ? nmask : 0, keep_p, zero, zero ? nzero : 0,
-               {zbig0, zbig1}, {zbig0 ? nzbig0 : 0, zbig1 ? nzbig1 : 0}};
+               {zbig0, zbig1}, {zbig0 ? nzbig0 : 0, zbig1 ? nzbig1 : 0}, (rz && zd > 0 && zp >= zd) ? zpad : nullptr, zd, zp, zpad_f32};
   const long long quads = std::max((r.nz + 3) / 4 + (r.nalpha + 3) / 4 + (r.nmask + 3) / 4, std::max(r.nzbig[0], r.nzbig[1]) / 16);
   const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 1024));
   hipLaunchKernelGGL(adam_hp_kernel, dim3(blocks), dim3(256), 0, st, hp, (float)(lr / bc1), (float)std::sqrt(bc2), (unsigned)seed,

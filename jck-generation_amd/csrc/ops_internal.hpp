@@ -38,7 +38,8 @@ int launch_igemm(int prec, const IgemmParams& p, int nch_pad, int phases, int ns
 int jck_adam_set_step(float* hp, double lr, double beta1, double beta2, int step, unsigned long long seed, hipStream_t st,
                       float* rz = nullptr, long long nz = 0, float* ralpha = nullptr, long long nalpha = 0, float* rmasks = nullptr,
                       long long nmask = 0, float keep_p = 0.75f, float* zero = nullptr, long long nzero = 0, float* zbig0 = nullptr,
-                      long long nzbig0 = 0, float* zbig1 = nullptr, long long nzbig1 = 0);
+                      long long nzbig0 = 0, float* zbig1 = nullptr, long long nzbig1 = 0, void* zpad = nullptr, int zd = 0, int zp = 0,
+                      int zpad_f32 = 0);      // zpad: the drawn z also as rows [nz / zd][zp] of type T (G.conv1's operand; padding columns untouched)
 int jck_adam_hp(float* p, const float* g, float* m, float* v, long long n, double beta1, double beta2, double eps,
                 float grad_scale, const float* hp, hipStream_t st, float* zero = nullptr, long long nzero = 0,
                 const unsigned* skip_if = nullptr);      // skip_if: device word; non-zero = leave p, m, v untouched (a grid barrier of the step timed out)
