@@ -32,12 +32,13 @@ __device__ __forceinline__ void pixel_normals(const unsigned* __restrict__ rng, 
   philox4x32_10((unsigned)i, (unsigned)(i >> 32), tensor_id, rng[2], rng[0], rng[1], o);
   const float u0 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
   const float u2 = ((float)(o[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(o[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
-  float s0, c0, s1, c1;
-  sincosf(6.283185307179586f * u1, &s0, &c0);
-  sincosf(6.283185307179586f * u3, &s1, &c1);
-  nz[0] = r0 * c0; nz[1] = r0 * s0; nz[2] = r1 * c1;
-  (void)s1;
+  // Box-Muller on the hardware transcendentals (round 5): v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in
+  // REVOLUTIONS - sin(2 pi u) is one instruction on u itself - and v_sqrt_f32 needs no fix-up here.  The library logf / sincosf (range
+  // reduction, correctly rounded) made the two noise kernels of a step ALU-bound: ~150 instructions per pixel for three normals
+  // whose last bits nobody can check (the reference's noise is torch.randn of another generator; parity tests hand the noise in).
+  const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  nz[0] = r0 * __builtin_amdgcn_cosf(u1); nz[1] = r0 * __builtin_amdgcn_sinf(u1); nz[2] = r1 * __builtin_amdgcn_cosf(u3);
 }
 
 // ------------------------------------------------------------------------------------------------------
