@@ -215,6 +215,10 @@ def measure(a, model, world, rank, dev, dist):
             # of its D(real) pass runs under G's all-reduce
             kw = dict(reduce_d=reducer("d"), reduce_g=reducer("g"), grad_scale=1.0 / world,
                       next_real=None if (cgan or not overlap["on"]) else batches[(i + 1) % 4])
+        if not kw and not cgan and overlap["on"]:
+            # one GPU: the next batch is announced all the same (as the trainer does): the forward half of its D(real) pass runs beside
+            # this step's Adam(G) + repack, where the second stream is idle - every step still does one D(real) forward
+            kw = dict(next_real=batches[(i + 1) % 4])
         eng.step_async(batches[i % 4], None, 2e-4, generator=gen, labels=labels[i % 4] if cgan else None, **kw)
 
     # every rank must hold the same parameters (the all-reduced gradients went through the same Adam); on a mismatch the guard

@@ -520,7 +520,7 @@ class DcganEngine:
         and the optimiser phases (data-parallel gradient all-reduce) and return a wait-callable.  With self.ddp_overlap
         (default; JCK_DDP_SPLIT=0 or hipgan.dist.ReplicaGuard switch it off) the DCGAN step puts D's all-reduce in two pieces
         under D's own backward, and:
-        next_real (with reduce_g; DCGAN, batched schedule, eager launches): the NEXT step's real batch.  The forward half of
+        next_real (DCGAN, batched schedule, eager launches): the NEXT step's real batch.  The forward half of
         its D(real) pass (input transform, instance noise - next_noise["n1"] when the caller supplies noise tensors -, conv
         stack + BatchNorm statistics) is then enqueued right behind the start of G's gradient all-reduce, so the collective
         runs under ~0.13 ms of compute that needs no G weights, instead of being waited for at once; the next step_async call
@@ -598,10 +598,14 @@ class DcganEngine:
         if lr_g is not None:
             si.lr = lr_g                 # the engine rewrites only the Adam scalars of the step for the new rate
         handle = reduce_g(self.arenas["g_grads"]) if reduce_g else None
+        # the forward half of the next step's D(real) pass, announced by the caller: under G's all-reduce when data parallel, and on
+        # one GPU beside this step's Adam(G) + repack and the next step's set-step launch, which leave the second stream idle
+        # (round 5: -0.4 % of the step; JCK_PREFETCH_SINGLE=0 keeps it for the data-parallel step only)
+        if (next_real is not None and self.family == 0 and self.ddp_overlap and getattr(self, "_prefetch_ok", True)
+                and not (self.graphs if graph is None else graph)
+                and (handle is not None or os.environ.get("JCK_PREFETCH_SINGLE", "1") != "0")):
+            keep += self._prefetch_real(next_real, next_noise, lr, grad_scale, st)
         if handle is not None:
-            if (next_real is not None and self.family == 0 and self.ddp_overlap and getattr(self, "_prefetch_ok", True)
-                    and not (self.graphs if graph is None else graph)):
-                keep += self._prefetch_real(next_real, next_noise, lr, grad_scale, st)     # runs under G's all-reduce
             handle()
         lib.jck_engine_phase(h, PHASE_G_STEP, C.byref(si), st)
         self.t += 1

@@ -278,9 +278,10 @@ class DCGANTrainer(Trainer):
                     break
                 real = nxt_real if nxt_real is not None else to_dev(nxt)
                 nxt = next(it, None)
-                # data parallel: the next batch is announced to the step, which runs the forward half of its D(real) pass under
-                # G's gradient all-reduce (hipgan/engine.py step_async next_real); same-sized batches only (one engine per size)
-                nxt_real = to_dev(nxt) if (nxt is not None and self.world > 1 and not self.host_rng) else None
+                # the next batch is announced to the step, which runs the forward half of its D(real) pass under G's gradient
+                # all-reduce (data parallel) / beside Adam(G) and the repack (one GPU): hipgan/engine.py step_async next_real;
+                # same-sized batches only (one engine per size)
+                nxt_real = to_dev(nxt) if (nxt is not None and not self.host_rng) else None
                 if nxt_real is not None and nxt_real.size(0) != real.size(0):
                     announce = None
                 else:

@@ -229,8 +229,10 @@ def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
     B, steps = 16, 4
     imgs = synth_images(B * steps).cuda()
     res = []
-    for announce, split in ((False, "0"), (True, "1")):      # plain order and one all-reduce per net  vs  everything that overlaps
-        os.environ["JCK_DDP_SPLIT"] = split                  # PHASE_D_LOSS_A / _B: D's arena tail is reduced under the rest of the backward
+    # plain order and one all-reduce per net  vs  everything that overlaps  vs  one GPU (no reducer) with the next batch announced
+    for announce, split in ((False, "0"), (True, "1"), (True, None)):
+        single = split is None
+        os.environ["JCK_DDP_SPLIT"] = split or "1"           # PHASE_D_LOSS_A / _B: D's arena tail is reduced under the rest of the backward
         torch.manual_seed(12345)
         g, d = build_params("dcgan")
         eng = DcganEngine(batch=B, prec=prec, device="cuda:0")
@@ -245,19 +247,22 @@ def test_d_real_forward_under_the_g_allreduce_changes_no_bit(prec, explicit):
             nz = {k: v.cuda() for k, v in _noise(B, 300 + s).items()} if explicit else None
             nn = ({k: v.cuda() for k, v in _noise(B, 300 + s + 1).items()} if explicit else None) if s + 1 < steps else None
             kw = dict(next_real=imgs[(s + 1) * B:(s + 2) * B], next_noise=nn) if (announce and s + 1 < steps) else {}
-            eng.step_async(imgs[s * B:(s + 1) * B], nz, 2e-4, reduce_d=red, reduce_g=red, generator=gen, **kw)
+            eng.step_async(imgs[s * B:(s + 1) * B], nz, 2e-4, reduce_d=None if single else red, reduce_g=None if single else red, generator=gen, **kw)
+            if announce and s + 1 < steps:
+                assert eng._prefetched_real is not None          # PHASE_D_REAL_FWD of the next step is enqueued
             scal.append(eng.scalars())
-        assert len(waits) == (3 if split == "1" else 2) * steps
+        assert len(waits) == (0 if single else 3 if split == "1" else 2) * steps
         if announce:
             assert getattr(eng, "_prefetch_ok", True)
         gs, ds = eng.state_dicts()
         res.append((scal, {k: v.clone() for k, v in gs.items()}, {k: v.clone() for k, v in ds.items()},
                     {t: {k: v.clone() for k, v in eng.named_views(t, w).items()} for t in "gd" for w in ("m",)}))
     os.environ.pop("JCK_DDP_SPLIT", None)
-    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2]), (res[0][3]["g"], res[1][3]["g"]), (res[0][3]["d"], res[1][3]["d"])):
-        for k in a:
-            assert torch.equal(a[k], b[k]), k
+    for other in (res[1], res[2]):
+        assert res[0][0] == other[0], (res[0][0], other[0])
+        for a, b in ((res[0][1], other[1]), (res[0][2], other[2]), (res[0][3]["g"], other[3]["g"]), (res[0][3]["d"], other[3]["d"])):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
 
 
 def test_split_d_pass_is_offered_only_where_it_exists():

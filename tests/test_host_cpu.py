@@ -116,9 +116,12 @@ def test_synthetic_preprocessor_duck_type(tmp_path, monkeypatch):
     loader, metric_src = pre.get_data_loader()
     assert len(loader) == 3 and hasattr(metric_src, "targets") and len(metric_src.targets) == 40
     batch = next(iter(loader))
-    assert batch[0].shape == (16, 3, 64, 64) and batch[0].dtype == torch.float32
-    assert float(batch[0].min()) >= -1.0 and float(batch[0].max()) <= 1.0
-    sizes = [b[0].shape[0] for b in loader]
+    if torch.cuda.is_available():        # (run on a GPU box: the dataset lives in HBM as uint8 and a batch is an index vector)
+        assert batch[0].size(0) == 16 and batch[0].data.dtype == torch.uint8
+    else:
+        assert batch[0].shape == (16, 3, 64, 64) and batch[0].dtype == torch.float32
+        assert float(batch[0].min()) >= -1.0 and float(batch[0].max()) <= 1.0
+    sizes = [b[0].size(0) for b in loader]
     assert sorted(sizes) == [8, 16, 16]                      # ragged last batch, like CIFAR's 50000 % 128
 
 
