@@ -1125,7 +1125,10 @@ static int phase_impl(jck_engine* e, int phase, const jck_step_inputs* in_, void
   // scalars only: the step's accumulator rows and random inputs are live)
   if (!e->capturing) {
     if (e->hp_step[in->step & 1] != in->step)
-      JCK_TRY(set_step_impl(e, in->step, in->lr, st, (phase & 0xff) == JCK_PHASE_D_LOSS || (phase & 0xff) == JCK_PHASE_D_LOSS_A || (phase & 0xff) == JCK_PHASE_D_REAL));
+      // (PHASE_D_REAL_FWD ahead of its step: D's gradients of the step before were consumed by its PHASE_D_STEP, and nothing writes
+      // them until this step's D pass - the set-step launch clears them here as well, instead of a memset in front of that pass)
+      JCK_TRY(set_step_impl(e, in->step, in->lr, st, (phase & 0xff) == JCK_PHASE_D_LOSS || (phase & 0xff) == JCK_PHASE_D_LOSS_A || (phase & 0xff) == JCK_PHASE_D_REAL ||
+                                                    (phase & 0xff) == JCK_PHASE_D_REAL_FWD));
     else if (e->hp_lr[in->step & 1] != in->lr) JCK_TRY(refresh_adam_scalars(e, in->step, in->lr, st));
   }
   e->acc = e->acc2 + (size_t)8 * e->acc_ld * e->parity;
